@@ -1,0 +1,128 @@
+"""Seeded input / weight builders shared by ``make_golden.py`` (which runs the imported REFERENCE in the
+build container) and by the tests (which re-create the same inputs for the oracle / the HIP path).
+Only torch CPU generators are used, so the tensors are reproducible wherever the same torch runs.
+"""
+import math
+
+import torch
+
+# (name, C, heads, ctx, N, T)  -- head dim = C // heads: 40 / 80 / 160 (SD-1.5) and 64 (SD-2.1 / SDXL)
+ATTN_CASES = [
+    ("sd15_c320", 320, 8, 768, 64, 4),
+    ("sd15_c640", 640, 8, 768, 36, 4),
+    ("sd15_c1280", 1280, 8, 768, 16, 16),
+    ("sd21_c640", 640, 10, 1024, 36, 4),
+    ("sdxl_c1280", 1280, 20, 2048, 16, 16),
+]
+IP_SCALES = [0.0, 0.1, 0.4, 1.0]
+
+RESAMPLER_CASES = {
+    # reference ip_adapter/test_resampler.py:18-30 shape family (pos-emb + mean-pooled latents), small dims
+    "small_posemb": dict(dim=64, depth=2, dim_head=16, heads=4, num_queries=8, embedding_dim=48, output_dim=80,
+                         ff_mult=4, max_seq_len=33, apply_pos_emb=True, num_latents_mean_pooled=4, seq=33),
+    # IPAdapterPlus.init_proj, reference ip_adapter/ip_adapter.py:292-303
+    "sd15_plus": dict(dim=768, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=768,
+                      ff_mult=4, seq=257),
+    # IPAdapterPlusXL.init_proj, reference ip_adapter/ip_adapter.py:334-345
+    "sdxl_plus": dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=16, embedding_dim=1280, output_dim=2048,
+                      ff_mult=4, seq=257),
+}
+
+
+def _u(shape, fan_in, g):
+    return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+
+def attn_weights(C, ctx, seed, with_ip=True):
+    """Parameter dict with the reference's names (Attention :113-128, IPAttnProcessor :418-419)."""
+    g = torch.Generator().manual_seed(seed)
+    w = {
+        "to_q.weight": _u((C, C), C, g),
+        "to_k.weight": _u((C, ctx), ctx, g),
+        "to_v.weight": _u((C, ctx), ctx, g),
+        "to_out.0.weight": _u((C, C), C, g),
+        "to_out.0.bias": _u((C,), C, g),
+    }
+    if with_ip:
+        w["to_k_ip.weight"] = _u((C, ctx), ctx, g)
+        w["to_v_ip.weight"] = _u((C, ctx), ctx, g)
+    return w
+
+
+def attn_inputs(C, ctx, N, T, seed, batch=2, text_len=77):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((batch, N, C), generator=g)
+    enc = torch.randn((batch, text_len + T, ctx), generator=g) * 0.5
+    return x, enc
+
+
+def case_scales(ci):
+    """all four IP scales on the first case, scale 0.4 elsewhere (keeps the fixtures small)"""
+    return IP_SCALES if ci == 0 else [0.4]
+
+
+def imageproj_params(seed=600):
+    """ImageProjModel (reference ip_adapter/ip_adapter.py:30-47): Linear(1024 -> 4*768) + LayerNorm(768)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {"proj.weight": _u((4 * 768, 1024), 1024, g), "proj.bias": _u((4 * 768,), 1024, g),
+          "norm.weight": 1 + 0.1 * torch.randn(768, generator=g), "norm.bias": 0.1 * torch.randn(768, generator=g)}
+    e = torch.randn(2, 1024, generator=g)
+    return sd, e
+
+
+GUIDANCE_KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+GUIDANCE_HW = {GUIDANCE_KEYS[0]: 64, GUIDANCE_KEYS[1]: 256, GUIDANCE_KEYS[2]: 256, GUIDANCE_KEYS[3]: 256}
+GUIDANCE_BOXES = {
+    1: [[40 / 512, 150 / 512, 230 / 512, 450 / 512]],
+    2: [[40 / 512, 150 / 512, 230 / 512, 450 / 512], [280 / 512, 150 / 512, 470 / 512, 450 / 512]],
+    4: [[40 / 512, 150 / 512, 230 / 512, 450 / 512], [280 / 512, 150 / 512, 470 / 512, 450 / 512],
+        [150 / 512, 40 / 512, 270 / 512, 160 / 512], [[330 / 512, 40 / 512, 450 / 512, 160 / 512], [0.0, 0.0, 0.12, 0.12]]],
+}
+GUIDANCE_POSITIONS = {1: [[2, 3]], 2: [[2, 3], [7]], 4: [[2, 3], [7], [10, 11, 12], [15]]}
+
+
+def guidance_attn_maps(nbox):
+    """Synthetic cond-half attention maps [1, heads=8, HW, 77] whose rows sum to one (softmax-like)."""
+    g = torch.Generator().manual_seed(800 + nbox)
+    maps = {}
+    for k in GUIDANCE_KEYS:
+        a = torch.rand(1, 8, GUIDANCE_HW[k], 77, generator=g)
+        maps[k] = a / a.sum(-1, keepdim=True)
+    return maps, g
+
+
+def guidance_ref_maps(g):
+    return [{3: {k: torch.rand(1, 8, GUIDANCE_HW[k], 1, generator=g) for k in GUIDANCE_KEYS}} for _ in range(2)]
+
+
+def resampler_input(case, seed, batch=2):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((batch, case["seq"], case["embedding_dim"]), generator=g)
+
+
+class FakeTokenizer:
+    """Whitespace tokenizer with <bos>/<eos>, standing in for the CLIP tokenizer (vocab unavailable
+    offline) in ``get_phrase_indices`` tests; implements just what reference utils/guidance.py:10-30 uses."""
+    eos_token = "<eos>"
+    bos_token = "<bos>"
+
+    def __init__(self):
+        self.vocab = {}
+        self.inv = {}
+
+    def _id(self, tok):
+        if tok not in self.vocab:
+            self.vocab[tok] = len(self.vocab)
+            self.inv[self.vocab[tok]] = tok
+        return self.vocab[tok]
+
+    def __call__(self, prompts, padding="do_not_pad", max_length=77, return_tensors="np"):
+        import numpy as np
+        out = []
+        for p in prompts:
+            toks = [self.bos_token] + p.replace("|", " | ").replace(",", " , ").split() + [self.eos_token]
+            out.append(np.array([self._id(t) for t in toks]))
+        return {"input_ids": out}
+
+    def _convert_id_to_token(self, i):
+        return self.inv[i]
