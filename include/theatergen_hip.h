@@ -1,0 +1,230 @@
+/* theatergen_hip.h — C ABI of libtheatergen_hip.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * The reference (donahowe/TheaterGen) is 100 % Python on PyTorch and has NO FFI; this boundary is new
+ * (last row).  Each entry point replaces the eager PyTorch op sequence of one piece of
+ * the per-character denoising hot path; the reference lines it replaces are cited on each declaration
+ * (paths relative to the reference repo).  The reference-side binding a maintainer would add is the
+ * ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (tensor.data_ptr()), sizes, POD descriptors in HOST memory;
+ *     no torch / C++ types.  Caller owns every buffer; outputs are caller-allocated; no ownership
+ *     transfer; nothing is retained after return.
+ *   - `stream` is a hipStream_t passed as void*; every call is stream-ordered, asynchronous and
+ *     re-entrant (no global mutable state except the thread-local error string).
+ *   - return 0 on success, negative TG_ERR_* otherwise; tg_last_error() gives the message.  The Python
+ *     shim maps any non-zero code to RuntimeError so the caller policy of reference generate.py:250-259
+ *     ("RuntimeError => skip turn") is preserved.
+ *   - dtype: TG_BF16 / TG_F16 select the storage type of activations and weights; all accumulation,
+ *     softmax and normalisation statistics are fp32.
+ *   - activations are token-major ("NHWC"): [batch, h*w, channels], channels contiguous.
+ */
+#ifndef THEATERGEN_HIP_H
+#define THEATERGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_BF16 0
+#define TG_F16 1
+
+#define TG_OK 0
+#define TG_ERR_ARG (-1)      /* invalid / unsupported argument */
+#define TG_ERR_LAUNCH (-2)   /* HIP launch error */
+#define TG_ERR_UNSUPPORTED (-3)
+
+#define TG_ACT_NONE 0
+#define TG_ACT_SILU 1
+#define TG_ACT_GELU 2        /* exact (erf) GELU */
+
+int tg_version(void);
+const char* tg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM 3x3 convolution on MFMA:   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+ * Replaces nn.Linear / nn.Conv2d of:
+ *   Attention.to_q/to_k/to_v/to_out      ip_adapter/attention_processor.py:113-128, 333-362
+ *   IPAttnProcessor.to_k_ip/to_v_ip      ip_adapter/attention_processor.py:418-419, 497-498
+ *   Transformer2DModel.proj_in/proj_out  models/transformer_2d.py:286-293, 322-328
+ *   FeedForward / GEGLU                  models/attention.py:243-292, 317-338
+ *   ResnetBlock2D conv1/conv2/shortcut/time_emb_proj, Downsample2D, Upsample2D
+ *                                        (diffusers 0.21.4; call sites models/unet_2d_blocks.py:184-195,
+ *                                         313-324, 355-362, 477-488, 578-589, 620-622, 742-753)
+ *   TimestepEmbedding                    models/unet_2d_condition.py:315-328
+ *   Resampler linears                    ip_adapter/resampler.py:13-20, 45-47, 94-97
+ * mode 0: A is row-major [M, K] (K = c0 + c1 when a1 != NULL: channel-concat of two sources with
+ *         row pitches c0 / c1 — the skip-connection cat of models/unet_2d_blocks.py:648-651 without a copy).
+ * mode 1: A is gathered on the fly from NHWC activations [batch, in_h, in_w, c0 (+c1)] for a 3x3,
+ *         pad-1 convolution with `stride` 1|2, optionally on the nearest-neighbour x2 upsampled input
+ *         (`upsample`=1, Upsample2D); W is [N, 9*(c0+c1)] tap-major (ky, kx, c).  M = batch*out_h*out_w.
+ * Epilogue (all optional, fp32):  v = acc + bias[n] + bvec[m / rows_per_batch, n] + res[m, n];
+ *         v = act(v) * out_scale;  act in TG_ACT_*;  or GEGLU (geglu=1: N counts a|gate pairs, W rows are
+ *         [a(0..N/2) ; gate(0..N/2)] as in GEGLU.proj, out is [M, N/2] = a * gelu(gate)).
+ * Output: out[m * ldc + n] for n < n_split (n_split <= 0: all); columns n >= n_split are written
+ *         TRANSPOSED per batch item, out_t[(b * (N - n_split) + n - n_split) * ldt + (m % rows_per_batch)]
+ *         (the V^T operand of tg_attention).
+ * `workspace`: fp32 scratch of `workspace_bytes`, used when the kernel splits K (small-M layers);
+ *         tg_gemm_workspace_bytes() gives the size needed for a descriptor.
+ */
+typedef struct {
+  int32_t dtype;
+  int32_t mode;
+  const void* a0;
+  const void* a1;
+  int32_t c0, c1;
+  int32_t batch, in_h, in_w, out_h, out_w;
+  int32_t stride, upsample;
+  const void* w;
+  int64_t M, N, K;
+  const void* bias;      /* [N] dtype, or NULL */
+  const void* bvec;      /* [M / rows_per_batch, N] dtype, or NULL */
+  int64_t ldbvec;        /* row pitch of bvec (elements) */
+  int64_t rows_per_batch;
+  const void* res;       /* [M, ldres] dtype, or NULL */
+  int64_t ldres;
+  int32_t act;
+  int32_t geglu;
+  float out_scale;
+  void* out;
+  int64_t ldc;
+  int64_t n_split;
+  void* out_t;
+  int64_t ldt;
+  void* workspace;
+  int64_t workspace_bytes;
+  int32_t force_split_k; /* 0 = heuristic; >0 forces that many K splits (testing) */
+  int32_t force_tile;    /* 0 = heuristic; otherwise tile config id (testing) */
+} tg_gemm_desc;
+
+int tg_gemm(const tg_gemm_desc* d, void* stream);
+int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused flash-style attention with up to two independently-normalised K/V segments:
+ *     O = softmax(s Q K0^T) V0  +  w1 * softmax(s Q K1^T) V1
+ * Segment 0 alone = AttnProcessor self/cross attention (ip_adapter/attention_processor.py:187-219,
+ * 346-357: baddbmm -> softmax -> bmm, here without materialising [B*h, N, Lk]); both segments =
+ * IPAttnProcessor's decoupled text + image cross-attention (:475-516, TWO softmaxes, w1 = scale);
+ * also PerceiverAttention (ip_adapter/resampler.py:69-75; s = d^-0.5 = (d^-0.25)^2).
+ * Layouts (elements of dtype): q[b, i, h*d + c] with row pitch q_ld and batch pitch q_bs;
+ * k{0,1}[b, j, h*d + c] likewise; vt{0,1} is V TRANSPOSED per batch: vt[b, h*d + c, j], row pitch vt_ld
+ * (multiple of 8), batch pitch vt_bs.  out[b, i, h*d + c].  head_dim in {40, 64, 80, 160} (or any
+ * multiple of 8 <= 160).  len1 == 0 disables segment 1.
+ */
+typedef struct {
+  int32_t dtype;
+  int32_t batch, heads, head_dim;
+  int32_t n_q;
+  const void* q; int64_t q_ld, q_bs;
+  const void* k0; int64_t k0_ld, k0_bs;
+  const void* vt0; int64_t vt0_ld, vt0_bs;
+  int32_t len0;
+  const void* k1; int64_t k1_ld, k1_bs;
+  const void* vt1; int64_t vt1_ld, vt1_bs;
+  int32_t len1;
+  float scale;
+  float w1;
+  void* out; int64_t out_ld, out_bs;
+} tg_attn_desc;
+
+int tg_attention(const tg_attn_desc* d, void* stream);
+
+/* Attention-probability export (the save_attn_to_dict side channel, attention_processor.py:532-551):
+ * probs[b - b0, h, i, t] = softmax_j(s q_i . k_j)[tokens[t]] for batch items b in [b0, batch), fp32 out
+ * [batch - b0, heads, n_q, n_tokens].  tokens == NULL: all `len` columns.  */
+int tg_attn_probs(int32_t dtype, int32_t batch, int32_t b0, int32_t heads, int32_t head_dim, int32_t n_q,
+                  const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld, int64_t k_bs,
+                  int32_t len, float scale, const int32_t* tokens, int32_t n_tokens, float* probs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation (HBM-bound).
+ * tg_groupnorm: GroupNorm(groups, eps) over NHWC [batch, hw, c0(+c1)] (+ optional SiLU) -> out [batch*hw, C].
+ *   Two sources = channel concat (skip connection).  `partials` fp32 scratch of
+ *   tg_groupnorm_scratch_bytes(batch, hw, groups).  Replaces ResnetBlock2D.norm1/norm2 + nonlinearity,
+ *   Transformer2DModel.norm (models/transformer_2d.py:146, 285), conv_norm_out + conv_act
+ *   (models/unet_2d_condition.py:1015-1017).
+ * tg_layernorm: LayerNorm(C, eps) per row: BasicTransformerBlock.norm1/2/3 (models/attention.py:186, 206, 226),
+ *   Resampler norms (ip_adapter/resampler.py:43-44, 66-67, 100).  gamma/beta may be NULL.
+ */
+int64_t tg_groupnorm_scratch_bytes(int32_t batch, int64_t hw, int32_t groups);
+int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch, int64_t hw,
+                 int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu, void* out,
+                 void* partials, void* stream);
+int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, const void* gamma,
+                 const void* beta, void* out, int64_t ldo, void* stream);
+
+/* out[m, j] = x[m, j] * gelu(x[m, inner + j])  (GEGLU.forward, models/attention.py:337-338) */
+int tg_geglu(int32_t dtype, const void* x, int64_t rows, int64_t inner, void* out, void* stream);
+/* out = act(x) elementwise (n elements) */
+int tg_act(int32_t dtype, const void* x, int64_t n, int32_t act, void* out, void* stream);
+/* out = a + b (n elements; ControlNet residual injection, models/unet_2d_condition.py:938-946, 975-976) */
+int tg_add(int32_t dtype, const void* a, const void* b, int64_t n, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * UNet boundary convolutions (tiny channel counts, direct):
+ * tg_conv_in : sample NCHW [batch, cin, h, w] (src_dtype: 0 bf16, 1 f16, 2 f32) -> NHWC [batch, h*w, cout],
+ *              3x3 pad 1, weight [cout, 3, 3, cin] + bias  (conv_in, models/unet_2d_condition.py:294-297, 879)
+ * tg_conv_out: NHWC [batch, h*w, cin] (already GroupNorm+SiLU'ed) -> NCHW fp32|dtype [batch, cout, h, w]
+ *              (conv_out, models/unet_2d_condition.py:583-586, 1018)
+ */
+int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, int32_t batch, int32_t cin, int32_t h, int32_t w,
+               const void* weight, const void* bias, int32_t cout, void* out, void* stream);
+int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_t h, int32_t w, const void* weight,
+                const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream);
+
+/* Sinusoidal timestep embedding (diffusers Timesteps; call site models/unet_2d_condition.py:315-316, 819):
+ * out[r, :] for r < rows; t read from DEVICE fp32 array `t` (stride t_stride, 0 = broadcast one value). */
+int tg_timestep_embedding(int32_t dtype, const float* t, int32_t t_stride, int32_t rows, int32_t dim,
+                          int32_t flip_sin_to_cos, float freq_shift, void* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Step epilogue: CFG combine + DDIM update (+ frozen-mask replace) in one pass over the latents
+ * (models/pipelines.py:441-447 and 833-834).  noise_pred: [2*n_img, C, h, w] fp32 (uncond half first) when
+ * has_cfg, else [n_img, C, h, w] used as the model output directly (plain scheduler.step);
+ * latents fp32 [n_img, C, h, w] updated IN PLACE.  coef: DEVICE fp32 table [n_steps][4] =
+ * {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_idx: DEVICE int32 (read, then
+ * incremented when `advance`).  prediction_type 0 = epsilon, 1 = v_prediction.
+ * frozen (may be NULL): fp32 [n_steps+1, n_img, C, h, w]; the row step_idx+1 is blended in with
+ * frozen_mask fp32 [n_img|1, h, w] while step_idx < frozen_steps.  history (may be NULL):
+ * fp32 [n_steps+1, n_img, C, h, w], row step_idx+1 receives the new latents (latents_all, :449-453, 488).
+ */
+int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int32_t chw, int32_t hw,
+                     int32_t has_cfg, float guidance_scale, const float* coef, int32_t* step_idx, int32_t advance,
+                     int32_t prediction_type, const float* frozen, const float* frozen_mask, int32_t mask_per_img,
+                     int32_t frozen_steps, float* history, void* model_in, int32_t model_in_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Latent utilities (utils/latents.py, utils/utils.py) on fp32 latents [.., h, w]:
+ * tg_blend_latents : bg (1-M) + (bg sqrt(1-r) + fg sqrt(r)) M                      (latents.py:156-166)
+ * tg_shift         : zero-filled integer shift of the last two dims               (utils.py:143-178)
+ * tg_masked_compose: dst = dst (1-M) + src M over `planes` planes of h*w           (latents.py:203-214)
+ */
+int tg_blend_latents(const float* bg, const float* fg, const float* mask, int32_t planes, int32_t hw, float ratio,
+                     float sigma, float* out, void* stream);
+int tg_shift(const float* src, int64_t planes, int32_t h, int32_t w, int32_t dx, int32_t dy, float* dst, void* stream);
+int tg_masked_compose(float* dst, const float* src, const float* mask, int64_t planes, int32_t hw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-box guidance reductions (utils/guidance.py:91-148, 223-233) on an attention map
+ * attn fp32 [heads, hw, n_tok]; mask fp32 [hw] (box mask).  One (token) column per call-row:
+ * tg_guidance_topk: for each head: fg = mean(topk_{k_fg}(A*M)), bg = mean(topk_{k_bg}(A*(1-M)));
+ *    out[0] += fg_w * sum_h (1 - fg) + bg_w * sum_h bg   (scaled by `scale`)
+ *    grad (may be NULL) [heads, hw, n_tok] += d out / d A.
+ * tg_guidance_ratio: out[0] += scale * mean_h (1 - sum(A*M)/sum(A))^2  (+ grad)
+ */
+int tg_guidance_topk(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* mask,
+                     int32_t k_fg, int32_t k_bg, float fg_w, float bg_w, float scale, float* out, float* grad,
+                     void* stream);
+int tg_guidance_ratio(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* mask,
+                      float scale, float* out, float* grad, void* stream);
+
+/* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
+int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

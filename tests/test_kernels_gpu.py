@@ -1,0 +1,385 @@
+"""GPU: every HIP kernel family against a plain PyTorch fp32 CPU reference of the same op, called through
+the C ABI (theatergen_amd.ops -> libtheatergen_hip.so).  Inputs are rounded to the storage dtype first so the
+comparison isolates the kernel (fp32 accumulate) from input quantisation.
+
+Tolerances (stated per test): outputs are stored in bf16 (8 mantissa bits) / fp16 (11 bits):
+  bf16: |err| <= 1.0e-2 * max|ref| + small abs;  fp16: 2.5e-3 * max|ref|.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rel_tol(dtype):
+    return 1.0e-2 if dtype == torch.bfloat16 else 2.5e-3
+
+
+def check(got, ref, dtype, what="", scale=1.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    tol = rel_tol(dtype) * scale * max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"{what}: max err {err:.4e} > tol {tol:.4e} (max|ref| {ref.abs().max().item():.3e})"
+
+
+def rnd(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def test_library_loads_and_reports_version():
+    from theatergen_amd import _lib
+    assert _lib.lib().tg_version() >= 100
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mfma_layout_probe(dtype):
+    """A[i][k], B[k][j] fragments laid out as the kernels assume: lane l holds row/col l&31, k = 8*(l>>5)+e."""
+    from theatergen_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    A = rnd((32, 16), dtype, g)
+    Bm = rnd((16, 32), dtype, g)
+    af = torch.empty(64, 8, dtype=dtype)
+    bf = torch.empty(64, 8, dtype=dtype)
+    for l in range(64):
+        for e in range(8):
+            af[l, e] = A[l & 31, 8 * (l >> 5) + e]
+            bf[l, e] = Bm[8 * (l >> 5) + e, l & 31]
+    d = torch.zeros(64, 16, dtype=torch.float32, device=dev)
+    afd, bfd = af.to(dev), bf.to(dev)
+    _lib.check(_lib.lib().tg_debug_mfma32(0 if dtype == torch.bfloat16 else 1, afd.data_ptr(), bfd.data_ptr(), d.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref = A.float() @ Bm.float()
+    got = torch.empty(32, 32)
+    dc = d.cpu()
+    for l in range(64):
+        for r in range(16):
+            got[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = dc[l, r]
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+GEMM_SHAPES = [
+    # M, N, K
+    (256, 320, 320), (8192, 320, 320), (2, 1280, 320), (154, 640, 768), (130, 1280, 2560), (512, 2560, 320),
+    (100, 64, 72),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_plain(dtype, shape):
+    from theatergen_amd import ops
+    dev = _dev()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias = rnd((N,), dtype, g)
+    ref = a.float() @ w.float().t() + bias.float()
+    out = ops.linear(a.to(dev), w.to(dev), bias.to(dev))
+    check(out, ref, dtype, f"gemm {shape}")
+    for tile in (1, 2, 3, 4):
+        out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), force_tile=tile)
+        check(out, ref, dtype, f"gemm {shape} tile {tile}")
+    if K >= 256:
+        out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), force_split_k=3, force_tile=2)
+        check(out, ref, dtype, f"gemm {shape} split-K 3")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    from theatergen_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    B, rows, N, K = 3, 50, 192, 128
+    M = B * rows
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias, bvec, res = rnd((N,), dtype, g), rnd((B, N), dtype, g), rnd((M, N), dtype, g)
+    base = a.float() @ w.float().t() + bias.float() + bvec.float().repeat_interleave(rows, 0) + res.float()
+    for act, fn in ((ops.ACT_NONE, lambda v: v), (ops.ACT_SILU, F.silu), (ops.ACT_GELU, F.gelu)):
+        for split in (0, 2):
+            out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), bvec=bvec.to(dev), rows_per_batch=rows, res=res.to(dev),
+                             act=act, out_scale=0.5, force_split_k=split)
+            check(out, fn(base) * 0.5, dtype, f"epilogue act={act} split={split}")
+    # two-source A (channel concat) + transposed tail columns (the V^T operand of attention)
+    a0, a1 = rnd((M, 64), dtype, g), rnd((M, 128), dtype, g)
+    w2 = rnd((N, 192), dtype, g, 1 / math.sqrt(192))
+    ref = torch.cat([a0, a1], 1).float() @ w2.float().t()
+    n_split = 128
+    ldt = 56
+    out = torch.zeros((M, n_split), dtype=dtype, device=dev)
+    out_t = torch.zeros((B, N - n_split, ldt), dtype=dtype, device=dev)
+    ops.gemm(a0.to(dev), w2.to(dev), M, N, 192, a1=a1.to(dev), c0=64, c1=128, rows_per_batch=rows, out=out,
+             n_split=n_split, out_t=out_t, ldt=ldt)
+    check(out, ref[:, :n_split], dtype, "two-source main")
+    ref_t = ref[:, n_split:].reshape(B, rows, N - n_split).permute(0, 2, 1)
+    check(out_t[:, :, :rows], ref_t, dtype, "transposed tail")
+    assert (out_t[:, :, rows:] == 0).all()
+
+
+CONV_CASES = [
+    # batch, h, w, cin, c1, cout, stride, upsample
+    (2, 16, 16, 64, 0, 64, 1, False), (2, 16, 16, 128, 0, 64, 2, False), (1, 8, 8, 64, 0, 128, 1, True),
+    (2, 8, 8, 128, 64, 128, 1, False), (2, 64, 64, 320, 0, 320, 1, False), (3, 5, 7, 64, 0, 64, 1, False),
+    (2, 7, 7, 64, 0, 64, 2, False), (2, 8, 8, 1280, 1280, 1280, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(dtype, case):
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    B, h, w, cin, c1, cout, stride, up = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    ctot = cin + c1
+    x = rnd((B, ctot, h, w), dtype, g)
+    wt = rnd((cout, ctot, 3, 3), dtype, g, 1 / math.sqrt(9 * ctot))
+    bias = rnd((cout,), dtype, g)
+    xin = x.float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1)
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, ctot)
+    x0 = tok[:, :cin].contiguous().to(dev)
+    x1 = tok[:, cin:].contiguous().to(dev) if c1 else None
+    out = ops.conv3x3(x0, pack_conv3x3(wt).to(dev), B, h, w, cin, x1=x1, c1=c1, stride=stride, upsample=up, bias=bias.to(dev))
+    oh, ow = ref.shape[-2:]
+    got = out.float().cpu().reshape(B, oh, ow, cout).permute(0, 3, 1, 2)
+    check(got, ref, dtype, f"conv {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 64, 320, 0, True), (2, 256, 1280, 640, True), (1, 16, 64, 0, False), (3, 100, 128, 64, True),
+                                  (2, 4096, 320, 0, True), (2, 64, 2560, 0, True)])
+def test_groupnorm(dtype, case):
+    from theatergen_amd import ops
+    dev = _dev()
+    B, hw, c0, c1, silu = case
+    g = torch.Generator().manual_seed(hw + c0)
+    C = c0 + c1
+    x = rnd((B, hw, C), dtype, g) + 0.5
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dtype), (0.1 * torch.randn(C, generator=g)).to(dtype)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    x0 = x[:, :, :c0].reshape(B * hw, c0).contiguous().to(dev)
+    x1 = x[:, :, c0:].reshape(B * hw, c1).contiguous().to(dev) if c1 else None
+    out = ops.groupnorm(x0, B, hw, 32, 1e-5, gamma.to(dev), beta.to(dev), silu=silu, x1=x1)
+    check(out.reshape(B, hw, C), ref, dtype, f"groupnorm {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(8192, 320), (300, 1280), (33, 768), (32, 2048), (5, 64)])
+def test_layernorm(dtype, shape):
+    from theatergen_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(shape[0])
+    rows, C = shape
+    x = rnd((rows, C), dtype, g) + 0.3
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dtype), (0.1 * torch.randn(C, generator=g)).to(dtype)
+    ref = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    out = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev))
+    check(out, ref, dtype, f"layernorm {shape}")
+    out = ops.layernorm(x.to(dev), None, None)
+    check(out, F.layer_norm(x.float(), (C,)), dtype, f"layernorm no-affine {shape}")
+
+
+def _attn_ref(q, k, v, heads, scale):
+    B, N, Cc = q.shape
+    d = Cc // heads
+    qh = q.float().reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    p = (qh @ kh.transpose(-1, -2) * scale).softmax(-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, N, Cc), p
+
+
+ATTN_CASES = [
+    # heads, d, n_q, len0, len1
+    (8, 40, 256, 256, 0), (8, 40, 200, 77, 4), (8, 80, 64, 77, 16), (8, 160, 64, 64, 0), (8, 160, 36, 77, 4),
+    (10, 64, 144, 144, 0), (20, 64, 96, 77, 16), (2, 32, 70, 70, 0), (4, 128, 16, 81, 0), (4, 16, 8, 41, 0),
+    (8, 40, 1024, 1024, 0), (12, 64, 16, 273, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(dtype, case):
+    from theatergen_amd import ops
+    dev = _dev()
+    heads, d, n_q, len0, len1 = case
+    B = 2
+    Cc = heads * d
+    g = torch.Generator().manual_seed(sum(case))
+    q = rnd((B, n_q, Cc), dtype, g)
+    k0, v0 = rnd((B, len0, Cc), dtype, g), rnd((B, len0, Cc), dtype, g)
+    scale = d ** -0.5
+    ref, _ = _attn_ref(q, k0, v0, heads, scale)
+    w1 = 0.4
+    pad0 = (len0 + 7) // 8 * 8
+    # V^T buffers: padding columns deliberately poisoned with NaN bits: the kernel must not read them as data
+    vt0 = torch.full((B, Cc, pad0), float("nan"), dtype=dtype)
+    vt0[:, :, :len0] = v0.permute(0, 2, 1)
+    args = dict(k1=None, vt1=None, len1=0, w1=0.0)
+    if len1:
+        k1, v1 = rnd((B, len1, Cc), dtype, g), rnd((B, len1, Cc), dtype, g)
+        ref = ref + w1 * _attn_ref(q, k1, v1, heads, scale)[0]
+        pad1 = (len1 + 7) // 8 * 8
+        vt1 = torch.full((B, Cc, pad1), float("nan"), dtype=dtype)
+        vt1[:, :, :len1] = v1.permute(0, 2, 1)
+        k1d, vt1d = k1.to(dev), vt1.to(dev)
+        args = dict(k1=k1d, k1_ld=Cc, k1_bs=len1 * Cc, vt1=vt1d, vt1_ld=pad1, vt1_bs=Cc * pad1, len1=len1, w1=w1)
+    out = torch.zeros((B, n_q, Cc), dtype=dtype, device=dev)
+    ops.attention(q.to(dev), Cc, n_q * Cc, k0.to(dev), Cc, len0 * Cc, vt0.to(dev), pad0, Cc * pad0, len0, B, heads, d, n_q,
+                  scale, out, Cc, n_q * Cc, **args)
+    check(out, ref, dtype, f"attention {case}", scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_forced_rescale(dtype):
+    """Online-softmax rescale branch: one key far above the rest in a LATE tile (cdna guide rule 26)."""
+    from theatergen_amd import ops
+    dev = _dev()
+    heads, d, n_q, len0, B = 2, 64, 64, 320, 1
+    Cc = heads * d
+    g = torch.Generator().manual_seed(99)
+    q, k0, v0 = rnd((B, n_q, Cc), dtype, g), rnd((B, len0, Cc), dtype, g), rnd((B, len0, Cc), dtype, g)
+    k0[0, 300] = (q[0, 5].float() * 3).to(dtype)      # spike for query 5 in tile 4
+    k0[0, 10] = (q[0, 40].float() * 2).to(dtype)      # and an early one for query 40
+    ref, _ = _attn_ref(q, k0, v0, heads, d ** -0.5)
+    vt0 = v0.permute(0, 2, 1).contiguous()
+    out = torch.zeros((B, n_q, Cc), dtype=dtype, device=dev)
+    ops.attention(q.to(dev), Cc, n_q * Cc, k0.to(dev), Cc, len0 * Cc, vt0.to(dev), len0, Cc * len0, len0, B, heads, d, n_q,
+                  d ** -0.5, out, Cc, n_q * Cc)
+    check(out, ref, dtype, "attention forced rescale", scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attn_probs(dtype):
+    from theatergen_amd import ops
+    dev = _dev()
+    heads, d, n_q, ln, B = 8, 40, 64, 77, 2
+    Cc = heads * d
+    g = torch.Generator().manual_seed(5)
+    q, k = rnd((B, n_q, Cc), dtype, g), rnd((B, ln, Cc), dtype, g)
+    _, p = _attn_ref(q, k, k, heads, d ** -0.5)
+    got = ops.attn_probs(q.to(dev), Cc, n_q * Cc, k.to(dev), Cc, ln * Cc, B, 0, heads, d, n_q, ln, d ** -0.5)
+    assert torch.allclose(got.cpu(), p, rtol=2e-3, atol=2e-5)
+    tok = torch.tensor([1, 3, 70], dtype=torch.int32, device=dev)
+    got = ops.attn_probs(q.to(dev), Cc, n_q * Cc, k.to(dev), Cc, ln * Cc, B, 1, heads, d, n_q, ln, d ** -0.5, tokens=tok)
+    assert torch.allclose(got.cpu(), p[1:, :, :, [1, 3, 70]], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise_and_boundary_convs(dtype):
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    x = rnd((300, 512), dtype, g)
+    ref = x[:, :256].float() * F.gelu(x[:, 256:].float())
+    check(ops.geglu(x.to(dev)), ref, dtype, "geglu")
+    check(ops.act(x.to(dev), ops.ACT_SILU), F.silu(x.float()), dtype, "silu")
+    y = rnd((300, 512), dtype, g)
+    check(ops.add(x.to(dev), y.to(dev)), x.float() + y.float(), dtype, "add")
+    # conv_in: NCHW fp32 sample -> token-major
+    s = torch.randn(2, 4, 16, 16, generator=g)
+    w, b = rnd((64, 4, 3, 3), dtype, g, 1 / 6), rnd((64,), dtype, g)
+    ref = F.conv2d(s, w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 64)
+    check(ops.conv_in(s.to(dev), pack_conv3x3(w).to(dev), b.to(dev), 64, dtype), ref, dtype, "conv_in")
+    # conv_out: token-major -> NCHW fp32
+    xin = rnd((2, 64, 16, 16), dtype, g)
+    w, b = rnd((4, 64, 3, 3), dtype, g, 1 / 24), rnd((4,), dtype, g)
+    ref = F.conv2d(xin.float(), w.float(), b.float(), padding=1)
+    tok = xin.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
+    got = ops.conv_out(tok.to(dev), pack_conv3x3(w).to(dev), b.to(dev), 2, 16, 16, 4, torch.float32)
+    assert torch.allclose(got.cpu(), ref, rtol=1e-3, atol=1e-3)
+    # timestep embedding
+    from oracle.unet import timestep_sinusoid
+    t = torch.tensor([981.0, 1.0, 500.0])
+    got = ops.timestep_embedding(t.to(dev), 3, 320, True, 0.0, dtype, t_stride=1)
+    check(got, timestep_sinusoid(t, 320, True, 0.0), dtype, "timestep embedding")
+
+
+def test_step_epilogue_and_latent_ops():
+    """fp32 paths: tolerance 1e-5 relative (fma contraction differences only)."""
+    from oracle import ddim as oddim
+    from oracle import box_geometry as geo
+    from oracle import latent_ops as ol
+    from theatergen_amd import ops
+    from theatergen_amd.scheduler import DDIMScheduler
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for pred in ("epsilon", "v_prediction"):
+        osch = oddim.DDIMSchedule(prediction_type=pred)
+        osch.set_timesteps(50)
+        sch = DDIMScheduler(prediction_type=pred)
+        sch.set_timesteps(50)
+        coef = sch.coef_table().to(dev)
+        lat = torch.randn(2, 4, 64, 64, generator=g)
+        frozen = torch.randn(51, 2, 4, 64, 64, generator=g)
+        mask = (torch.rand(64, 64, generator=g) > 0.5).float()
+        hist = torch.zeros(51, 2, 4, 64, 64, device=dev)
+        lat_d = lat.clone().to(dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        ref = lat.clone()
+        model_in = torch.zeros(4, 4, 64, 64, dtype=torch.bfloat16, device=dev)
+        for i in range(3):
+            npred = torch.randn(4, 4, 64, 64, generator=g)
+            t = int(osch.timesteps[i])
+            ref = oddim.step_epilogue(osch, npred, t, ref, 7.5, frozen[i + 1] if i < 2 else None, mask)
+            ops.step_epilogue(npred.to(dev), lat_d, 7.5, coef, step, prediction_type=0 if pred == "epsilon" else 1,
+                              frozen=frozen.to(dev), frozen_mask=mask.to(dev), frozen_steps=2, history=hist, model_in=model_in)
+            assert torch.allclose(lat_d.cpu(), ref, rtol=1e-5, atol=1e-5), f"step {i} {pred}"
+            assert torch.equal(hist[i + 1], lat_d)
+            assert torch.equal(model_in[:2].float(), lat_d.to(torch.bfloat16).float())
+        assert int(step.item()) == 3
+    # blend / shift / compose
+    bg, fg = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
+    m = geo.proportion_to_mask([0.1, 0.2, 0.6, 0.9], 64, 64)
+    got = ops.blend_latents(bg.to(dev), fg.to(dev), m.to(dev), 0.01)
+    assert torch.allclose(got.cpu(), ol.blend_latents(bg, fg, m, 0.01), rtol=1e-6, atol=1e-6)
+    t = torch.randn(5, 1, 4, 64, 64, generator=g)
+    for dx, dy in ((8, -16), (-24, 0), (0, 0), (64, 8)):
+        assert torch.equal(ops.shift(t.to(dev), dx, dy).cpu(), geo.shift_tensor(t, dx, dy))
+    dst, src = torch.randn(51, 1, 4, 64, 64, generator=g), torch.randn(51, 1, 4, 64, 64, generator=g)
+    want = dst * (1 - m) + src * m
+    got = ops.masked_compose_(dst.clone().to(dev), src.to(dev), m.to(dev))
+    assert torch.allclose(got.cpu(), want, rtol=1e-6, atol=1e-6)
+
+
+def test_guidance_reductions():
+    from oracle import guidance_loss as og
+    from tests.golden import gen_common as gc
+    from theatergen_amd import guidance as G
+    dev = _dev()
+    keys = gc.GUIDANCE_KEYS
+    for nbox in (1, 2, 4):
+        maps, _ = gc.guidance_attn_maps(nbox)
+        for kw in (dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0),
+                   dict(use_ratio_based_loss=True)):
+            saved = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+            ref = og.compute_ca_lossv3(saved, gc.GUIDANCE_BOXES[nbox], gc.GUIDANCE_POSITIONS[nbox], keys, **kw)
+            ref_grads = torch.autograd.grad(ref, [saved[k] for k in keys])
+            dmaps = {k: v.to(dev) for k, v in maps.items()}
+            loss, grads = G.compute_ca_lossv3(dmaps, gc.GUIDANCE_BOXES[nbox], gc.GUIDANCE_POSITIONS[nbox], keys,
+                                              return_grads=True, **kw)
+            assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (nbox, kw, loss.item(), ref.item())
+            for k, rg in zip(keys, ref_grads):
+                assert torch.allclose(grads[k].cpu(), rg, rtol=1e-4, atol=1e-7), (nbox, k)

@@ -1,0 +1,90 @@
+"""ctypes binding of libtheatergen_hip.so (C ABI: include/theatergen_hip.h).
+
+The library is the ONLY compute path: ``lib()`` raises RuntimeError if it is missing (no CPU / PyTorch
+fallback).  Any non-zero return code becomes ``RuntimeError(tg_last_error())`` so callers keep the policy of
+reference ``generate.py:250-259`` (RuntimeError => skip the turn).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtheatergen_hip.so")
+
+TG_BF16, TG_F16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("mode", i32), ("a0", vp), ("a1", vp), ("c0", i32), ("c1", i32),
+        ("batch", i32), ("in_h", i32), ("in_w", i32), ("out_h", i32), ("out_w", i32),
+        ("stride", i32), ("upsample", i32), ("w", vp), ("M", i64), ("N", i64), ("K", i64),
+        ("bias", vp), ("bvec", vp), ("ldbvec", i64), ("rows_per_batch", i64), ("res", vp), ("ldres", i64),
+        ("act", i32), ("geglu", i32), ("out_scale", f32), ("out", vp), ("ldc", i64), ("n_split", i64),
+        ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
+        ("force_split_k", i32), ("force_tile", i32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("batch", i32), ("heads", i32), ("head_dim", i32), ("n_q", i32),
+        ("q", vp), ("q_ld", i64), ("q_bs", i64),
+        ("k0", vp), ("k0_ld", i64), ("k0_bs", i64), ("vt0", vp), ("vt0_ld", i64), ("vt0_bs", i64), ("len0", i32),
+        ("k1", vp), ("k1_ld", i64), ("k1_bs", i64), ("vt1", vp), ("vt1_ld", i64), ("vt1_bs", i64), ("len1", i32),
+        ("scale", f32), ("w1", f32), ("out", vp), ("out_ld", i64), ("out_bs", i64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/theatergen_hip.h
+SIGNATURES = {
+    "tg_version": (i32, []),
+    "tg_last_error": (C.c_char_p, []),
+    "tg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "tg_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
+    "tg_attention": (i32, [C.POINTER(AttnDesc), vp]),
+    "tg_attn_probs": (i32, [i32, i32, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, f32, vp, i32, vp, vp]),
+    "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),
+    "tg_groupnorm": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, i32, vp, vp, vp]),
+    "tg_layernorm": (i32, [i32, vp, i64, i32, i64, f32, vp, vp, vp, i64, vp]),
+    "tg_geglu": (i32, [i32, vp, i64, i64, vp, vp]),
+    "tg_act": (i32, [i32, vp, i64, i32, vp, vp]),
+    "tg_add": (i32, [i32, vp, vp, i64, vp, vp]),
+    "tg_conv_in": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "tg_conv_out": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "tg_timestep_embedding": (i32, [i32, vp, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "tg_step_epilogue": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp]),
+    "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, vp]),
+    "tg_shift": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
+    "tg_masked_compose": (i32, [vp, vp, vp, i64, i32, vp]),
+    "tg_guidance_topk": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, f32, f32, f32, vp, vp, vp]),
+    "tg_guidance_ratio": (i32, [vp, i32, i32, i32, i32, vp, f32, vp, vp, vp]),
+    "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"theatergen_amd: HIP library not found at {LIB_PATH}; build it with "
+                "`python -m theatergen_amd.build` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().tg_last_error()
+        raise RuntimeError(f"theatergen_hip error {rc}: {msg.decode() if msg else ''}")

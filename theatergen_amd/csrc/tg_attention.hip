@@ -1,0 +1,387 @@
+// Flash-style fused attention on MFMA for gfx950 (include/theatergen_hip.h: tg_attention, tg_attn_probs).
+//
+//   O = softmax(s Q K0^T) V0  +  w1 * softmax(s Q K1^T) V1        (segment 1 optional, len1 <= 64)
+//
+// No [B*h, N, Lk] probability tensor ever reaches HBM (the reference materialises it three times:
+// ip_adapter/attention_processor.py:187-219).  Segment 1 is IP-Adapter's image-token K/V: it gets its OWN
+// softmax (two independent normalisations, attention_processor.py:482, :503, :516) — its K/V tile is staged in
+// the same LDS buffers right after the text segment and folded into the same accumulator as
+// (w1 / l1) * exp(s1 - m1), so decoupled cross-attention costs one extra tile, not a second kernel.
+//
+// Work split: block = 4 waves x 32 queries; K tile [64 keys][d] and V^T tile [d][64 keys] in LDS, shared by
+// the 4 waves.  Everything is computed TRANSPOSED so that lane&31 is the query:
+//   S^T[key][q]  = mfma32x32x16(A = K rows,   B = Q rows)      -> a lane holds 32 of the 64 scores of ITS query
+//   O^T[d][q]   += mfma32x32x16(A = V^T rows, B = P^T)         -> P^T is consumed straight from the S^T
+// registers (the MFMA C layout of S^T is a valid B-operand layout once V^T's keys are read in the matching
+// permuted order: two ds_read_b64 per fragment), running max / sum / rescale are lane-local, and the only
+// cross-lane traffic of the online softmax is one exchange with lane^32.
+// head_dim 40 / 80 (SD-1.5) are zero-padded to 48 / 80 for QK^T (K of the MFMA) and 64 / 96 rows for PV.
+#include "tg_common.h"
+
+namespace {
+
+constexpr int KV = 64;        // keys per tile
+constexpr int VT_LDP = KV + 8;  // V^T tile row pitch (elements)
+
+struct AttnParams {
+  int heads, hd, n_q;
+  const void* q; long q_ld, q_bs;
+  const void* k0; long k0_ld, k0_bs;
+  const void* vt0; long vt0_ld, vt0_bs;
+  int len0;
+  const void* k1; long k1_ld, k1_bs;
+  const void* vt1; long vt1_ld, vt1_bs;
+  int len1;
+  float scale_log2;
+  float w1;
+  void* out; long out_ld, out_bs;
+};
+
+template <typename T, int DPAD, int DV>
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+  typedef typename Vec<T>::v8 V8;
+  typedef typename Vec<T>::v4 V4;
+  constexpr int K_LDP = DPAD + 8;
+  constexpr int KCH = DPAD / 8;                 // 16-B chunks per K row
+  constexpr int K_ITEMS = (KV * KCH + 255) / 256;
+  constexpr int V_ITEMS = (DV * (KV / 8) + 255) / 256;
+  constexpr int NKS = DPAD / 16;
+  constexpr int DT = DV / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);            // [KV][K_LDP]
+  T* sV = sK + KV * K_LDP;                       // [DV][VT_LDP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int HD = p.hd;
+  const long qrow = (long)blockIdx.x * 128 + wave * 32 + l31;
+  const bool q_ok = qrow < p.n_q;
+
+  // Q fragments (B operand): this lane's query row, d = ks*16 + hi*8 .. +8
+  V8 qf[NKS];
+  {
+    const T* qp = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + qrow * p.q_ld + (long)h * HD;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int d = ks * 16 + hi * 8;
+      V8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(0.f);
+      if (q_ok && d < HD) v = *reinterpret_cast<const V8*>(qp + d);
+      qf[ks] = v;
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  u32x4 kreg[K_ITEMS], vreg[V_ITEMS];
+
+  auto load_regs = [&](const void* kbase, long k_ld, long k_bs, const void* vbase, long vt_ld, long vt_bs, int len, int kv0) {
+    const T* kp = reinterpret_cast<const T*>(kbase) + (long)b * k_bs + (long)h * HD;
+    const T* vp = reinterpret_cast<const T*>(vbase) + (long)b * vt_bs + (long)h * HD * vt_ld;
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < KV * KCH && kv0 + row < len && ch * 8 < HD) v = *reinterpret_cast<const u32x4*>(kp + (long)(kv0 + row) * k_ld + ch * 8);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, ch = idx & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int c0 = kv0 + ch * 8;
+      if (idx < DV * 8 && row < HD && c0 < len) {
+        v = *reinterpret_cast<const u32x4*>(vp + (long)row * vt_ld + c0);
+        if (c0 + 8 > len) {  // partial chunk: padding columns may hold anything -> force exact zeros
+          V8 e = __builtin_bit_cast(V8, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j >= len) e[j] = from_f32<T>(0.f);
+          v = __builtin_bit_cast(u32x4, e);
+        }
+      }
+      vreg[i] = v;
+    }
+  };
+
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      if (idx < KV * KCH) *reinterpret_cast<u32x4*>(sK + row * K_LDP + ch * 8) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, ch = idx & 7;
+      if (idx < DV * 8) *reinterpret_cast<u32x4*>(sV + row * VT_LDP + ch * 8) = vreg[i];
+    }
+  };
+
+  // scores of one 64-key tile for this lane's query, already scaled to log2 units and masked
+  auto scores = [&](f32x16 (&s)[2], int len, int kv0) {
+#pragma unroll
+    for (int kvt = 0; kvt < 2; ++kvt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvt][r] = 0.f;
+      const T* kr = sK + (kvt * 32 + l31) * K_LDP + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        V8 kf = *reinterpret_cast<const V8*>(kr + ks * 16);
+        s[kvt] = mfma32(kf, qf[ks], s[kvt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + kvt * 32 + mfma32_row(r, lane);
+        s[kvt][r] = kv < len ? s[kvt][r] * p.scale_log2 : -INFINITY;
+      }
+    }
+  };
+
+  auto tile_max = [&](const f32x16 (&s)[2]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvt][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+
+  // O^T += V^T * P^T for one tile; P^T comes straight from the score registers
+  auto pv = [&](const f32x16 (&s)[2]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int kvt = c >> 1, cc = c & 1;
+      V8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[kvt][8 * cc + j]);
+      const T* vr = sV + l31 * VT_LDP + kvt * 32 + 16 * cc + 4 * hi;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        V4 lo = *reinterpret_cast<const V4*>(vr + t * 32 * VT_LDP);
+        V4 hi4 = *reinterpret_cast<const V4*>(vr + t * 32 * VT_LDP + 8);
+        V8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
+        o[t] = mfma32(vf, pf, o[t]);
+      }
+    }
+  };
+
+  // ---------------- segment 0: online softmax over len0 keys
+  const int nt0 = (p.len0 + KV - 1) / KV;
+  load_regs(p.k0, p.k0_ld, p.k0_bs, p.vt0, p.vt0_ld, p.vt0_bs, p.len0, 0);
+  for (int t = 0; t < nt0; ++t) {
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    if (t + 1 < nt0) load_regs(p.k0, p.k0_ld, p.k0_bs, p.vt0, p.vt0_ld, p.vt0_bs, p.len0, (t + 1) * KV);
+    else if (p.len1 > 0) load_regs(p.k1, p.k1_ld, p.k1_bs, p.vt1, p.vt1_ld, p.vt1_bs, p.len1, 0);
+    f32x16 s[2];
+    scores(s, p.len0, t * KV);
+    const float m_new = fmaxf(m_run, tile_max(s));
+    const float alpha = exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(s[kvt][r] - m_new);
+        s[kvt][r] = e;
+        ps += e;
+      }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+    pv(s);
+  }
+  {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+#pragma unroll
+    for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t2][r] *= inv;
+  }
+
+  // ---------------- segment 1 (single tile, own softmax), folded in with weight w1 / l1
+  if (p.len1 > 0) {
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    f32x16 s[2];
+    scores(s, p.len1, 0);
+    const float m1 = tile_max(s);
+    float ps = 0.f;
+#pragma unroll
+    for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(s[kvt][r] - m1);
+        s[kvt][r] = e;
+        ps += e;
+      }
+    const float l1 = ps + __shfl_xor(ps, 32, 64);
+    const float f = p.w1 / l1;
+#pragma unroll
+    for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvt][r] *= f;
+    pv(s);
+  }
+
+  // ---------------- store: O^T regs -> out[b, q, h*HD + d], 4 consecutive d per 8-byte store
+  if (q_ok) {
+    T* op = reinterpret_cast<T*>(p.out) + (long)b * p.out_bs + qrow * p.out_ld + (long)h * HD;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = t * 32 + 8 * g + 4 * hi;
+        if (d < HD) {
+          V4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = from_f32<T>(o[t][4 * g + j]);
+          *reinterpret_cast<V4*>(op + d) = v;
+        }
+      }
+  }
+}
+
+template <typename T, int DPAD, int DV>
+int launch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
+  const size_t lds = ((size_t)KV * (DPAD + 8) + (size_t)DV * VT_LDP) * sizeof(T);
+  dim3 grid((unsigned)((d->n_q + 127) / 128), (unsigned)d->heads, (unsigned)d->batch);
+  hipLaunchKernelGGL((attention_kernel<T, DPAD, DV>), grid, dim3(256), lds, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+template <typename T>
+int dispatch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
+  const int hd = d->head_dim;
+  if (hd <= 16) return launch_attn<T, 16, 32>(d, p, st);
+  if (hd <= 32) return launch_attn<T, 32, 32>(d, p, st);
+  if (hd <= 48) return launch_attn<T, 48, 64>(d, p, st);
+  if (hd <= 64) return launch_attn<T, 64, 64>(d, p, st);
+  if (hd <= 80) return launch_attn<T, 80, 96>(d, p, st);
+  if (hd <= 96) return launch_attn<T, 96, 96>(d, p, st);
+  if (hd <= 128) return launch_attn<T, 128, 128>(d, p, st);
+  return launch_attn<T, 160, 160>(d, p, st);
+}
+
+// ---- attention-probability export (save_attn_to_dict side channel): one wave per query row --------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(int b0, int heads, int hd, int n_q, const T* q, long q_ld, long q_bs,
+                                                         const T* k, long k_ld, long k_bs, int len, float scale,
+                                                         const int* tokens, int n_tokens, float* probs) {
+  typedef typename Vec<T>::v8 V8;
+  const int lane = threadIdx.x & 63;
+  const long qi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int h = blockIdx.y, bb = blockIdx.z, b = b0 + bb;
+  if (qi >= n_q) return;
+  const T* qp = q + (long)b * q_bs + qi * q_ld + (long)h * hd;
+  const T* kp = k + (long)b * k_bs + (long)h * hd;
+  constexpr int MAXJ = 4;  // keys per lane (len <= 256)
+  float sc[MAXJ];
+#pragma unroll
+  for (int jj = 0; jj < MAXJ; ++jj) {
+    const int j = lane + 64 * jj;
+    float acc = 0.f;
+    if (j < len) {
+      for (int d = 0; d < hd; d += 8) {
+        V8 a = *reinterpret_cast<const V8*>(qp + d);
+        V8 c = *reinterpret_cast<const V8*>(kp + (long)j * k_ld + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += to_f32<T>(a[e]) * to_f32<T>(c[e]);
+      }
+    }
+    sc[jj] = j < len ? acc * scale : -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < MAXJ; ++jj) mx = fmaxf(mx, sc[jj]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < MAXJ; ++jj) { sc[jj] = __expf(sc[jj] - mx); sum += sc[jj]; }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  const int nt = tokens ? n_tokens : len;
+  float* op = probs + (((long)bb * heads + h) * n_q + qi) * nt;
+  if (!tokens) {
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int j = lane + 64 * jj;
+      if (j < len) op[j] = sc[jj] * inv;
+    }
+  } else {
+    for (int t = 0; t < n_tokens; ++t) {
+      const int j = tokens[t];
+      const int owner = j & 63, slot = j >> 6;
+      float v = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj)
+        if (jj == slot) v = sc[jj];
+      v = __shfl(v, owner, 64);
+      if (lane == 0) op[t] = v * inv;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_attention(const tg_attn_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_attention: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_attention: bad dtype");
+  TG_CHECK(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->len0 > 0, TG_ERR_ARG, "tg_attention: empty problem");
+  TG_CHECK(d->head_dim > 0 && d->head_dim % 8 == 0 && d->head_dim <= 160, TG_ERR_ARG,
+           "tg_attention: head_dim %d unsupported (multiple of 8, <= 160)", d->head_dim);
+  TG_CHECK(d->q && d->k0 && d->vt0 && d->out, TG_ERR_ARG, "tg_attention: null q/k0/vt0/out");
+  TG_CHECK(d->q_ld % 8 == 0 && d->k0_ld % 8 == 0 && d->vt0_ld % 8 == 0 && d->out_ld % 4 == 0, TG_ERR_ARG,
+           "tg_attention: pitches must keep 16-byte alignment");
+  TG_CHECK(d->len1 >= 0 && d->len1 <= KV, TG_ERR_ARG, "tg_attention: len1 (%d) must be <= 64", d->len1);
+  if (d->len1 > 0) TG_CHECK(d->k1 && d->vt1 && d->k1_ld % 8 == 0 && d->vt1_ld % 8 == 0, TG_ERR_ARG, "tg_attention: bad segment 1");
+  AttnParams p{};
+  p.heads = d->heads; p.hd = d->head_dim; p.n_q = d->n_q;
+  p.q = d->q; p.q_ld = d->q_ld; p.q_bs = d->q_bs;
+  p.k0 = d->k0; p.k0_ld = d->k0_ld; p.k0_bs = d->k0_bs; p.vt0 = d->vt0; p.vt0_ld = d->vt0_ld; p.vt0_bs = d->vt0_bs; p.len0 = d->len0;
+  p.k1 = d->k1; p.k1_ld = d->k1_ld; p.k1_bs = d->k1_bs; p.vt1 = d->vt1; p.vt1_ld = d->vt1_ld; p.vt1_bs = d->vt1_bs; p.len1 = d->len1;
+  p.scale_log2 = d->scale * 1.4426950408889634f;
+  p.w1 = d->w1;
+  p.out = d->out; p.out_ld = d->out_ld; p.out_bs = d->out_bs;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return dispatch_attn<bf16_t>(d, p, st);
+  return dispatch_attn<f16_t>(d, p, st);
+}
+
+extern "C" int tg_attn_probs(int32_t dtype, int32_t batch, int32_t b0, int32_t heads, int32_t head_dim, int32_t n_q,
+                             const void* q, int64_t q_ld, int64_t q_bs, const void* k, int64_t k_ld, int64_t k_bs,
+                             int32_t len, float scale, const int32_t* tokens, int32_t n_tokens, float* probs, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_attn_probs: bad dtype");
+  TG_CHECK(q && k && probs && batch > b0 && b0 >= 0 && heads > 0 && n_q > 0, TG_ERR_ARG, "tg_attn_probs: bad args");
+  TG_CHECK(len > 0 && len <= 256 && head_dim % 8 == 0, TG_ERR_ARG, "tg_attn_probs: len (%d) must be in 1..256", len);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((n_q + 3) / 4), (unsigned)heads, (unsigned)(batch - b0));
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(attn_probs_kernel<bf16_t>, grid, dim3(256), 0, st, b0, heads, head_dim, n_q, (const bf16_t*)q, q_ld, q_bs,
+                       (const bf16_t*)k, k_ld, k_bs, len, scale, tokens, n_tokens, probs);
+  else
+    hipLaunchKernelGGL(attn_probs_kernel<f16_t>, grid, dim3(256), 0, st, b0, heads, head_dim, n_q, (const f16_t*)q, q_ld, q_bs,
+                       (const f16_t*)k, k_ld, k_bs, len, scale, tokens, n_tokens, probs);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}

@@ -1,0 +1,368 @@
+// Elementwise / boundary kernels (HBM- or latency-bound): GEGLU gate, activations, residual add,
+// conv_in / conv_out (tiny channel counts, NCHW <-> token-major conversion folded in), sinusoidal
+// timestep embedding, the fused CFG + DDIM + frozen-mask step epilogue, latent blend / shift / compose.
+#include "tg_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* x, long rows, long inner, T* out) {
+  typedef typename Vec<T>::v8 V8;
+  const long c8 = inner / 8;
+  const long total = rows * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8, c = (i - r * c8) * 8;
+    V8 a = *reinterpret_cast<const V8*>(x + r * 2 * inner + c);
+    V8 g = *reinterpret_cast<const V8*>(x + r * 2 * inner + inner + c);
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(to_f32<T>(a[j]) * gelu_erf_f(to_f32<T>(g[j])));
+    *reinterpret_cast<V8*>(out + r * inner + c) = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_kernel(const T* x, long n, int act, T* out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float f = to_f32<T>(x[i]);
+    f = act == TG_ACT_SILU ? silu_f(f) : (act == TG_ACT_GELU ? gelu_erf_f(f) : f);
+    out[i] = from_f32<T>(f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, long n, T* out) {
+  typedef typename Vec<T>::v8 V8;
+  const long n8 = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    V8 x = *reinterpret_cast<const V8*>(a + i * 8), y = *reinterpret_cast<const V8*>(b + i * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(to_f32<T>(x[j]) + to_f32<T>(y[j]));
+    *reinterpret_cast<V8*>(out + i * 8) = o;
+  }
+  for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+}
+
+__device__ __forceinline__ float load_src(const void* p, int src_dtype, long i) {
+  if (src_dtype == 0) return (float)reinterpret_cast<const bf16_t*>(p)[i];
+  if (src_dtype == 1) return (float)reinterpret_cast<const f16_t*>(p)[i];
+  return reinterpret_cast<const float*>(p)[i];
+}
+
+// one thread = one (pixel, output channel): cin is tiny (4), K = 9*cin
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_kernel(const void* sample, int src_dtype, int batch, int cin, int h, int w,
+                                                      const T* weight, const T* bias, int cout, T* out) {
+  extern __shared__ float patch[];  // [pixels_per_block][9*cin]
+  const int K = 9 * cin;
+  const int ppb = blockDim.x / 64;            // pixels per block (64 threads cooperate per pixel)
+  const long pix0 = (long)blockIdx.x * ppb;
+  const long npix = (long)batch * h * w;
+  for (int i = threadIdx.x; i < ppb * K; i += blockDim.x) {
+    const int lp = i / K, k = i - lp * K;
+    const long pix = pix0 + lp;
+    float v = 0.f;
+    if (pix < npix) {
+      const int tap = k / cin, c = k - tap * cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int b = (int)(pix / (h * w));
+      const int r = (int)(pix - (long)b * h * w);
+      const int y = r / w + ky - 1, x = r % w + kx - 1;
+      if (y >= 0 && y < h && x >= 0 && x < w) v = load_src(sample, src_dtype, (((long)b * cin + c) * h + y) * w + x);
+    }
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int lp = threadIdx.x / 64, l = threadIdx.x & 63;
+  const long pix = pix0 + lp;
+  if (pix >= npix) return;
+  for (int n = l; n < cout; n += 64) {
+    float acc = bias ? to_f32<T>(bias[n]) : 0.f;
+    for (int k = 0; k < K; ++k) acc += patch[lp * K + k] * to_f32<T>(weight[(long)n * K + k]);
+    out[pix * cout + n] = from_f32<T>(acc);
+  }
+}
+
+// one wave = one output pixel: 64 lanes split K = 9*cin, all cout (<= 8) outputs reduced by shuffles
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_kernel(const T* x, int batch, int cin, int h, int w, const T* weight,
+                                                       const T* bias, int cout, void* out, int out_f32) {
+  typedef typename Vec<T>::v8 V8;
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long npix = (long)batch * h * w;
+  if (pix >= npix) return;
+  const int b = (int)(pix / (h * w));
+  const int r = (int)(pix - (long)b * h * w);
+  const int oy = r / w, ox = r % w;
+  const int c8 = cin / 8;
+  float acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+  for (int i = lane; i < 9 * c8; i += 64) {
+    const int tap = i / c8, c = (i - tap * c8) * 8;
+    const int y = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+    if (y < 0 || y >= h || xx < 0 || xx >= w) continue;
+    V8 v = *reinterpret_cast<const V8*>(x + (((long)b * h + y) * w + xx) * cin + c);
+    for (int n = 0; n < cout; ++n) {
+      V8 wv = *reinterpret_cast<const V8*>(weight + ((long)n * 9 + tap) * cin + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[n] += to_f32<T>(v[j]) * to_f32<T>(wv[j]);
+    }
+  }
+  for (int n = 0; n < cout; ++n) {
+    float s = wave_sum(acc[n]);
+    if (lane == 0) {
+      s += bias ? to_f32<T>(bias[n]) : 0.f;
+      const long o = (((long)b * cout + n) * h + oy) * w + ox;
+      if (out_f32) reinterpret_cast<float*>(out)[o] = s;
+      else reinterpret_cast<T*>(out)[o] = from_f32<T>(s);
+    }
+  }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* t, int t_stride, int rows, int dim, int flip, float freq_shift,
+                                          T* out, long ldo) {
+  const int half = dim / 2;
+  const int r = blockIdx.x;
+  const float tv = t[(long)r * t_stride];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float e = __expf(-9.210340371976184f * (float)i / ((float)half - freq_shift));  // ln(10000)
+    const float a = tv * e;
+    const float s = sinf(a), c = cosf(a);
+    T* o = out + (long)r * ldo;
+    if (flip) { o[i] = from_f32<T>(c); o[half + i] = from_f32<T>(s); }
+    else { o[i] = from_f32<T>(s); o[half + i] = from_f32<T>(c); }
+  }
+}
+
+struct StepParams {
+  const float* noise_pred;
+  float* latents;
+  int n_img, chw, hw;
+  int has_cfg;
+  float g;
+  const float* coef;
+  int* step_idx;
+  int advance;
+  int pred_type;
+  const float* frozen;
+  const float* frozen_mask;
+  int mask_per_img;
+  int frozen_steps;
+  float* history;
+  void* model_in;
+  int model_in_dtype;
+};
+
+__global__ __launch_bounds__(256) void step_epilogue_kernel(StepParams p) {
+  const int step = *p.step_idx;
+  const float sa = p.coef[step * 4], sb = p.coef[step * 4 + 1], sap = p.coef[step * 4 + 2], sbp = p.coef[step * 4 + 3];
+  const long total = (long)p.n_img * p.chw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float u = p.noise_pred[i];
+    float mo = u;
+    if (p.has_cfg) { const float c = p.noise_pred[total + i]; mo = u + p.g * (c - u); }
+    const float x = p.latents[i];
+    float x0, eps;
+    if (p.pred_type == 0) { x0 = (x - sb * mo) / sa; eps = mo; }
+    else { x0 = sa * x - sb * mo; eps = sa * mo + sb * x; }
+    float nx = sap * x0 + sbp * eps;
+    if (p.frozen && step < p.frozen_steps) {
+      const long img = i / p.chw;
+      const long pix = (i - img * p.chw) % p.hw;
+      const float m = p.frozen_mask[(p.mask_per_img ? img * p.hw : 0) + pix];
+      const float f = p.frozen[(long)(step + 1) * total + i];
+      nx = f * m + nx * (1.f - m);
+    }
+    p.latents[i] = nx;
+    if (p.history) p.history[(long)(step + 1) * total + i] = nx;
+    if (p.model_in) {
+      // next UNet input = cat([latents] * 2) in the model dtype (models/pipelines.py:409-414)
+      if (p.model_in_dtype == TG_BF16) {
+        reinterpret_cast<bf16_t*>(p.model_in)[i] = (bf16_t)nx;
+        reinterpret_cast<bf16_t*>(p.model_in)[total + i] = (bf16_t)nx;
+      } else if (p.model_in_dtype == TG_F16) {
+        reinterpret_cast<f16_t*>(p.model_in)[i] = (f16_t)nx;
+        reinterpret_cast<f16_t*>(p.model_in)[total + i] = (f16_t)nx;
+      } else {
+        reinterpret_cast<float*>(p.model_in)[i] = nx;
+        reinterpret_cast<float*>(p.model_in)[total + i] = nx;
+      }
+    }
+  }
+}
+
+__global__ void step_advance_kernel(int* step_idx) { *step_idx += 1; }
+
+__global__ __launch_bounds__(256) void blend_kernel(const float* bg, const float* fg, const float* mask, int planes, int hw,
+                                                    float s1, float s2, float sigma, float* out) {
+  const long total = (long)planes * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float m = mask[i % hw];
+    const float b = bg[i];
+    out[i] = (b * (1.f - m) + (b * s1 + fg[i] * s2) * m) * sigma;
+  }
+}
+
+__global__ __launch_bounds__(256) void shift_kernel(const float* src, long planes, int h, int w, int dx, int dy, float* dst) {
+  const long total = planes * h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pl = i / (h * w);
+    const int r = (int)(i - pl * h * w);
+    const int y = r / w, x = r % w;
+    const int sy = y - dy, sx = x - dx;
+    float v = 0.f;
+    if (sy >= 0 && sy < h && sx >= 0 && sx < w) v = src[pl * h * w + (long)sy * w + sx];
+    dst[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void compose_kernel(float* dst, const float* src, const float* mask, long planes, int hw) {
+  const long total = planes * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float m = mask[i % hw];
+    dst[i] = dst[i] * (1.f - m) + src[i] * m;
+  }
+}
+
+inline int grid_for(long n, int per_thread = 1) {
+  long b = (n / per_thread + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, NAME, GRID, BLOCK, LDS, ...)                                            \
+  do {                                                                                          \
+    if ((dtype) == TG_BF16) hipLaunchKernelGGL(NAME<bf16_t>, GRID, BLOCK, LDS, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(NAME<f16_t>, GRID, BLOCK, LDS, st, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int tg_geglu(int32_t dtype, const void* x, int64_t rows, int64_t inner, void* out, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && out && rows > 0 && inner > 0 && inner % 8 == 0, TG_ERR_ARG,
+           "tg_geglu: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(rows * inner / 8);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(geglu_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, rows, inner, (bf16_t*)out);
+  else hipLaunchKernelGGL(geglu_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)x, rows, inner, (f16_t*)out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_act(int32_t dtype, const void* x, int64_t n, int32_t act, void* out, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && out && n > 0, TG_ERR_ARG, "tg_act: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(n);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, n, act, (bf16_t*)out);
+  else hipLaunchKernelGGL(act_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)x, n, act, (f16_t*)out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_add(int32_t dtype, const void* a, const void* b, int64_t n, void* out, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && a && b && out && n > 0, TG_ERR_ARG, "tg_add: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(n, 8);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, n, (bf16_t*)out);
+  else hipLaunchKernelGGL(add_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, n, (f16_t*)out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, int32_t batch, int32_t cin, int32_t h,
+                          int32_t w, const void* weight, const void* bias, int32_t cout, void* out, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && sample && weight && out, TG_ERR_ARG, "tg_conv_in: bad args");
+  TG_CHECK(src_dtype >= 0 && src_dtype <= 2 && batch > 0 && cin > 0 && cin <= 16 && cout > 0, TG_ERR_ARG, "tg_conv_in: bad shape");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long npix = (long)batch * h * w;
+  const int ppb = 4;
+  const size_t lds = (size_t)ppb * 9 * cin * sizeof(float);
+  dim3 grid((unsigned)((npix + ppb - 1) / ppb));
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(conv_in_kernel<bf16_t>, grid, dim3(256), lds, st, sample, src_dtype, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(conv_in_kernel<f16_t>, grid, dim3(256), lds, st, sample, src_dtype, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, (f16_t*)out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_t h, int32_t w,
+                           const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && weight && out, TG_ERR_ARG, "tg_conv_out: bad args");
+  TG_CHECK(batch > 0 && cin % 8 == 0 && cout > 0 && cout <= 8, TG_ERR_ARG, "tg_conv_out: bad shape cin=%d cout=%d", cin, cout);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long npix = (long)batch * h * w;
+  dim3 grid((unsigned)((npix + 3) / 4));
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(conv_out_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
+  else
+    hipLaunchKernelGGL(conv_out_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_timestep_embedding(int32_t dtype, const float* t, int32_t t_stride, int32_t rows, int32_t dim,
+                                     int32_t flip_sin_to_cos, float freq_shift, void* out, int64_t ldo, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && t && out && rows > 0 && dim > 0 && dim % 2 == 0, TG_ERR_ARG,
+           "tg_timestep_embedding: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(timestep_embedding_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, t, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (bf16_t*)out, ldo);
+  else
+    hipLaunchKernelGGL(timestep_embedding_kernel<f16_t>, dim3(rows), dim3(128), 0, st, t, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (f16_t*)out, ldo);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int32_t chw, int32_t hw,
+                                int32_t has_cfg, float guidance_scale, const float* coef, int32_t* step_idx, int32_t advance,
+                                int32_t prediction_type, const float* frozen, const float* frozen_mask,
+                                int32_t mask_per_img, int32_t frozen_steps, float* history, void* model_in,
+                                int32_t model_in_dtype, void* stream) {
+  TG_CHECK(noise_pred && latents && coef && step_idx && n_img > 0 && chw > 0 && hw > 0 && chw % hw == 0, TG_ERR_ARG,
+           "tg_step_epilogue: bad args");
+  TG_CHECK(prediction_type == 0 || prediction_type == 1, TG_ERR_ARG, "tg_step_epilogue: bad prediction type");
+  TG_CHECK(!frozen || frozen_mask, TG_ERR_ARG, "tg_step_epilogue: frozen latents need a mask");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  StepParams p{noise_pred, latents, n_img, chw, hw, has_cfg, guidance_scale, coef, step_idx, advance, prediction_type, frozen,
+               frozen_mask, mask_per_img, frozen_steps, history, model_in, model_in_dtype};
+  hipLaunchKernelGGL(step_epilogue_kernel, dim3(grid_for((long)n_img * chw)), dim3(256), 0, st, p);
+  TG_LAUNCH_CHECK();
+  if (advance) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, step_idx);
+    TG_LAUNCH_CHECK();
+  }
+  return TG_OK;
+}
+
+extern "C" int tg_blend_latents(const float* bg, const float* fg, const float* mask, int32_t planes, int32_t hw,
+                                float ratio, float sigma, float* out, void* stream) {
+  TG_CHECK(bg && fg && mask && out && planes > 0 && hw > 0, TG_ERR_ARG, "tg_blend_latents: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(blend_kernel, dim3(grid_for((long)planes * hw)), dim3(256), 0, st, bg, fg, mask, planes, hw,
+                     (float)sqrt(1.0 - (double)ratio), (float)sqrt((double)ratio), sigma, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_shift(const float* src, int64_t planes, int32_t h, int32_t w, int32_t dx, int32_t dy, float* dst,
+                        void* stream) {
+  TG_CHECK(src && dst && planes > 0 && h > 0 && w > 0 && src != dst, TG_ERR_ARG, "tg_shift: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(shift_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, st, src, (long)planes, h, w, dx, dy, dst);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_masked_compose(float* dst, const float* src, const float* mask, int64_t planes, int32_t hw, void* stream) {
+  TG_CHECK(dst && src && mask && planes > 0 && hw > 0, TG_ERR_ARG, "tg_masked_compose: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(compose_kernel, dim3(grid_for(planes * hw)), dim3(256), 0, st, dst, src, mask, (long)planes, hw);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}

@@ -1,0 +1,150 @@
+// Per-box cross-attention guidance reductions (reference utils/guidance.py:91-148, 223-233) as wavefront
+// primitives: one wave owns one attention head; the masked top-k MEAN is computed without sorting by a
+// 32-step radix select on the (non-negative) float bit pattern using __ballot/__popcll counts, then one
+// wave_sum.  Deterministic: heads are accumulated in head order by a single lane (no float atomics).
+#include "tg_common.h"
+
+namespace {
+
+constexpr int G_WAVES = 4;
+
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// k-th largest of x[0..n) (all x >= 0), values in LDS; returns threshold bits; also count(x > thr) and sum(x > thr)
+__device__ void wave_topk_select(const float* x, int n, int k, int lane, float& thr, int& cnt_gt, float& sum_gt) {
+  unsigned int cand = 0u;
+  for (int bit = 30; bit >= 0; --bit) {   // sign bit is always 0
+    const unsigned int trial = cand | (1u << bit);
+    int c = 0;
+    for (int i = lane; i - lane < n; i += 64) {
+      const bool ge = i < n && __float_as_uint(x[i]) >= trial;
+      c += __popcll(__ballot(ge));
+    }
+    if (c >= k) cand = trial;   // at least k values >= trial: the k-th largest is >= trial
+  }
+  thr = __uint_as_float(cand);
+  int c = 0;
+  float s = 0.f;
+  for (int i = lane; i - lane < n; i += 64) {
+    const bool gt = i < n && x[i] > thr;
+    c += __popcll(__ballot(gt));
+    s += gt ? x[i] : 0.f;
+  }
+  cnt_gt = c;
+  sum_gt = wave_sum(s);
+}
+
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_topk_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                     const float* mask, int k_fg, int k_bg, float fg_w,
+                                                                     float bg_w, float scale, float* out, float* grad) {
+  extern __shared__ float sh[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xf = sh + (size_t)wave * 2 * hw;   // A * M
+  float* xb = xf + hw;                      // A * (1 - M)
+  float* head_loss = sh + (size_t)G_WAVES * 2 * hw;  // [heads]
+  for (int h = wave; h < heads; h += G_WAVES) {
+    const float* col = attn + (long)h * hw * n_tok + token;
+    for (int i = lane; i < hw; i += 64) {
+      const float a = col[(long)i * n_tok], m = mask[i];
+      xf[i] = a * m;
+      xb[i] = a * (1.f - m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float thr_f, thr_b, sf, sb;
+    int cf, cb;
+    wave_topk_select(xf, hw, k_fg, lane, thr_f, cf, sf);
+    wave_topk_select(xb, hw, k_bg, lane, thr_b, cb, sb);
+    const float mean_f = (sf + (float)(k_fg - cf) * thr_f) / (float)k_fg;
+    const float mean_b = (sb + (float)(k_bg - cb) * thr_b) / (float)k_bg;
+    if (lane == 0) head_loss[h] = fg_w * (1.f - mean_f) + bg_w * mean_b;
+    if (grad) {
+      float* gcol = grad + (long)h * hw * n_tok + token;
+      int run_f = 0, run_b = 0;
+      const int need_f = k_fg - cf, need_b = k_bg - cb;
+      for (int i = lane; i - lane < hw; i += 64) {
+        const bool in = i < hw;
+        const float vf = in ? xf[i] : -1.f, vb = in ? xb[i] : -1.f;
+        const bool eqf = in && vf == thr_f, eqb = in && vb == thr_b;
+        const unsigned long long bf = __ballot(eqf), bb = __ballot(eqb);
+        const bool self = (vf > thr_f) || (eqf && run_f + __popcll(bf & lanemask_lt(lane)) < need_f);
+        const bool selb = (vb > thr_b) || (eqb && run_b + __popcll(bb & lanemask_lt(lane)) < need_b);
+        run_f += __popcll(bf);
+        run_b += __popcll(bb);
+        if (in) {
+          const float m = mask[i];
+          float g = 0.f;
+          if (self) g -= scale * fg_w * m / (float)k_fg;
+          if (selb) g += scale * bg_w * (1.f - m) / (float)k_bg;
+          if (g != 0.f) gcol[(long)i * n_tok] += g;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int h = 0; h < heads; ++h) s += head_loss[h];
+    out[0] += scale * s;
+  }
+}
+
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_ratio_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                      const float* mask, float scale, float* out, float* grad) {
+  extern __shared__ float head_loss[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int h = wave; h < heads; h += G_WAVES) {
+    const float* col = attn + (long)h * hw * n_tok + token;
+    float sm = 0.f, sa = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+      const float a = col[(long)i * n_tok];
+      sm += a * mask[i];
+      sa += a;
+    }
+    sm = wave_sum(sm);
+    sa = wave_sum(sa);
+    const float r = sm / sa;
+    if (lane == 0) head_loss[h] = (1.f - r) * (1.f - r);
+    if (grad) {
+      float* gcol = grad + (long)h * hw * n_tok + token;
+      const float c = scale / (float)heads * (-2.f) * (1.f - r) / (sa * sa);
+      for (int i = lane; i < hw; i += 64) gcol[(long)i * n_tok] += c * (mask[i] * sa - sm);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int h = 0; h < heads; ++h) s += head_loss[h];
+    out[0] += scale * s / (float)heads;
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_guidance_topk(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token,
+                                const float* mask, int32_t k_fg, int32_t k_bg, float fg_w, float bg_w, float scale,
+                                float* out, float* grad, void* stream) {
+  TG_CHECK(attn && mask && out && heads > 0 && hw > 0 && n_tok > 0 && token >= 0 && token < n_tok, TG_ERR_ARG,
+           "tg_guidance_topk: bad args");
+  TG_CHECK(k_fg >= 1 && k_fg <= hw && k_bg >= 1 && k_bg <= hw, TG_ERR_ARG, "tg_guidance_topk: k out of range");
+  const size_t lds = ((size_t)G_WAVES * 2 * hw + heads) * sizeof(float);
+  TG_CHECK(lds <= 160 * 1024, TG_ERR_ARG, "tg_guidance_topk: hw too large (%d)", hw);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(guidance_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(guidance_topk_kernel, dim3(1), dim3(64 * G_WAVES), lds, st, attn, heads, hw, n_tok, token, mask, k_fg,
+                     k_bg, fg_w, bg_w, scale, out, grad);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_guidance_ratio(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token,
+                                 const float* mask, float scale, float* out, float* grad, void* stream) {
+  TG_CHECK(attn && mask && out && heads > 0 && hw > 0 && n_tok > 0 && token >= 0 && token < n_tok, TG_ERR_ARG,
+           "tg_guidance_ratio: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(guidance_ratio_kernel, dim3(1), dim3(64 * G_WAVES), heads * sizeof(float), st, attn, heads, hw, n_tok,
+                     token, mask, scale, out, grad);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}

@@ -1,0 +1,275 @@
+// GroupNorm (+SiLU) over token-major activations and LayerNorm per token row — HBM-bound kernels.
+// 16-byte (8 x bf16/f16) accesses per lane, channels contiguous -> fully coalesced rows.
+//
+// GroupNorm is three launches: (1) per-slab partial sum / sum-of-squares per (batch, group) — no atomics,
+// deterministic; (2) finalize mean / rstd per (batch, group) in fp64; (3) apply gamma/beta (+SiLU) and write
+// the normalised activations once.  The input may be the channel concat of two tensors (skip connection):
+// groups may straddle the boundary (e.g. 1280 + 640 channels -> 60 channels per group).
+#include "tg_common.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 4;  // channel chunks (of 8) per thread column: supports C <= 8 * 256 * 4
+
+struct GnParams {
+  const void* x0;
+  const void* x1;
+  int c0, c1;
+  int batch;
+  long hw;
+  int groups;
+  float eps;
+  const void* gamma;
+  const void* beta;
+  int silu;
+  void* out;
+  float* partials;  // [batch][nblk][groups][2]
+  float* stats;     // [batch][groups][2] (mean, rstd) — placed after the partials
+  int nblk;
+  int cx, ry;       // thread grid: cx channel-chunk columns x ry pixel rows
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 gn_load8(const GnParams& p, int b, long pix, int ch) {
+  typedef typename Vec<T>::v8 V8;
+  if (ch < p.c0) return *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.x0) + ((long)b * p.hw + pix) * p.c0 + ch);
+  return *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.x1) + ((long)b * p.hw + pix) * p.c1 + (ch - p.c0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
+  extern __shared__ float sh[];  // [2][C]
+  const int C = p.c0 + p.c1;
+  const int cpr = C / 8;
+  const int b = blockIdx.y;
+  const int blk = blockIdx.x;
+  const long per = (p.hw + p.nblk - 1) / p.nblk;
+  const long p_begin = (long)blk * per;
+  long p_end = p_begin + per;
+  if (p_end > p.hw) p_end = p.hw;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  const int tx = threadIdx.x % p.cx;
+  const int ty = threadIdx.x / p.cx;
+  if (ty < p.ry) {
+    for (int c = tx; c < cpr; c += p.cx) {
+      float s[8], q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+      for (long pix = p_begin + ty; pix < p_end; pix += p.ry) {
+        typename Vec<T>::v8 v = gn_load8<T>(p, b, pix, c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = to_f32<T>(v[j]);
+          s[j] += f;
+          q[j] += f * f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sh[c * 8 + j], s[j]);
+        atomicAdd(&sh[C + c * 8 + j], q[j]);
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / p.groups;
+  for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int j = 0; j < cpg; ++j) { s += sh[g * cpg + j]; q += sh[C + g * cpg + j]; }
+    float* o = p.partials + (((long)b * p.nblk + blk) * p.groups + g) * 2;
+    o[0] = s;
+    o[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(GnParams p) {
+  const int b = blockIdx.x;
+  const int C = p.c0 + p.c1;
+  const double cnt = (double)p.hw * (C / p.groups);
+  for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < p.nblk; ++k) {
+      const float* o = p.partials + (((long)b * p.nblk + k) * p.groups + g) * 2;
+      s += (double)o[0];
+      q += (double)o[1];
+    }
+    double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    p.stats[((long)b * p.groups + g) * 2] = (float)mean;
+    p.stats[((long)b * p.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
+  typedef typename Vec<T>::v8 V8;
+  const int C = p.c0 + p.c1;
+  const int cpr = C / 8;
+  const int cpg = C / p.groups;
+  const int b = blockIdx.y;
+  const int blk = blockIdx.x;
+  const long per = (p.hw + p.nblk - 1) / p.nblk;
+  const long p_begin = (long)blk * per;
+  long p_end = p_begin + per;
+  if (p_end > p.hw) p_end = p.hw;
+  const int tx = threadIdx.x % p.cx;
+  const int ty = threadIdx.x / p.cx;
+  if (ty >= p.ry) return;
+  const T* gam = reinterpret_cast<const T*>(p.gamma);
+  const T* bet = reinterpret_cast<const T*>(p.beta);
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int c = tx; c < cpr; c += p.cx) {
+    float a[8], d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = c * 8 + j;
+      const int g = ch / cpg;
+      const float mean = p.stats[((long)b * p.groups + g) * 2];
+      const float rstd = p.stats[((long)b * p.groups + g) * 2 + 1];
+      const float ga = gam ? to_f32<T>(gam[ch]) : 1.f;
+      const float be = bet ? to_f32<T>(bet[ch]) : 0.f;
+      a[j] = rstd * ga;
+      d[j] = be - mean * a[j];
+    }
+    for (long pix = p_begin + ty; pix < p_end; pix += p.ry) {
+      V8 v = gn_load8<T>(p, b, pix, c * 8);
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = to_f32<T>(v[j]) * a[j] + d[j];
+        if (p.silu) f = silu_f(f);
+        o[j] = from_f32<T>(f);
+      }
+      *reinterpret_cast<V8*>(out + ((long)b * p.hw + pix) * C + c * 8) = o;
+    }
+  }
+}
+
+int gn_nblk(int batch, long hw) {
+  long target = 1024 / (batch > 0 ? batch : 1);
+  if (target < 1) target = 1;
+  long nblk = hw / 8;  // at least 8 pixels per slab
+  if (nblk > target) nblk = target;
+  if (nblk < 1) nblk = 1;
+  return (int)nblk;
+}
+
+template <typename T, int MAXC8>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, int C, long ldx, float eps, const T* gamma,
+                                                        const T* beta, T* out, long ldo) {
+  typedef typename Vec<T>::v8 V8;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cpr = C / 8;
+  float v[MAXC8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cpr) {
+      V8 t = *reinterpret_cast<const V8*>(x + row * ldx + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[i][j] = to_f32<T>(t[j]); s += v[i][j]; }
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cpr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float dlt = v[i][j] - mean; q += dlt * dlt; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC8; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cpr) {
+      V8 o;
+      V8 g8, b8;
+      if (gamma) g8 = *reinterpret_cast<const V8*>(gamma + c * 8);
+      if (beta) b8 = *reinterpret_cast<const V8*>(beta + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (v[i][j] - mean) * rstd;
+        if (gamma) f *= to_f32<T>(g8[j]);
+        if (beta) f += to_f32<T>(b8[j]);
+        o[j] = from_f32<T>(f);
+      }
+      *reinterpret_cast<V8*>(out + row * ldo + c * 8) = o;
+    }
+  }
+}
+
+template <typename T>
+int launch_ln(const void* x, long rows, int C, long ldx, float eps, const void* gamma, const void* beta, void* out,
+              long ldo, hipStream_t st) {
+  dim3 grid((unsigned)((rows + 3) / 4));
+  const int c8 = (C / 8 + 63) / 64;
+#define LN_CASE(N)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, rows, C, ldx, eps, (const T*)gamma, \
+                     (const T*)beta, (T*)out, ldo)
+  if (c8 <= 1) LN_CASE(1);
+  else if (c8 <= 2) LN_CASE(2);
+  else if (c8 <= 3) LN_CASE(3);
+  else if (c8 <= 4) LN_CASE(4);
+  else LN_CASE(8);
+#undef LN_CASE
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tg_groupnorm_scratch_bytes(int32_t batch, int64_t hw, int32_t groups) {
+  const int nblk = gn_nblk(batch, hw);
+  return ((int64_t)batch * nblk * groups * 2 + (int64_t)batch * groups * 2) * 4;
+}
+
+extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
+                            int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu,
+                            void* out, void* partials, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_groupnorm: bad dtype");
+  TG_CHECK(x0 && out && partials, TG_ERR_ARG, "tg_groupnorm: null pointer");
+  if (!x1) c1 = 0;
+  const int C = c0 + c1;
+  TG_CHECK(batch > 0 && hw > 0 && groups > 0 && C % groups == 0 && c0 % 8 == 0 && c1 % 8 == 0, TG_ERR_ARG,
+           "tg_groupnorm: bad shape batch=%d hw=%lld C=%d+%d groups=%d", batch, (long long)hw, c0, c1, groups);
+  TG_CHECK(C <= 8 * 256 * GN_MAX_CHUNKS, TG_ERR_ARG, "tg_groupnorm: C too large");
+  GnParams p{};
+  p.x0 = x0; p.x1 = x1; p.c0 = c0; p.c1 = c1; p.batch = batch; p.hw = hw; p.groups = groups; p.eps = eps;
+  p.gamma = gamma; p.beta = beta; p.silu = silu; p.out = out;
+  p.nblk = gn_nblk(batch, hw);
+  p.partials = reinterpret_cast<float*>(partials);
+  p.stats = p.partials + (long)batch * p.nblk * groups * 2;
+  const int cpr = C / 8;
+  p.cx = cpr < 256 ? cpr : 256;
+  p.ry = 256 / p.cx;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(p.nblk, batch);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(gn_partial_kernel<f16_t>, grid, dim3(256), lds, st, p);
+  TG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(64), 0, st, p);
+  TG_LAUNCH_CHECK();
+  if (dtype == TG_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps,
+                            const void* gamma, const void* beta, void* out, int64_t ldo, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_layernorm: bad dtype");
+  TG_CHECK(x && out && rows > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * 8 && ldx % 8 == 0 && ldo % 8 == 0, TG_ERR_ARG,
+           "tg_layernorm: bad args rows=%lld C=%d", (long long)rows, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == TG_BF16) return launch_ln<bf16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
+  return launch_ln<f16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
+}

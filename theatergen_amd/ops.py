@@ -1,0 +1,259 @@
+"""Tensor-level wrappers over the C ABI (one function per kernel family).
+
+PyTorch is used ONLY for device memory (``torch.empty`` / views / data_ptr) and the current HIP stream;
+every computation is a call into libtheatergen_hip.so.  Activations are token-major 2-D views
+``[rows, channels]`` (``rows = batch * h * w``) in bf16 or fp16.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc  # noqa: F401
+
+_workspaces = {}
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return _lib.TG_BF16
+    if t.dtype == torch.float16:
+        return _lib.TG_F16
+    raise RuntimeError(f"theatergen_amd: unsupported activation dtype {t.dtype} (bf16 / fp16 only)")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("theatergen_amd: tensors must live on the GPU (no CPU fallback)")
+
+
+def workspace(nbytes, device):
+    """Persistent fp32 scratch per device (split-K partials, GroupNorm partial sums)."""
+    key = (device.index, "ws")
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
+         res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0):
+    """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
+    ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
+    _need_cuda(a0)
+    L = _lib.lib()
+    d = GemmDesc()
+    d.dtype = _dt(a0)
+    d.mode = mode
+    d.a0, d.a1 = _ptr(a0), _ptr(a1)
+    d.c0 = int(c0 if c0 is not None else (K if mode == 0 else K // 9))
+    d.c1 = int(c1)
+    if conv is not None:
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.stride, d.upsample = [int(v) for v in conv]
+    d.w = _ptr(w)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.bias = _ptr(bias)
+    d.bvec = _ptr(bvec)
+    d.ldbvec = int(bvec.stride(0)) if bvec is not None else 0
+    d.rows_per_batch = int(rows_per_batch)
+    d.res = _ptr(res)
+    d.ldres = int(res.stride(0)) if res is not None else 0
+    d.act = act
+    d.geglu = 0
+    d.out_scale = float(out_scale)
+    n_main = n_split if n_split > 0 else N
+    if out is None:
+        out = torch.empty((M, n_main), dtype=a0.dtype, device=a0.device)
+    d.out = _ptr(out)
+    d.ldc = int(out.stride(0))
+    d.n_split = int(n_split)
+    d.out_t = _ptr(out_t)
+    d.ldt = int(ldt)
+    d.force_split_k = force_split_k
+    d.force_tile = force_tile
+    need = L.tg_gemm_workspace_bytes(C.byref(d))
+    if need < 0:
+        _lib.check(-1)
+    if need > 0:
+        ws = workspace(need, a0.device)
+        d.workspace = ws.data_ptr()
+        d.workspace_bytes = ws.numel() * 4
+    _lib.check(L.tg_gemm(C.byref(d), _stream()))
+    return out
+
+
+def linear(x, w, bias=None, **kw):
+    """x [rows, K] (row pitch = K) @ w[N, K]^T"""
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.stride(0) == K and w.shape[1] == K
+    return gemm(x, w, M, N, K, bias=bias, **kw)
+
+
+def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, **kw):
+    """3x3 pad-1 convolution as implicit GEMM over token-major x [batch*in_h*in_w, cin] (+ optional concat x1).
+    w_packed: [cout, 9*(cin+c1)] tap-major."""
+    if upsample:
+        oh, ow = 2 * in_h, 2 * in_w
+    else:
+        oh, ow = (in_h + 2 - 3) // stride + 1, (in_w + 2 - 3) // stride + 1
+    N = w_packed.shape[0]
+    K = 9 * (cin + c1)
+    return gemm(x, w_packed, batch * oh * ow, N, K, mode=1, a1=x1, c0=cin, c1=c1,
+                conv=(batch, in_h, in_w, oh, ow, stride, 1 if upsample else 0), bias=bias, **kw)
+
+
+def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch, heads, head_dim, n_q, scale,
+              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0):
+    _need_cuda(q)
+    d = AttnDesc()
+    d.dtype = _dt(q)
+    d.batch, d.heads, d.head_dim, d.n_q = int(batch), int(heads), int(head_dim), int(n_q)
+    d.q, d.q_ld, d.q_bs = _ptr(q), int(q_ld), int(q_bs)
+    d.k0, d.k0_ld, d.k0_bs = _ptr(k0), int(k0_ld), int(k0_bs)
+    d.vt0, d.vt0_ld, d.vt0_bs = _ptr(vt0), int(vt0_ld), int(vt0_bs)
+    d.len0 = int(len0)
+    d.k1, d.k1_ld, d.k1_bs = _ptr(k1), int(k1_ld), int(k1_bs)
+    d.vt1, d.vt1_ld, d.vt1_bs = _ptr(vt1), int(vt1_ld), int(vt1_bs)
+    d.len1 = int(len1)
+    d.scale, d.w1 = float(scale), float(w1)
+    d.out, d.out_ld, d.out_bs = _ptr(out), int(out_ld), int(out_bs)
+    _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
+    return out
+
+
+def attn_probs(q, q_ld, q_bs, k, k_ld, k_bs, batch, b0, heads, head_dim, n_q, length, scale, tokens=None):
+    """fp32 [batch-b0, heads, n_q, n_tokens] softmax probabilities (save_attn_to_dict side channel)."""
+    nt = length if tokens is None else int(tokens.numel())
+    out = torch.empty((batch - b0, heads, n_q, nt), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().tg_attn_probs(_dt(q), batch, b0, heads, head_dim, n_q, _ptr(q), q_ld, q_bs, _ptr(k), k_ld, k_bs,
+                                        length, float(scale), _ptr(tokens), nt, _ptr(out), _stream()))
+    return out
+
+
+def groupnorm(x0, batch, hw, groups, eps, gamma, beta, silu=False, x1=None, out=None):
+    _need_cuda(x0)
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty((batch * hw, c0 + c1), dtype=x0.dtype, device=x0.device)
+    scratch = workspace(L.tg_groupnorm_scratch_bytes(batch, hw, groups), x0.device)
+    _lib.check(L.tg_groupnorm(_dt(x0), _ptr(x0), _ptr(x1), c0, c1, batch, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+                              1 if silu else 0, _ptr(out), _ptr(scratch), _stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _need_cuda(x)
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().tg_layernorm(_dt(x), _ptr(x), rows, Cc, x.stride(0), float(eps), _ptr(gamma), _ptr(beta), _ptr(out),
+                                       out.stride(0), _stream()))
+    return out
+
+
+def geglu(x, out=None):
+    rows, two_inner = x.shape
+    inner = two_inner // 2
+    if out is None:
+        out = torch.empty((rows, inner), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().tg_geglu(_dt(x), _ptr(x), rows, inner, _ptr(out), _stream()))
+    return out
+
+
+def act(x, kind, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().tg_act(_dt(x), _ptr(x), x.numel(), kind, _ptr(out), _stream()))
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.lib().tg_add(_dt(a), _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()))
+    return out
+
+
+_SRC = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def conv_in(sample, weight_packed, bias, cout, dtype):
+    """sample NCHW (bf16/f16/f32) -> token-major [B*h*w, cout] in ``dtype``"""
+    _need_cuda(sample)
+    B, cin, h, w = sample.shape
+    out = torch.empty((B * h * w, cout), dtype=dtype, device=sample.device)
+    _lib.check(_lib.lib().tg_conv_in(_dt(out), _ptr(sample), _SRC[sample.dtype], B, cin, h, w, _ptr(weight_packed), _ptr(bias),
+                                     cout, _ptr(out), _stream()))
+    return out
+
+
+def conv_out(x, weight_packed, bias, batch, h, w, cout, out_dtype):
+    cin = x.shape[-1]
+    out = torch.empty((batch, cout, h, w), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().tg_conv_out(_dt(x), _ptr(x), batch, cin, h, w, _ptr(weight_packed), _ptr(bias), cout, _ptr(out),
+                                      1 if out_dtype == torch.float32 else 0, _stream()))
+    return out
+
+
+def timestep_embedding(t_dev, rows, dim, flip_sin_to_cos, freq_shift, dtype, t_stride=0):
+    out = torch.empty((rows, dim), dtype=dtype, device=t_dev.device)
+    _lib.check(_lib.lib().tg_timestep_embedding(_dt(out), _ptr(t_dev), t_stride, rows, dim, 1 if flip_sin_to_cos else 0,
+                                                float(freq_shift), _ptr(out), dim, _stream()))
+    return out
+
+
+def step_epilogue(noise_pred, latents, guidance_scale, coef, step_idx, *, has_cfg=True, advance=True, prediction_type=0, frozen=None,
+                  frozen_mask=None, frozen_steps=0, history=None, model_in=None):
+    n_img = latents.shape[0]
+    chw = latents[0].numel()
+    hw = latents.shape[-1] * latents.shape[-2]
+    mask_per_img = 1 if (frozen_mask is not None and frozen_mask.numel() == n_img * hw and n_img > 1) else 0
+    mi_dt = -1 if model_in is None else _SRC[model_in.dtype]
+    _lib.check(_lib.lib().tg_step_epilogue(_ptr(noise_pred), _ptr(latents), n_img, chw, hw, 1 if has_cfg else 0, float(guidance_scale), _ptr(coef),
+                                           _ptr(step_idx), 1 if advance else 0, prediction_type, _ptr(frozen), _ptr(frozen_mask),
+                                           mask_per_img, int(frozen_steps), _ptr(history), _ptr(model_in), mi_dt, _stream()))
+
+
+def blend_latents(bg, fg, mask, ratio, sigma=1.0):
+    out = torch.empty_like(bg)
+    hw = bg.shape[-1] * bg.shape[-2]
+    _lib.check(_lib.lib().tg_blend_latents(_ptr(bg), _ptr(fg), _ptr(mask), bg.numel() // hw, hw, float(ratio), float(sigma),
+                                           _ptr(out), _stream()))
+    return out
+
+
+def shift(src, dx, dy):
+    h, w = src.shape[-2:]
+    out = torch.empty_like(src)
+    _lib.check(_lib.lib().tg_shift(_ptr(src), src.numel() // (h * w), h, w, int(dx), int(dy), _ptr(out), _stream()))
+    return out
+
+
+def masked_compose_(dst, src, mask):
+    hw = dst.shape[-1] * dst.shape[-2]
+    _lib.check(_lib.lib().tg_masked_compose(_ptr(dst), _ptr(src), _ptr(mask), dst.numel() // hw, hw, _stream()))
+    return dst
+
+
+def guidance_topk(attn, token, mask, k_fg, k_bg, fg_w, bg_w, scale, out, grad=None):
+    heads, hw, n_tok = attn.shape
+    _lib.check(_lib.lib().tg_guidance_topk(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), int(k_fg), int(k_bg),
+                                           float(fg_w), float(bg_w), float(scale), _ptr(out), _ptr(grad), _stream()))
+
+
+def guidance_ratio(attn, token, mask, scale, out, grad=None):
+    heads, hw, n_tok = attn.shape
+    _lib.check(_lib.lib().tg_guidance_ratio(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), float(scale), _ptr(out),
+                                            _ptr(grad), _stream()))
