@@ -97,6 +97,11 @@ typedef struct {
   int64_t workspace_bytes;
   int32_t force_split_k; /* 0 = heuristic; >0 forces that many K splits (testing) */
   int32_t force_tile;    /* 0 = heuristic; otherwise tile config id (testing) */
+  /* mode 0 only: A rows grouped per batch item with a batch pitch (elements): row m lives at
+   * a0 + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * c0.  0 = contiguous.
+   * (slices encoder_hidden_states[:, :L-T] / [:, L-T:] without a copy, attention_processor.py:467-471) */
+  int64_t a_rows_per_batch;
+  int64_t a_batch_stride;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
@@ -163,6 +168,10 @@ int tg_act(int32_t dtype, const void* x, int64_t n, int32_t act, void* out, void
 /* out = a + b (n elements; ControlNet residual injection, models/unet_2d_condition.py:938-946, 975-976) */
 int tg_add(int32_t dtype, const void* a, const void* b, int64_t n, void* out, void* stream);
 
+/* dst[b, c, r] = src[b, r, c]: NCHW <-> token-major conversion for the processors' 4-D input path
+ * (attention_processor.py:318-320, 363-364) and ControlNet residual injection (models/unet_2d_condition.py:938-946). */
+int tg_transpose(int32_t dtype, const void* src, int32_t batch, int32_t rows, int32_t cols, void* dst, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * UNet boundary convolutions (tiny channel counts, direct):
  * tg_conv_in : sample NCHW [batch, cin, h, w] (src_dtype: 0 bf16, 1 f16, 2 f32) -> NHWC [batch, h*w, cout],
@@ -176,8 +185,10 @@ int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_
                 const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream);
 
 /* Sinusoidal timestep embedding (diffusers Timesteps; call site models/unet_2d_condition.py:315-316, 819):
- * out[r, :] for r < rows; t read from DEVICE fp32 array `t` (stride t_stride, 0 = broadcast one value). */
-int tg_timestep_embedding(int32_t dtype, const float* t, int32_t t_stride, int32_t rows, int32_t dim,
+ * out[r, :] for r < rows; t read from DEVICE fp32 array `t` (stride t_stride, 0 = broadcast one value).  When
+ * `index` (DEVICE int32, may be NULL) is given the value is t[*index + r * t_stride]: the whole 50-step schedule
+ * lives on the device and a captured hipGraph of one step replays without host updates. */
+int tg_timestep_embedding(int32_t dtype, const float* t, const int32_t* index, int32_t t_stride, int32_t rows, int32_t dim,
                           int32_t flip_sin_to_cos, float freq_shift, void* out, int64_t ldo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
         ("bias", vp), ("bvec", vp), ("ldbvec", i64), ("rows_per_batch", i64), ("res", vp), ("ldres", i64),
         ("act", i32), ("geglu", i32), ("out_scale", f32), ("out", vp), ("ldc", i64), ("n_split", i64),
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
-        ("force_split_k", i32), ("force_tile", i32),
+        ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
     ]
 
 
@@ -52,9 +52,10 @@ SIGNATURES = {
     "tg_geglu": (i32, [i32, vp, i64, i64, vp, vp]),
     "tg_act": (i32, [i32, vp, i64, i32, vp, vp]),
     "tg_add": (i32, [i32, vp, vp, i64, vp, vp]),
+    "tg_transpose": (i32, [i32, vp, i32, i32, i32, vp, vp]),
     "tg_conv_in": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     "tg_conv_out": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
-    "tg_timestep_embedding": (i32, [i32, vp, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "tg_timestep_embedding": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp, i64, vp]),
     "tg_step_epilogue": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp]),
     "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, vp]),
     "tg_shift": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),

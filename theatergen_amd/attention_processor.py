@@ -1,0 +1,303 @@
+"""Attention module + attention processors with the reference's diffusers call surface, running on HIP.
+
+Mirrors reference ``ip_adapter/attention_processor.py``:
+  ``Attention``        :12-279   (parameter names to_q / to_k / to_v / to_out.0; ``heads``; ``scale``)
+  ``AttnProcessor``    :282-393  (self / plain cross attention)            -> installed on every ``attn1``
+  ``IPAttnProcessor``  :396-553  (decoupled text + image cross attention)  -> installed on every ``attn2``
+  ``CNAttnProcessor``  :861-923  (ControlNet: text tokens only)
+Same constructor arguments, same mutable ``.scale`` / ``.num_tokens`` attributes (``IPAdapter.set_scale`` mutates
+them by ``isinstance`` check, reference ``ip_adapter/ip_adapter.py:155-158``), same ``__call__`` keyword set,
+``to_k_ip`` / ``to_v_ip`` parameter names so ``ModuleList(unet.attn_processors.values()).load_state_dict``
+(``ip_adapter.py:139-140``) works unchanged.
+
+What differs: the computation.  ``baddbmm -> softmax -> bmm`` with a materialised [B*h, N, Lk] tensor
+(:187-219) becomes ONE fused MFMA kernel (``tg_attention``); the head split / merge permutes (:169-185)
+disappear because the kernel reads Q / K / V^T straight from the projection GEMM outputs; the two softmaxes
+of the IP path stay independent (segment 1 of the kernel).  ``torch.nn`` modules are used as parameter
+containers only; there is no PyTorch compute and no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
+class Attention(nn.Module):
+    """Parameter container + dispatcher (reference attention_processor.py:12-167)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, upcast_softmax=False, cross_attention_norm=None, added_kv_proj_dim=None,
+                 norm_num_groups=None, spatial_norm_dim=None, out_bias=True, scale_qk=True, only_cross_attention=False,
+                 eps=1e-5, rescale_output_factor=1.0, residual_connection=False, processor=None):
+        super().__init__()
+        for name, val in (("cross_attention_norm", cross_attention_norm), ("added_kv_proj_dim", added_kv_proj_dim),
+                          ("norm_num_groups", norm_num_groups), ("spatial_norm_dim", spatial_norm_dim)):
+            if val is not None:
+                raise ValueError(f"theatergen_amd.Attention: {name} is not on the TheaterGen hot path (unsupported)")
+        if only_cross_attention:
+            raise ValueError("`only_cross_attention` can only be set to True if `added_kv_proj_dim` is not None.")
+        inner_dim = dim_head * heads
+        self.query_dim = query_dim
+        self.inner_dim = inner_dim
+        self.is_cross = cross_attention_dim is not None
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.upcast_attention = upcast_attention      # accumulation / softmax are always fp32 in the kernel
+        self.upcast_softmax = upcast_softmax
+        self.rescale_output_factor = rescale_output_factor
+        self.residual_connection = residual_connection
+        self.scale_qk = scale_qk
+        self.scale = dim_head ** -0.5 if scale_qk else 1.0
+        self.heads = heads
+        self.dim_head = dim_head
+        self.group_norm = None
+        self.spatial_norm = None
+        self.norm_cross = None
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=bias)
+        self.to_k = nn.Linear(self.cross_attention_dim, inner_dim, bias=bias)
+        self.to_v = nn.Linear(self.cross_attention_dim, inner_dim, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner_dim, query_dim, bias=out_bias), nn.Dropout(dropout)])
+        if bias:
+            raise ValueError("theatergen_amd.Attention: q/k/v bias is not used by SD UNets (unsupported)")
+        self._packed = {}
+        self.set_processor(processor if processor is not None else AttnProcessor())
+
+    def set_processor(self, processor):
+        if hasattr(self, "processor") and isinstance(self.processor, nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **cross_attention_kwargs)
+
+    # ---- packed (fused) projection weights, rebuilt when the parameters change ---------------------------
+    def _cached(self, name, tensors, build):
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in tensors)
+        hit = self._packed.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, build())
+            self._packed[name] = hit
+        return hit[1]
+
+    def qkv_weight(self):
+        """[3*inner, C]: rows = to_q ; to_k ; to_v (self-attention, one GEMM)."""
+        ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight]
+        return self._cached("qkv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
+
+    def kv_weight(self):
+        ws = [self.to_k.weight, self.to_v.weight]
+        return self._cached("kv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
+
+
+def _check_common(attn, hidden_states, attention_mask, attn_process_fn):
+    if attention_mask is not None:
+        raise NotImplementedError("theatergen_amd: attention_mask is not used on the TheaterGen hot path")
+    if attn_process_fn is not None:
+        raise NotImplementedError("theatergen_amd: attn_process_fn would need materialised probabilities (unsupported)")
+    if not hidden_states.is_cuda:
+        raise RuntimeError("theatergen_amd: attention runs on the GPU only (no CPU fallback)")
+
+
+def _to_tokens(hidden_states):
+    """[B,N,C] (or [B,C,H,W] -> token-major through tg_transpose) -> ([B*N, C] view, B, N, C, shape4)."""
+    if hidden_states.ndim == 4:
+        b, c, h, w = hidden_states.shape
+        x = ops.transpose(hidden_states.contiguous(), b, c, h * w)         # [b, hw, c]
+        return x.reshape(b * h * w, c), b, h * w, c, (b, c, h, w)
+    b, n, c = hidden_states.shape
+    return hidden_states.contiguous().reshape(b * n, c), b, n, c, None
+
+
+def _finish(attn, o2d, B, N, C, shape4, x_tokens, fused_residual):
+    """to_out projection (+bias) with the optional residual / rescale folded into the GEMM epilogue:
+    ``(to_out(o) + residual) / rescale_output_factor`` (reference :358-369).  ``x_tokens`` is the token-major
+    view of the processor input (= the residual of ``residual_connection``)."""
+    res = fused_residual
+    if res is None and attn.residual_connection:
+        res = x_tokens
+    out = ops.linear(o2d, attn.to_out[0].weight, attn.to_out[0].bias, res=res, out_scale=1.0 / attn.rescale_output_factor)
+    if shape4 is not None:
+        b, c, h, w = shape4
+        return ops.transpose(out, b, h * w, c).reshape(b, c, h, w)
+    return out.reshape(B, N, C)
+
+
+def _enc_rows(enc):
+    """encoder_hidden_states [B, L, ctx] possibly narrowed along dim 1 (``enc[:, :end]``) -> (tensor, rows/batch, batch pitch)
+    for tg_gemm's batched-A addressing; falls back to a contiguous copy for any other layout."""
+    B, L, ctx = enc.shape
+    if enc.stride(2) == 1 and enc.stride(1) == ctx and enc.stride(0) >= L * ctx and enc.stride(0) % 8 == 0:
+        return enc, L, enc.stride(0)
+    enc = enc.contiguous()
+    return enc, L, L * ctx
+
+
+def _save_probs(attn, q, q_ld, k, k_ld, B, N, L, save_attn_to_dict, save_keys, attn_key, return_cond_ca_only,
+                return_token_ca_only, offload_cross_attn_to_cpu):
+    """Attention-map capture side channel (reference :532-551): fp32 [B', heads, N, tokens]."""
+    b0 = 0
+    if return_cond_ca_only:
+        assert B % 2 == 0, f"Samples are not in pairs: {B} samples"
+        b0 = B // 2
+    tokens = None
+    if return_token_ca_only is not None:
+        if isinstance(return_token_ca_only, int):
+            tokens = torch.tensor([return_token_ca_only], dtype=torch.int32, device=q.device)
+        else:
+            tokens = torch.as_tensor(return_token_ca_only).to(device=q.device, dtype=torch.int32).reshape(-1)
+    probs = ops.attn_probs(q, q_ld, N * q_ld, k, k_ld, L * k_ld, B, b0, attn.heads, attn.dim_head, N, L, attn.scale, tokens)
+    if offload_cross_attn_to_cpu:
+        probs = probs.cpu()
+    if save_attn_to_dict is not None and (save_keys is None or (tuple(attn_key) in save_keys)):
+        save_attn_to_dict[tuple(attn_key)] = probs
+    return probs
+
+
+class AttnProcessor(nn.Module):
+    """Self-attention (and plain cross-attention) processor — reference :282-393."""
+
+    def __init__(self, hidden_size=None, cross_attention_dim=None):
+        super().__init__()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
+                 return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
+                 enable_flash_attn=True, _fused_residual=None):
+        _check_common(attn, hidden_states, attention_mask, attn_process_fn)
+        x, B, N, C, shape4 = _to_tokens(hidden_states)
+        inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
+        o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
+        if encoder_hidden_states is None:
+            # one GEMM: [Q | K] token-major + V^T per batch item
+            ldt = _round8(N)
+            qk = torch.empty((B * N, 2 * inner), dtype=x.dtype, device=x.device)
+            vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
+            ops.gemm(x, attn.qkv_weight(), B * N, 3 * inner, C, rows_per_batch=N, out=qk, n_split=2 * inner, out_t=vt, ldt=ldt)
+            ops.attention(qk, 2 * inner, N * 2 * inner, qk[:, inner:], 2 * inner, N * 2 * inner, vt, ldt, inner * ldt, N,
+                          B, heads, d, N, attn.scale, o, inner, N * inner)
+        else:
+            enc, L, enc_bs = _enc_rows(encoder_hidden_states)
+            ctx = enc.shape[2]
+            q = ops.linear(x, attn.to_q.weight)
+            ldt = _round8(L)
+            k = torch.empty((B * L, inner), dtype=x.dtype, device=x.device)
+            vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
+            ops.gemm(enc, attn.kv_weight(), B * L, 2 * inner, ctx, rows_per_batch=L, out=k, n_split=inner,
+                     out_t=vt, ldt=ldt, a_rows_per_batch=L, a_batch_stride=enc_bs)
+            ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
+                          o, inner, N * inner)
+            # like the reference (:371) self.return_attntion_probs is forced False; maps are still saved (:386-389)
+            if save_attn_to_dict is not None:
+                _save_probs(attn, q, inner, k, inner, B, N, L, save_attn_to_dict, save_keys, attn_key, return_cond_ca_only,
+                            return_token_ca_only, bool(save_attn_to_dict) or offload_cross_attn_to_cpu)
+        return _finish(attn, o, B, N, C, shape4, x, _fused_residual)
+
+
+AttentionProcessor = AttnProcessor
+
+
+class IPAttnProcessor(nn.Module):
+    """Decoupled text + image cross-attention for IP-Adapter — reference :396-553.
+
+    ``O = softmax(s Q Kt^T) Vt + scale * softmax(s Q Kip^T) Vip`` in one fused kernel; the last ``num_tokens``
+    rows of ``encoder_hidden_states`` are the image tokens (:467-471)."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, scale=1.0, num_tokens=4):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.scale = scale
+        self.num_tokens = num_tokens
+        self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self._packed = None
+        self._kv_cache = None
+        self._kv_bufs = None
+
+    def _ip_weight(self):
+        ws = (self.to_k_ip.weight, self.to_v_ip.weight)
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ws)
+        if self._packed is None or self._packed[0] != key:
+            with torch.no_grad():
+                self._packed = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+        return self._packed[1]
+
+    def project_kv(self, attn, enc):
+        """Text and image K / V^T from ``encoder_hidden_states`` (step-invariant: cached per tensor version)."""
+        B, Ltot, ctx = enc.shape
+        T = self.num_tokens
+        L = Ltot - T
+        inner = attn.inner_dim
+        key = (enc.data_ptr(), enc._version, tuple(enc.shape), enc.dtype, T, id(attn),
+               attn.to_k.weight._version, attn.to_v.weight._version, self.to_k_ip.weight._version, self.to_v_ip.weight._version)
+        if self._kv_cache is not None and self._kv_cache[0] == key:
+            return self._kv_cache[1]
+        if L < 1 or T < 1 or T > 64:
+            raise RuntimeError(f"IPAttnProcessor: need 1 <= num_tokens <= 64 and at least one text token (L={L}, T={T})")
+        ldt, ldi = _round8(L), _round8(T)
+        # buffers are allocated once per shape and refreshed IN PLACE, so a captured hipGraph of the UNet step
+        # keeps valid K / V^T pointers when new embeddings are copied into the same encoder tensor
+        bkey = (B, L, T, inner, enc.dtype, enc.device)
+        if self._kv_bufs is None or self._kv_bufs[0] != bkey:
+            self._kv_bufs = (bkey, (torch.empty((B * L, inner), dtype=enc.dtype, device=enc.device),
+                                    torch.zeros((B, inner, ldt), dtype=enc.dtype, device=enc.device),
+                                    torch.empty((B * T, inner), dtype=enc.dtype, device=enc.device),
+                                    torch.zeros((B, inner, ldi), dtype=enc.dtype, device=enc.device)))
+        k, vt, kip, vtip = self._kv_bufs[1]
+        ops.gemm(enc, attn.kv_weight(), B * L, 2 * inner, ctx, rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt,
+                 a_rows_per_batch=L, a_batch_stride=Ltot * ctx)
+        ops.gemm(enc.reshape(-1)[L * ctx:], self._ip_weight(), B * T, 2 * inner, ctx, rows_per_batch=T, out=kip,
+                 n_split=inner, out_t=vtip, ldt=ldi, a_rows_per_batch=T, a_batch_stride=Ltot * ctx)
+        kv = (k, vt, ldt, kip, vtip, ldi, L, T)
+        self._kv_cache = (key, kv)
+        return kv
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
+                 return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
+                 enable_flash_attn=True, _fused_residual=None):
+        _check_common(attn, hidden_states, attention_mask, attn_process_fn)
+        if encoder_hidden_states is None:
+            raise RuntimeError("IPAttnProcessor is a cross-attention processor: encoder_hidden_states is required")
+        x, B, N, C, shape4 = _to_tokens(hidden_states)
+        inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
+        enc = encoder_hidden_states.contiguous()
+        k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
+        q = ops.linear(x, attn.to_q.weight)
+        o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
+        ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
+                      o, inner, N * inner, k1=kip, k1_ld=inner, k1_bs=T * inner, vt1=vtip, vt1_ld=ldi, vt1_bs=inner * ldi,
+                      len1=T, w1=float(self.scale))
+        out = _finish(attn, o, B, N, C, shape4, x, _fused_residual)
+        if return_attntion_probs or save_attn_to_dict is not None:
+            probs = _save_probs(attn, q, inner, k, inner, B, N, L, save_attn_to_dict, save_keys, attn_key,
+                                return_cond_ca_only, return_token_ca_only, offload_cross_attn_to_cpu)
+            if return_attntion_probs:
+                return out, probs
+        return out
+
+
+class CNAttnProcessor:
+    """ControlNet processor: attends to the text tokens only — reference :861-923."""
+
+    def __init__(self, num_tokens=4):
+        self.num_tokens = num_tokens
+        self._plain = AttnProcessor()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, _fused_residual=None):
+        if encoder_hidden_states is not None:
+            end_pos = encoder_hidden_states.shape[1] - self.num_tokens
+            encoder_hidden_states = encoder_hidden_states[:, :end_pos]
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
+                           temb=temb, _fused_residual=_fused_residual)
+
+
+# the reference's torch-2 aliases (ip_adapter/ip_adapter.py:13-24 selects these names)
+AttnProcessor2_0 = AttnProcessor
+IPAttnProcessor2_0 = IPAttnProcessor
+CNAttnProcessor2_0 = CNAttnProcessor

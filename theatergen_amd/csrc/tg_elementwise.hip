@@ -123,11 +123,11 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T* x, int batch, in
 }
 
 template <typename T>
-__global__ void timestep_embedding_kernel(const float* t, int t_stride, int rows, int dim, int flip, float freq_shift,
-                                          T* out, long ldo) {
+__global__ void timestep_embedding_kernel(const float* t, const int* index, int t_stride, int rows, int dim, int flip,
+                                          float freq_shift, T* out, long ldo) {
   const int half = dim / 2;
   const int r = blockIdx.x;
-  const float tv = t[(long)r * t_stride];
+  const float tv = t[(index ? *index : 0) + (long)r * t_stride];
   for (int i = threadIdx.x; i < half; i += blockDim.x) {
     const float e = __expf(-9.210340371976184f * (float)i / ((float)half - freq_shift));  // ln(10000)
     const float a = tv * e;
@@ -228,6 +228,22 @@ __global__ __launch_bounds__(256) void compose_kernel(float* dst, const float* s
   }
 }
 
+// dst[b][c][r] = src[b][r][c]  (NCHW <-> token-major), 32x32 LDS tiles, pad 1 -> conflict-free
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* src, int rows, int cols, T* dst) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const T* s = src + (long)b * rows * cols;
+  T* d = dst + (long)b * rows * cols;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = s[(long)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) d[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 inline int grid_for(long n, int per_thread = 1) {
   long b = (n / per_thread + 255) / 256;
   if (b < 1) b = 1;
@@ -306,15 +322,15 @@ extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t 
   return TG_OK;
 }
 
-extern "C" int tg_timestep_embedding(int32_t dtype, const float* t, int32_t t_stride, int32_t rows, int32_t dim,
+extern "C" int tg_timestep_embedding(int32_t dtype, const float* t, const int32_t* index, int32_t t_stride, int32_t rows, int32_t dim,
                                      int32_t flip_sin_to_cos, float freq_shift, void* out, int64_t ldo, void* stream) {
   TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && t && out && rows > 0 && dim > 0 && dim % 2 == 0, TG_ERR_ARG,
            "tg_timestep_embedding: bad args");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == TG_BF16)
-    hipLaunchKernelGGL(timestep_embedding_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, t, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (bf16_t*)out, ldo);
+    hipLaunchKernelGGL(timestep_embedding_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, t, index, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (bf16_t*)out, ldo);
   else
-    hipLaunchKernelGGL(timestep_embedding_kernel<f16_t>, dim3(rows), dim3(128), 0, st, t, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (f16_t*)out, ldo);
+    hipLaunchKernelGGL(timestep_embedding_kernel<f16_t>, dim3(rows), dim3(128), 0, st, t, index, t_stride, rows, dim, flip_sin_to_cos, freq_shift, (f16_t*)out, ldo);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }
@@ -363,6 +379,17 @@ extern "C" int tg_masked_compose(float* dst, const float* src, const float* mask
   TG_CHECK(dst && src && mask && planes > 0 && hw > 0, TG_ERR_ARG, "tg_masked_compose: bad args");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(compose_kernel, dim3(grid_for(planes * hw)), dim3(256), 0, st, dst, src, mask, (long)planes, hw);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_transpose(int32_t dtype, const void* src, int32_t batch, int32_t rows, int32_t cols, void* dst, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && src && dst && batch > 0 && rows > 0 && cols > 0 && src != dst, TG_ERR_ARG,
+           "tg_transpose: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, rows, cols, (bf16_t*)dst);
+  else hipLaunchKernelGGL(transpose_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)src, rows, cols, (f16_t*)dst);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

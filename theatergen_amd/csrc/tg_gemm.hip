@@ -48,6 +48,7 @@ struct GemmParams {
   int splits;
   int kt_per_split;
   int tiles_n;
+  long a_rpb, a_bs;
 };
 
 template <typename T>
@@ -133,14 +134,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int ctot = p.c0 + p.c1;
 
   // per-thread row bookkeeping for the activation gather
-  long xbase[XR];   // plain: row index; conv: packed (valid) pixel info below
+  long xbase[XR];   // plain: element offset of the row in source 0
+  long xrow[XR];
   int x_oy[XR], x_ox[XR], x_ob[XR];
   bool x_ok[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     long m = m0 + lrow + 32 * i;
     x_ok[i] = m < p.M;
-    xbase[i] = m;
+    xbase[i] = m * p.c0;
+    xrow[i] = m;
+    if (!CONV && p.a_rpb > 0) { const long bb = m / p.a_rpb; xbase[i] = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
     if (CONV) {
       long mm = x_ok[i] ? m : 0;
       int hw = p.out_h * p.out_w;
@@ -173,11 +177,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       long pitch = p.c0;
       long kk = kc;
       bool kok = kc < p.K;
-      if (A1 != nullptr && k0 >= p.c0) { src = A1; pitch = p.c1; kk = kc - p.c0; }
+      const bool second = A1 != nullptr && k0 >= p.c0;
+      if (second) { src = A1; pitch = p.c1; kk = kc - p.c0; }
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (kok && x_ok[i]) v = *reinterpret_cast<const u32x4*>(src + xbase[i] * pitch + kk);
+        const long off = second ? xrow[i] * pitch : xbase[i];
+        if (kok && x_ok[i]) v = *reinterpret_cast<const u32x4*>(src + off + kk);
         xreg[i] = v;
       }
     } else {
@@ -367,6 +373,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.out = d->out; p.ldc = d->ldc; p.n_split = d->n_split; p.out_t = d->out_t; p.ldt = d->ldt;
   p.ws = reinterpret_cast<float*>(d->workspace);
   p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; p.tiles_n = (int)pl.tiles_n;
+  p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
   if (pl.splits > 1) {
     TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= (int64_t)pl.splits * d->M * d->N * 4, TG_ERR_ARG,
              "tg_gemm: split-K needs %lld workspace bytes, got %lld", (long long)pl.splits * d->M * d->N * 4,
@@ -404,6 +411,8 @@ int validate(const tg_gemm_desc* d) {
   } else {
     TG_CHECK(d->mode == 0, TG_ERR_ARG, "tg_gemm: bad mode %d", d->mode);
     TG_CHECK(ctot == d->K, TG_ERR_ARG, "tg_gemm: K (%lld) != c0+c1 (%d)", (long long)d->K, ctot);
+    if (d->a_rows_per_batch > 0)
+      TG_CHECK(d->a1 == nullptr && d->a_batch_stride % 8 == 0, TG_ERR_ARG, "tg_gemm: batched A needs a single source and a 16-byte aligned batch pitch");
   }
   if (d->n_split > 0) {
     TG_CHECK(d->out_t && d->n_split % 4 == 0 && d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bad transposed-output args");

@@ -38,7 +38,7 @@ __device__ __forceinline__ typename Vec<T>::v8 gn_load8(const GnParams& p, int b
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
-  extern __shared__ float sh[];  // [2][C]
+  extern __shared__ float sh[];  // [ry][2][C]: one private row per pixel-row of threads -> no atomics, deterministic
   const int C = p.c0 + p.c1;
   const int cpr = C / 8;
   const int b = blockIdx.y;
@@ -47,11 +47,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
   const long p_begin = (long)blk * per;
   long p_end = p_begin + per;
   if (p_end > p.hw) p_end = p.hw;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
-  __syncthreads();
   const int tx = threadIdx.x % p.cx;
   const int ty = threadIdx.x / p.cx;
   if (ty < p.ry) {
+    float* mine = sh + (size_t)ty * 2 * C;
     for (int c = tx; c < cpr; c += p.cx) {
       float s[8], q[8];
 #pragma unroll
@@ -67,10 +66,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        atomicAdd(&sh[c * 8 + j], s[j]);
-        atomicAdd(&sh[C + c * 8 + j], q[j]);
+        mine[c * 8 + j] = s[j];
+        mine[C + c * 8 + j] = q[j];
       }
     }
+  }
+  __syncthreads();
+  // fold the ry private rows into row 0 in a fixed order
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float a = sh[i];
+    for (int r = 1; r < p.ry; ++r) a += sh[(size_t)r * 2 * C + i];
+    sh[i] = a;
   }
   __syncthreads();
   const int cpg = C / p.groups;
@@ -252,7 +258,7 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
   p.ry = 256 / p.cx;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(p.nblk, batch);
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)p.ry * 2 * C * sizeof(float);
   if (dtype == TG_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(gn_partial_kernel<f16_t>, grid, dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();

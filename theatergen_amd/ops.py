@@ -46,7 +46,8 @@ def workspace(nbytes, device):
 
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
-         res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0):
+         res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
+         a_rows_per_batch=0, a_batch_stride=0):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -80,6 +81,7 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.ldt = int(ldt)
     d.force_split_k = force_split_k
     d.force_tile = force_tile
+    d.a_rows_per_batch, d.a_batch_stride = int(a_rows_per_batch), int(a_batch_stride)
     need = L.tg_gemm_workspace_bytes(C.byref(d))
     if need < 0:
         _lib.check(-1)
@@ -186,6 +188,14 @@ def add(a, b, out=None):
     return out
 
 
+def transpose(src, batch, rows, cols, out=None):
+    """out[b, c, r] = src[b, r, c]"""
+    if out is None:
+        out = torch.empty((batch, cols, rows), dtype=src.dtype, device=src.device)
+    _lib.check(_lib.lib().tg_transpose(_dt(src), _ptr(src), batch, rows, cols, _ptr(out), _stream()))
+    return out
+
+
 _SRC = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
 
@@ -207,9 +217,9 @@ def conv_out(x, weight_packed, bias, batch, h, w, cout, out_dtype):
     return out
 
 
-def timestep_embedding(t_dev, rows, dim, flip_sin_to_cos, freq_shift, dtype, t_stride=0):
+def timestep_embedding(t_dev, rows, dim, flip_sin_to_cos, freq_shift, dtype, t_stride=0, index=None):
     out = torch.empty((rows, dim), dtype=dtype, device=t_dev.device)
-    _lib.check(_lib.lib().tg_timestep_embedding(_dt(out), _ptr(t_dev), t_stride, rows, dim, 1 if flip_sin_to_cos else 0,
+    _lib.check(_lib.lib().tg_timestep_embedding(_dt(out), _ptr(t_dev), _ptr(index), t_stride, rows, dim, 1 if flip_sin_to_cos else 0,
                                                 float(freq_shift), _ptr(out), dim, _stream()))
     return out
 

@@ -1,0 +1,187 @@
+"""The two denoising loops that call the hot path, restructured for MI355X (reference ``models/pipelines.py``).
+
+Reference loop bodies: stage 1 ``generate_semantic_guidance`` :406-453 (``cat([latents]*2)`` -> UNet -> CFG :441-442
+-> ``scheduler.step`` :447 -> ``latents_all.append(latents.cpu())`` :449-453) and stage 2
+``final_image_generation`` :742-835 (same + frozen-mask replace :833-834); IP embeds ``prepare_ip_embeds`` :860-950.
+
+Here one step = ONE captured hipGraph (UNet CFG call + fused CFG/DDIM/mask epilogue): the timestep table, DDIM
+coefficient table and step counter live on the device, the epilogue writes the next UNet input and the per-step
+history row itself, so the 50-step loop is 50 graph replays with no host<->device traffic (the reference syncs
+and copies latents to the CPU every step).  Any number of independent character images ride in the batch
+dimension (CFG batch 2*n: all uncond rows first, then all cond rows = ``noise_pred.chunk(2)`` order).
+"""
+import torch
+
+from . import ops
+from .scheduler import DDIMScheduler
+from .unet import DeviceSchedule
+
+
+class SDPipe:
+    """Minimal pipeline object: what ``IPAdapter`` and the latent utilities read from ``adapter.pipe``
+    (``.unet``, ``.scheduler``, ``.controlnet``; reference ``ip_adapter.py:74``, ``utils/latents.py:261``)."""
+
+    def __init__(self, unet, scheduler=None, controlnet=None):
+        self.unet = unet
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler(prediction_type=unet.config.prediction_type)
+        self.controlnet = controlnet
+        self.vae_scale_factor = 8
+
+    def to(self, device, dtype=None):
+        self.unet.to(device=device, dtype=dtype) if dtype is not None else self.unet.to(device)
+        return self
+
+
+def prepare_ip_embeds(prompt_embeds, negative_prompt_embeds, image_prompt_embeds, uncond_image_prompt_embeds):
+    """Text + image tokens along the sequence axis, negatives first (reference pipelines.py:230-233, 369-370, 937-948).
+    Inputs [n, 77, D] / [n, T, D]; returns [2n, 77+T, D] = [all negative rows ; all positive rows]."""
+    pos = torch.cat([prompt_embeds, image_prompt_embeds.to(prompt_embeds.dtype)], dim=1)
+    neg = torch.cat([negative_prompt_embeds, uncond_image_prompt_embeds.to(prompt_embeds.dtype)], dim=1)
+    return torch.cat([neg, pos], dim=0)
+
+
+class DenoiseEngine:
+    """Batched CFG denoiser for ``n_img`` independent character images on one GPU.
+
+    ``run()`` returns ``latents_all`` fp32 [steps+1, n_img, C, h, w] (row 0 = the input latents), the
+    ``torch.stack(latents_all)`` of reference pipelines.py:488 for every image of the batch."""
+
+    def __init__(self, unet, scheduler=None, n_img=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
+                 enc_len=81, use_graph=True):
+        self.unet = unet
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler(prediction_type=unet.config.prediction_type)
+        self.n_img = n_img
+        self.h, self.w = height // 8, width // 8
+        self.steps = num_inference_steps
+        self.g = guidance_scale
+        self.use_graph = use_graph
+        dev, dt, cfg = unet.device, unet.dtype, unet.config
+        self.dev, self.dt = dev, dt
+        C = cfg.in_channels
+        self.scheduler.set_timesteps(num_inference_steps)
+        self.timesteps = self.scheduler.timesteps.clone()
+        self.t_table = self.timesteps.to(device=dev, dtype=torch.float32)
+        self.coef = self.scheduler.coef_table().to(dev)
+        self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sched = DeviceSchedule(self.t_table, self.step_idx)
+        self.latents = torch.zeros((n_img, C, self.h, self.w), dtype=torch.float32, device=dev)
+        self.model_in = torch.zeros((2 * n_img, C, self.h, self.w), dtype=dt, device=dev)
+        self.enc = torch.zeros((2 * n_img, enc_len, cfg.cross_attention_dim), dtype=dt, device=dev)
+        self.history = torch.zeros((num_inference_steps + 1, n_img, C, self.h, self.w), dtype=torch.float32, device=dev)
+        self.frozen = None
+        self.frozen_mask = None
+        self.frozen_steps = 0
+        self.added = None
+        self.graph = None
+        self._graph_sig = None
+        self.pred_type = 0 if self.scheduler.config.prediction_type == "epsilon" else 1
+
+    # ---- conditioning -----------------------------------------------------------------------------------
+    def set_conditioning(self, encoder_hidden_states, added_cond_kwargs=None):
+        """[2*n_img, L, D] (negatives first).  Copied into the engine's static buffer; the step-invariant text /
+        image K, V^T of every IP cross-attention layer are re-projected once here (not once per step)."""
+        if tuple(encoder_hidden_states.shape) != tuple(self.enc.shape):
+            raise ValueError(f"conditioning shape {tuple(encoder_hidden_states.shape)} != engine shape {tuple(self.enc.shape)}")
+        self.enc.copy_(encoder_hidden_states)
+        if added_cond_kwargs is not None:
+            if self.added is None:
+                self.added = {k: v.to(self.dev).clone() for k, v in added_cond_kwargs.items()}
+            else:
+                for k, v in added_cond_kwargs.items():
+                    self.added[k].copy_(v)
+        self._refresh_kv()
+
+    def _refresh_kv(self):
+        from .attention_processor import Attention, IPAttnProcessor
+        for m in self.unet.modules():
+            if isinstance(m, Attention) and isinstance(m.processor, IPAttnProcessor):
+                m.processor.project_kv(m, self.enc)
+
+    def set_frozen(self, frozen_latents, frozen_mask, frozen_steps):
+        """Stage-2 frozen-mask replace (reference pipelines.py:733-738, 833-834): ``frozen_latents`` fp32
+        [steps+1, n_img, C, h, w], ``frozen_mask`` fp32 [h, w] or [n_img, h, w]."""
+        if self.graph is not None and (self.frozen is None) != (frozen_latents is None):
+            self.graph = None          # epilogue signature changed: re-capture
+        if frozen_latents is None:
+            self.frozen = self.frozen_mask = None
+            self.frozen_steps = 0
+            return
+        if self.frozen is None:
+            self.frozen = torch.empty_like(self.history)
+            self.frozen_mask = torch.empty((self.n_img, self.h, self.w), dtype=torch.float32, device=self.dev)
+        self.frozen.copy_(frozen_latents)
+        self.frozen_mask.copy_(frozen_mask.to(torch.float32).expand(self.n_img, self.h, self.w))
+        if self.graph is not None and frozen_steps != self.frozen_steps:
+            self.graph = None          # frozen_steps is a launch constant
+        self.frozen_steps = int(frozen_steps)
+
+    # ---- one step ---------------------------------------------------------------------------------------
+    def _step(self):
+        noise_pred = self.unet(self.model_in, self.sched, self.enc, added_cond_kwargs=self.added, return_dict=False,
+                               out_dtype=torch.float32)[0]
+        ops.step_epilogue(noise_pred, self.latents, self.g, self.coef, self.step_idx, advance=True,
+                          prediction_type=self.pred_type, frozen=self.frozen,
+                          frozen_mask=self.frozen_mask, frozen_steps=self.frozen_steps, history=self.history,
+                          model_in=self.model_in)
+
+    def _signature(self):
+        """Launch constants baked into a captured graph: the IP scales (IPAdapter.set_scale mutates them between
+        characters, reference pipelines.py:196, 213) and the frozen-mask configuration."""
+        from .attention_processor import IPAttnProcessor
+        scales = tuple(float(p.scale) for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor))
+        return scales, self.frozen is not None, self.frozen_steps, self.g
+
+    def _reset(self, latents):
+        self.latents.copy_(latents.to(device=self.dev, dtype=torch.float32))
+        self.history[0].copy_(self.latents)
+        self.model_in[:self.n_img].copy_(self.latents)           # dtype cast on copy = the `.half()` of pipelines.py:414
+        self.model_in[self.n_img:].copy_(self.latents)
+        self.step_idx.zero_()
+
+    def _capture(self):
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            self._step()                                          # warm-up: allocator, packed weights, K/V caches
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        self.graph = g
+
+    def run(self, latents):
+        """latents [n_img, C, h, w] (any float dtype / device) -> latents_all fp32 [steps+1, n_img, C, h, w] on the GPU."""
+        with torch.no_grad():
+            sig = self._signature()
+            if self.use_graph and (self.graph is None or sig != self._graph_sig):
+                self._reset(latents)
+                self._capture()
+                self._graph_sig = sig
+            self._reset(latents)
+            for _ in range(self.steps):
+                if self.use_graph:
+                    self.graph.replay()
+                else:
+                    self._step()
+        return self.history
+
+
+def denoise_single_object(adapter, prompt_embeds, negative_prompt_embeds, input_latents, scale, clip_image_embeds=None,
+                          image_prompt_embeds=None, uncond_image_prompt_embeds=None, num_inference_steps=50,
+                          guidance_scale=7.5, engine=None):
+    """Stage-1 per-character generation core (reference ``generate_semantic_guidance`` SD-1.5 branch, :183-247 image
+    prompt + scale, :369-453 loop, :488 stack): returns ``(latents [1,C,h,w], latents_all [steps+1,1,C,h,w])``."""
+    adapter.set_scale(scale)
+    if image_prompt_embeds is None:
+        image_prompt_embeds, uncond_image_prompt_embeds = adapter.get_image_embeds(clip_image_embeds=clip_image_embeds)
+    enc = prepare_ip_embeds(prompt_embeds.to(adapter.pipe.unet.dtype), negative_prompt_embeds.to(adapter.pipe.unet.dtype),
+                            image_prompt_embeds, uncond_image_prompt_embeds)
+    n = prompt_embeds.shape[0]
+    if engine is None:
+        engine = DenoiseEngine(adapter.pipe.unet, adapter.pipe.scheduler, n_img=n, height=input_latents.shape[-2] * 8,
+                               width=input_latents.shape[-1] * 8, num_inference_steps=num_inference_steps,
+                               guidance_scale=guidance_scale, enc_len=enc.shape[1])
+    engine.set_conditioning(enc)
+    latents_all = engine.run(input_latents)
+    return latents_all[-1], latents_all

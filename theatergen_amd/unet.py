@@ -1,0 +1,528 @@
+"""MI355X-native ``UNet2DConditionModel`` with the diffusers call surface the reference uses.
+
+Structure (block order, channel plan, where attention sits) follows the reference's UNet specification:
+``models/unet_2d_condition.py`` (ctor :209-593, ``forward`` :725-1023), ``models/unet_2d_blocks.py``
+(CrossAttnDownBlock2D :279-451, DownBlock2D :454-537, UNetMidBlock2DCrossAttn :155-276, CrossAttnUpBlock2D
+:540-713, UpBlock2D :716-797), ``models/transformer_2d.py`` (:216-370), ``models/attention.py``
+(BasicTransformerBlock :156-240, FeedForward/GEGLU :243-338); SDXL ``text_time`` embedding
+``ip_adapter/unet_2d_condition.py:937-954``.  Module / parameter names equal the diffusers state-dict keys, so
+``load_state_dict`` of an SD-1.5 / SD-2.1 / SDXL checkpoint works, and ``unet.attn_processors`` /
+``unet.set_attn_processor`` behave as in the reference (``models/unet_2d_condition.py:596-648``).
+
+Execution is MI355X-first, not a module-by-module translation:
+  * activations stay token-major ("NHWC") [B*h*w, C] end to end: the NCHW<->[B,HW,C] permutes of
+    Transformer2DModel (transformer_2d.py:289, 324) and the skip-connection ``torch.cat`` (unet_2d_blocks.py:648-651)
+    do not exist — GroupNorm and the implicit-GEMM conv read two sources;
+  * every conv / linear is the MFMA GEMM (``tg_gemm``) with bias, time-embedding add, residual add and scale in
+    its epilogue; the 22 ResBlock time projections are ONE GEMM per step;
+  * attention is the fused flash kernel (no [B*h, N, N] tensor); text / image K, V^T are projected once per
+    conditioning, not once per step;
+  * ``torch.nn`` modules are parameter containers only.  No PyTorch compute, no CPU fallback.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor
+from .config import UNetConfig
+from .weights_pack import pack_conv1x1, pack_conv3x3
+
+
+class DeviceSchedule:
+    """Device-resident timestep table + step counter: pass as ``timestep`` so a captured step graph replays
+    without host-side updates (``table`` fp32 [n_steps], ``index`` int32 [1] advanced by ``tg_step_epilogue``)."""
+
+    def __init__(self, table, index):
+        self.table, self.index = table, index
+
+
+class _Act:
+    """A token-major activation: 2-D tensor [B*h*w, C] + its geometry."""
+    __slots__ = ("t", "b", "h", "w", "c")
+
+    def __init__(self, t, b, h, w, c):
+        self.t, self.b, self.h, self.w, self.c = t, b, h, w, c
+
+    @property
+    def hw(self):
+        return self.h * self.w
+
+
+class _Packed:
+    """Kernel-layout copies of a module's weights, rebuilt when the parameters change (load_state_dict / .to)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, name, tensors, build):
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in tensors)
+        hit = self._c.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, build())
+            self._c[name] = hit
+        return hit[1]
+
+
+class ResnetBlock2D(nn.Module):
+    """diffusers 0.21.4 ResnetBlock2D semantics: h = conv1(silu(GN(x))) + Linear(silu(temb));
+    h = conv2(silu(GN(h))); out = (shortcut(x) + h) / output_scale_factor."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, groups=32, eps=1e-5, output_scale_factor=1.0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.groups, self.eps, self.output_scale_factor = groups, eps, output_scale_factor
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self._p = _Packed()
+        self.temb_slot = None      # (offset, width) into the fused time-projection output, set by the UNet
+
+    def run(self, x: _Act, skip: _Act, tproj):
+        """x (+ skip = channel concat) -> _Act.  ``tproj`` = fused time projections [B, sum(cout)]."""
+        c1 = skip.c if skip is not None else 0
+        assert x.c + c1 == self.in_channels
+        w1 = self._p.get("c1", [self.conv1.weight], lambda: pack_conv3x3(self.conv1.weight.detach()))
+        w2 = self._p.get("c2", [self.conv2.weight], lambda: pack_conv3x3(self.conv2.weight.detach()))
+        h = ops.groupnorm(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, silu=True,
+                          x1=skip.t if skip is not None else None)
+        off, width = self.temb_slot
+        h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias, bvec=tproj[:, off:off + width],
+                        rows_per_batch=x.hw)
+        h = ops.groupnorm(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias, silu=True)
+        if self.conv_shortcut is not None:
+            ws = self._p.get("sc", [self.conv_shortcut.weight], lambda: pack_conv1x1(self.conv_shortcut.weight.detach()))
+            res = ops.gemm(x.t, ws, x.b * x.hw, self.out_channels, self.in_channels, a1=skip.t if skip is not None else None,
+                           c0=x.c, c1=c1, bias=self.conv_shortcut.bias)
+        else:
+            res = x.t
+        out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, bias=self.conv2.bias, res=res,
+                          out_scale=1.0 / self.output_scale_factor)
+        return _Act(out, x.b, x.h, x.w, self.out_channels)
+
+
+class Downsample2D(nn.Module):
+    """conv3x3 stride 2, padding 1 (``Downsample2D(use_conv=True, padding=1, name="op")``, unet_2d_blocks.py:355-362)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+        self._p = _Packed()
+
+    def run(self, x: _Act):
+        w = self._p.get("w", [self.conv.weight], lambda: pack_conv3x3(self.conv.weight.detach()))
+        out = ops.conv3x3(x.t, w, x.b, x.h, x.w, x.c, stride=2, bias=self.conv.bias)
+        return _Act(out, x.b, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, x.c)
+
+
+class Upsample2D(nn.Module):
+    """nearest x2 folded into the conv3x3 gather (``Upsample2D(use_conv=True)``, unet_2d_blocks.py:620-622)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+        self._p = _Packed()
+
+    def run(self, x: _Act):
+        w = self._p.get("w", [self.conv.weight], lambda: pack_conv3x3(self.conv.weight.detach()))
+        out = ops.conv3x3(x.t, w, x.b, x.h, x.w, x.c, upsample=True, bias=self.conv.bias)
+        return _Act(out, x.b, 2 * x.h, 2 * x.w, x.c)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    """net.0 = GEGLU(C -> 4C), net.1 = Dropout, net.2 = Linear(4C -> C)  (models/attention.py:243-292)."""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        inner = dim * mult
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
+
+    def run(self, x2d, residual):
+        f = ops.linear(x2d, self.net[0].proj.weight, self.net[0].proj.bias)
+        g = ops.geglu(f)
+        return ops.linear(g, self.net[2].weight, self.net[2].bias, res=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    """LN -> attn1 (self) ; LN -> attn2 (cross) ; LN -> GEGLU FF, all residual (models/attention.py:156-240)."""
+
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(query_dim=dim, heads=heads, dim_head=dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=heads, dim_head=dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    @staticmethod
+    def _call(attn, x2d, b, n, enc, residual, kwargs):
+        proc = attn.processor
+        x3 = x2d.reshape(b, n, -1)
+        if isinstance(proc, (AttnProcessor, IPAttnProcessor)) and attn.rescale_output_factor == 1.0 \
+                and not attn.residual_connection and not kwargs.get("return_attntion_probs"):
+            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual, **kwargs).reshape(b * n, -1)
+        if isinstance(proc, CNAttnProcessor):
+            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual).reshape(b * n, -1)
+        # foreign processor: plain diffusers protocol, residual added afterwards
+        out = attn(x3, encoder_hidden_states=enc, **kwargs)
+        if isinstance(out, tuple):
+            out = out[0]
+        return ops.add(out.reshape(b * n, -1).contiguous(), residual)
+
+    def run(self, x2d, b, n, enc, ca_kwargs):
+        h = ops.layernorm(x2d, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
+        h = ops.layernorm(x2d, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x2d = self._call(self.attn2, h, b, n, enc, x2d, ca_kwargs)
+        h = ops.layernorm(x2d, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff.run(h, x2d)
+
+
+class Transformer2DModel(nn.Module):
+    """GroupNorm(eps 1e-6) -> proj_in -> N x BasicTransformerBlock -> proj_out -> + residual (transformer_2d.py:216-370)."""
+
+    def __init__(self, heads, dim_head, in_channels, num_layers, cross_attention_dim, groups, use_linear_projection):
+        super().__init__()
+        inner = heads * dim_head
+        assert inner == in_channels
+        self.groups = groups
+        self.use_linear_projection = use_linear_projection
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        if use_linear_projection:
+            self.proj_in = nn.Linear(in_channels, inner)
+            self.proj_out = nn.Linear(inner, in_channels)
+        else:
+            self.proj_in = nn.Conv2d(in_channels, inner, 1)
+            self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim) for _ in range(num_layers)])
+        self._p = _Packed()
+
+    def _w(self, name, mod):
+        if self.use_linear_projection:
+            return mod.weight
+        return self._p.get(name, [mod.weight], lambda: pack_conv1x1(mod.weight.detach()))
+
+    def run(self, x: _Act, enc, ca_kwargs):
+        y = ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False)
+        y = ops.linear(y, self._w("in", self.proj_in), self.proj_in.bias)
+        base_key = list(ca_kwargs.get("attn_key", [])) if "attn_key" in ca_kwargs else None
+        for i, blk in enumerate(self.transformer_blocks):
+            if base_key is not None:
+                ca_kwargs["attn_key"] = base_key + [i]           # transformer_2d.py:299-304
+            y = blk.run(y, x.b, x.hw, enc, ca_kwargs)
+        out = ops.linear(y, self._w("out", self.proj_out), self.proj_out.bias, res=x.t)
+        return _Act(out, x.b, x.h, x.w, x.c)
+
+
+class _Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.resnets = nn.ModuleList()
+        self.has_cross_attention = False
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def run(self, x2d):
+        h = ops.linear(x2d, self.linear_1.weight, self.linear_1.bias, act=ops.ACT_SILU)
+        return ops.linear(h, self.linear_2.weight, self.linear_2.bias)
+
+
+class UNet2DConditionOutput(SimpleNamespace):
+    pass
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, config: UNetConfig = None, **kw):
+        super().__init__()
+        cfg = config if config is not None else UNetConfig(**kw)
+        self.config = cfg
+        boc = tuple(cfg.block_out_channels)
+        nb = len(boc)
+        ted = cfg.time_embed_dim
+        heads_t = cfg.per_block(cfg.attention_head_dim)
+        tl_t = cfg.per_block(cfg.transformer_layers_per_block)
+        lpb = cfg.per_block(cfg.layers_per_block)
+        g, eps, ctx, lin = cfg.norm_num_groups, cfg.norm_eps, cfg.cross_attention_dim, cfg.use_linear_projection
+
+        self.conv_in = nn.Conv2d(cfg.in_channels, boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], ted)
+        if cfg.addition_embed_type == "text_time":
+            self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted)
+        elif cfg.addition_embed_type is not None:
+            raise ValueError(f"addition_embed_type {cfg.addition_embed_type} unsupported")
+
+        def tfm(c, heads, layers):
+            return Transformer2DModel(heads, c // heads, c, layers, ctx, g, lin)
+
+        self.down_blocks = nn.ModuleList()
+        out_c = boc[0]
+        for i, bt in enumerate(cfg.down_block_types):
+            in_c, out_c = out_c, boc[i]
+            blk = _Block()
+            if bt == "CrossAttnDownBlock2D":
+                blk.has_cross_attention = True
+                blk.attentions = nn.ModuleList()
+            elif bt != "DownBlock2D":
+                raise ValueError(f"unknown down block {bt}")
+            for j in range(lpb[i]):
+                blk.resnets.append(ResnetBlock2D(in_c if j == 0 else out_c, out_c, ted, g, eps))
+                if blk.has_cross_attention:
+                    blk.attentions.append(tfm(out_c, heads_t[i], tl_t[i]))
+            blk.downsamplers = nn.ModuleList([Downsample2D(out_c)]) if i != nb - 1 else None
+            self.down_blocks.append(blk)
+
+        mid = _Block()
+        mid.has_cross_attention = True
+        mid.resnets.append(ResnetBlock2D(boc[-1], boc[-1], ted, g, eps))
+        mid.attentions = nn.ModuleList([tfm(boc[-1], heads_t[-1], tl_t[-1])])
+        mid.resnets.append(ResnetBlock2D(boc[-1], boc[-1], ted, g, eps))
+        self.mid_block = mid
+
+        self.up_blocks = nn.ModuleList()
+        rboc, rheads, rtl, rlpb = tuple(reversed(boc)), tuple(reversed(heads_t)), tuple(reversed(tl_t)), tuple(reversed(lpb))
+        out_c = rboc[0]
+        for i, bt in enumerate(cfg.up_block_types):
+            prev_out, out_c = out_c, rboc[i]
+            in_c = rboc[min(i + 1, nb - 1)]
+            blk = _Block()
+            if bt == "CrossAttnUpBlock2D":
+                blk.has_cross_attention = True
+                blk.attentions = nn.ModuleList()
+            elif bt != "UpBlock2D":
+                raise ValueError(f"unknown up block {bt}")
+            n = rlpb[i] + 1
+            for j in range(n):
+                skip_c = in_c if j == n - 1 else out_c
+                res_in = prev_out if j == 0 else out_c
+                blk.resnets.append(ResnetBlock2D(res_in + skip_c, out_c, ted, g, eps))
+                if blk.has_cross_attention:
+                    blk.attentions.append(tfm(out_c, rheads[i], rtl[i]))
+            blk.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if i != nb - 1 else None
+            self.up_blocks.append(blk)
+
+        self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
+        self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
+
+        # fused time projections: one GEMM for all ResBlocks
+        self._resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        off = 0
+        for r in self._resnets:
+            r.temb_slot = (off, r.out_channels)
+            off += r.out_channels
+        self._tproj_width = off
+        self._p = _Packed()
+        self._t_cache = {}
+        for p_ in self.parameters():
+            p_.requires_grad_(False)
+
+    # ---- diffusers surface ----------------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    @property
+    def attn_processors(self):
+        """{"...attn1.processor": proc, ...} in module order (models/unet_2d_condition.py:596-618)."""
+        procs = {}
+        for name, m in self.named_modules():
+            if isinstance(m, Attention):
+                procs[f"{name}.processor"] = m.processor
+        return procs
+
+    def set_attn_processor(self, processor):
+        """dict keyed like ``attn_processors`` or a single processor (models/unet_2d_condition.py:620-648)."""
+        attns = {f"{n}.processor": m for n, m in self.named_modules() if isinstance(m, Attention)}
+        if isinstance(processor, dict):
+            if len(processor) != len(attns):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match "
+                                 f"the number of attention layers: {len(attns)}. Please make sure to pass {len(attns)} processor classes.")
+            for k, m in attns.items():
+                m.set_processor(processor[k])
+        else:
+            for m in attns.values():
+                m.set_processor(processor)
+
+    def set_default_attn_processor(self):
+        self.set_attn_processor(AttnProcessor())
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def _timestep_dev(self, timestep, B):
+        """-> (device fp32 tensor, stride) for the embedding kernel; Python numbers are cached per value."""
+        dev = self.device
+        if isinstance(timestep, DeviceSchedule):
+            return timestep.table, 0
+        if torch.is_tensor(timestep):
+            t = timestep
+            if t.device != dev or t.dtype != torch.float32:
+                t = t.to(device=dev, dtype=torch.float32)
+            t = t.reshape(-1)
+            return t, (1 if t.numel() == B and B > 1 else 0)
+        key = float(timestep)
+        if key not in self._t_cache:
+            self._t_cache[key] = torch.tensor([key], dtype=torch.float32, device=dev)
+        return self._t_cache[key], 0
+
+    def _tproj_weight(self):
+        ws = [r.time_emb_proj.weight for r in self._resnets]
+        bs = [r.time_emb_proj.bias for r in self._resnets]
+        return self._p.get("tproj", ws + bs, lambda: (torch.cat([w.detach() for w in ws], 0).contiguous(),
+                                                       torch.cat([b.detach() for b in bs], 0).contiguous()))
+
+    def time_embed(self, timestep, B, added_cond_kwargs=None):
+        cfg = self.config
+        dt = self.dtype
+        t, stride = self._timestep_dev(timestep, B)
+        index = timestep.index if isinstance(timestep, DeviceSchedule) else None
+        t_emb = ops.timestep_embedding(t, B, cfg.block_out_channels[0], cfg.flip_sin_to_cos, cfg.freq_shift, dt, t_stride=stride,
+                                       index=index)
+        emb = self.time_embedding.run(t_emb)
+        if cfg.addition_embed_type == "text_time":
+            if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+                raise ValueError("addition_embed_type 'text_time' requires `text_embeds` and `time_ids` in `added_cond_kwargs`")
+            text_embeds = added_cond_kwargs["text_embeds"].to(dt)
+            time_ids = added_cond_kwargs["time_ids"].to(device=self.device, dtype=torch.float32).contiguous()
+            n_ids = time_ids.shape[1]
+            d_add = cfg.addition_time_embed_dim
+            add_in = torch.empty((B, text_embeds.shape[1] + n_ids * d_add), dtype=dt, device=self.device)
+            add_in[:, :text_embeds.shape[1]].copy_(text_embeds)          # memory placement only
+            te = ops.timestep_embedding(time_ids.reshape(-1), B * n_ids, d_add, True, 0.0, dt, t_stride=1)
+            add_in[:, text_embeds.shape[1]:].copy_(te.reshape(B, n_ids * d_add))
+            aug = ops.linear(add_in, self.add_embedding.linear_1.weight, self.add_embedding.linear_1.bias, act=ops.ACT_SILU)
+            emb = ops.linear(aug, self.add_embedding.linear_2.weight, self.add_embedding.linear_2.bias, res=emb)
+        w, b = self._tproj_weight()
+        tproj = ops.linear(ops.act(emb, ops.ACT_SILU), w, b)            # [B, sum(cout)]: all ResBlock time projections
+        return emb, tproj
+
+    def _residual(self, act: _Act, extra):
+        """ControlNet / adapter residual (NCHW tensor from a diffusers module) added to a token-major activation."""
+        e = extra.to(act.t.dtype).contiguous()
+        e_tok = ops.transpose(e, act.b, act.c, act.hw).reshape(act.b * act.hw, act.c)
+        return _Act(ops.add(act.t, e_tok), act.b, act.h, act.w, act.c)
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None, attention_mask=None,
+                cross_attention_kwargs=None, added_cond_kwargs=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, encoder_attention_mask=None, return_dict=True, out_dtype=None):
+        cfg = self.config
+        if attention_mask is not None or encoder_attention_mask is not None or class_labels is not None or timestep_cond is not None:
+            raise NotImplementedError("attention masks / class labels / timestep_cond are not on the TheaterGen hot path")
+        if not sample.is_cuda:
+            raise RuntimeError("theatergen_amd UNet runs on the GPU only (no CPU fallback)")
+        dt = self.dtype
+        B, _, H, W = sample.shape
+        enc = encoder_hidden_states
+        if enc.dtype != dt:
+            enc = enc.to(dt)
+        enc = enc.contiguous()
+        ca_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
+        track_keys = cross_attention_kwargs is not None
+
+        emb, tproj = self.time_embed(timestep, B, added_cond_kwargs)
+
+        w_in = self._p.get("conv_in", [self.conv_in.weight], lambda: pack_conv3x3(self.conv_in.weight.detach()))
+        x = _Act(ops.conv_in(sample.contiguous(), w_in, self.conv_in.bias, cfg.block_out_channels[0], dt), B, H, W,
+                 cfg.block_out_channels[0])
+
+        res = [x]
+        for i, blk in enumerate(self.down_blocks):
+            for j, resnet in enumerate(blk.resnets):
+                x = resnet.run(x, None, tproj)
+                if blk.has_cross_attention:
+                    if track_keys:
+                        ca_kwargs["attn_key"] = ["down", i, j]
+                    x = blk.attentions[j].run(x, enc, ca_kwargs)
+                res.append(x)
+            if blk.downsamplers is not None:
+                x = blk.downsamplers[0].run(x)
+                res.append(x)
+
+        is_controlnet = mid_block_additional_residual is not None and down_block_additional_residuals is not None
+        is_adapter = mid_block_additional_residual is None and down_block_additional_residuals is not None
+        if is_adapter:
+            raise NotImplementedError("T2I-Adapter residuals are not on the TheaterGen hot path (SD-1.5 flow uses ControlNet)")
+        if is_controlnet:                                            # models/unet_2d_condition.py:938-946
+            if len(down_block_additional_residuals) != len(res):
+                raise ValueError("down_block_additional_residuals length mismatch")
+            res = [self._residual(r, e) for r, e in zip(res, down_block_additional_residuals)]
+
+        x = self.mid_block.resnets[0].run(x, None, tproj)
+        if track_keys:
+            ca_kwargs["attn_key"] = ["mid", 0, 0]
+        x = self.mid_block.attentions[0].run(x, enc, ca_kwargs)
+        x = self.mid_block.resnets[1].run(x, None, tproj)
+        if mid_block_additional_residual is not None:
+            x = self._residual(x, mid_block_additional_residual)
+
+        for i, blk in enumerate(self.up_blocks):
+            for j, resnet in enumerate(blk.resnets):
+                skip = res.pop()
+                x = resnet.run(x, skip, tproj)
+                if blk.has_cross_attention:
+                    if track_keys:
+                        ca_kwargs["attn_key"] = ["up", i, j]
+                    x = blk.attentions[j].run(x, enc, ca_kwargs)
+            if blk.upsamplers is not None:
+                x = blk.upsamplers[0].run(x)
+
+        y = ops.groupnorm(x.t, x.b, x.hw, cfg.norm_num_groups, cfg.norm_eps, self.conv_norm_out.weight, self.conv_norm_out.bias,
+                          silu=True)
+        w_out = self._p.get("conv_out", [self.conv_out.weight], lambda: pack_conv3x3(self.conv_out.weight.detach()))
+        out = ops.conv_out(y, w_out, self.conv_out.bias, B, x.h, x.w, cfg.out_channels, out_dtype if out_dtype is not None else dt)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    __call__ = forward  # nn.Module hooks are not needed; keeps launch overhead down
+
+    @classmethod
+    def from_state_dict(cls, config, state_dict, device="cuda", dtype=torch.bfloat16, ip_adapter=True, num_tokens=4, ip_scale=1.0):
+        """Build, optionally install IP-Adapter processors (so ``...attn2.processor.to_k_ip.weight`` keys load), load, move."""
+        m = cls(config)
+        if ip_adapter:
+            install_ip_processors(m, num_tokens=num_tokens, scale=ip_scale)
+        missing, unexpected = m.load_state_dict(state_dict, strict=False)
+        if unexpected or missing:
+            raise RuntimeError(f"state dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        return m.to(device=device, dtype=dtype)
+
+
+def install_ip_processors(unet, num_tokens=4, scale=1.0):
+    """The name-driven processor table of ``IPAdapter.set_ip_adapter`` (reference ip_adapter/ip_adapter.py:95-119)."""
+    cfg = unet.config
+    procs = {}
+    for name in unet.attn_processors.keys():
+        cross_attention_dim = None if name.endswith("attn1.processor") else cfg.cross_attention_dim
+        if name.startswith("mid_block"):
+            hidden_size = cfg.block_out_channels[-1]
+        elif name.startswith("up_blocks"):
+            hidden_size = list(reversed(cfg.block_out_channels))[int(name[len("up_blocks.")])]
+        elif name.startswith("down_blocks"):
+            hidden_size = cfg.block_out_channels[int(name[len("down_blocks.")])]
+        if cross_attention_dim is None:
+            procs[name] = AttnProcessor()
+        else:
+            procs[name] = IPAttnProcessor(hidden_size=hidden_size, cross_attention_dim=cross_attention_dim, scale=scale,
+                                          num_tokens=num_tokens).to(unet.device, dtype=unet.dtype)
+    unet.set_attn_processor(procs)
+    return procs
