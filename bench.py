@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — 512 px, 50-step character images / second on synthetic CMIGBench 4-turn stories (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]           # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                    # one rank per GPU over RCCL
+
+One "step" = one pass of the hot path over one batch of synthetic input = ONE 4-turn x 2-character story per
+GPU: 8 character images, each a full 50-step DDIM chain with CFG (SD-1.5 plan, 512x512, IP-Adapter decoupled
+cross-attention, 77 text + 4 image tokens), i.e. 50 CFG UNet calls of batch 2 x `char_batch` + the fused
+CFG/DDIM step epilogue.  Inputs (latents, embeddings) are resident in HBM before the timed region.  Weak
+scaling: every rank denoises its own dialogue per step (no data-path collective); RCCL only broadcasts the
+shared conditioning once and all-gathers the final latents of each step.  Rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 at N = 1 (outside the timed region):
+  roofline     — per-launch HIP-event timing of the dominant kernel family (MFMA GEMM / implicit-GEMM conv),
+                 algorithmic FLOPs (2*M*N*K per launch) / measured time vs the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline — the CPU oracle (fp32 PyTorch restatement of the reference path, `oracle/`) timed on the host
+                 cores for a bounded sample (CFG UNet calls), converted to char images / s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16/fp16, MI355X_MICROARCH.md
+SD15_FLOP_PER_CFG_CALL = 1.607e12  # 401.8 GMAC / sample, batch 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--char-batch", type=int, default=8, help="character images denoised together (8 = one whole story)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--plan", default="sd15")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-calls", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_model(plan, dtype, device, num_tokens=4, scale=0.4):
+    from theatergen_amd import config, weights
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.pipelines import SDPipe
+    from theatergen_amd.unet import UNet2DConditionModel
+    cfg = config.PLANS[plan]()
+    sd = weights.random_unet_state_dict(cfg, seed=0)
+    unet = UNet2DConditionModel.from_state_dict(cfg, sd, device=device, dtype=dtype, num_tokens=num_tokens, ip_scale=scale)
+    adapter = IPAdapter(SDPipe(unet), None, None, device, num_tokens=num_tokens)
+    adapter.set_scale(scale)
+    return cfg, sd, unet, adapter
+
+
+def roofline_leg(unet, engine):
+    """One eager CFG step with HIP events around every GEMM/conv launch -> the dominant kernel's achieved TFLOP/s."""
+    from theatergen_amd import ops
+    with torch.no_grad():
+        engine._reset(engine.history[0].clone())
+        engine._step()                                   # warm (eager)
+        torch.cuda.synchronize()
+        ops.gemm_profile_start()
+        t0 = time.perf_counter()
+        engine._step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) * 1e3
+        recs = ops.gemm_profile_stop()
+    by = {}
+    for r in recs:
+        k = by.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0))
+        k["launches"] += 1
+        k["ms"] += r["ms"]
+        k["flops"] += r["flops"]
+    name, top = max(by.items(), key=lambda kv: kv[1]["ms"])
+    tot_ms = sum(v["ms"] for v in by.values())
+    tot_fl = sum(v["flops"] for v in by.values())
+    ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "kernel": name, "launches_per_cfg_call": top["launches"],
+            "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
+            "flop_per_launch_avg": top["flops"] / top["launches"],
+            "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
+                                 "flop_per_cfg_call": tot_fl, "launches": len(recs)},
+            "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                          for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps):
+    """The oracle (CPU fp32 restatement of the reference op order) on the host cores: `n_calls` CFG UNet calls."""
+    from oracle import unet as ou
+    cores = min(os.cpu_count() or 1, 64)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, cfg.in_channels, 64, 64, generator=g)
+    enc = torch.randn(2, 81, cfg.cross_attention_dim, generator=g) * 0.5
+    sd32 = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        ou.unet_forward(cfg, sd32, x, 981, enc, ip_scale=0.4, num_tokens=4)      # warm-up
+        t0 = time.perf_counter()
+        for i in range(n_calls):
+            ou.unet_forward(cfg, sd32, x, 981 - 20 * i, enc, ip_scale=0.4, num_tokens=4)
+        dt = (time.perf_counter() - t0) / n_calls
+    torch.set_num_threads(prev)
+    return {"value": round(1.0 / (dt * ddim_steps), 6), "unit": "char_images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_calls} CFG UNet calls (batch 2, SD-1.5 512x512, fp32, reference op order incl. unfused "
+                      f"baddbmm/softmax/bmm attention) = {dt:.2f} s/call; x{ddim_steps} calls per char image",
+            "s_per_cfg_call": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    from theatergen_amd import distributed as D
+    rank, world, local = D.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    D.init(device=device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+
+    from theatergen_amd import story
+    from theatergen_amd.pipelines import DenoiseEngine
+    T = 4
+    cfg, sd, unet, adapter = build_model(args.plan, dtype, device, num_tokens=T)
+    ctx = cfg.cross_attention_dim
+    cb = args.char_batch
+    jobs_per_story = 8
+    assert jobs_per_story % cb == 0, "--char-batch must divide 8"
+    engine = DenoiseEngine(unet, None, n_img=cb, height=512, width=512, num_inference_steps=args.ddim_steps,
+                           guidance_scale=7.5, enc_len=77 + T)
+
+    # shared conditioning: generated on rank 0, broadcast over RCCL (the only collective besides the final gather)
+    shared = story.shared_conditioning(ctx, T, dtype, device)
+    if rank != 0:
+        for v in shared.values():
+            v.zero_()
+    D.broadcast_conditioning(shared, src=0)
+
+    n_steps_total = args.warmup + args.steps
+    # every rank owns dialogues rank, rank + world, ...: one dialogue (story) per step
+    my_dialogues = [rank + world * s for s in range(n_steps_total)]
+    prepared = []
+    for d in my_dialogues:
+        jobs = story.story_jobs(d)
+        char_ids = sorted({j.char_id for j in jobs})
+        img_tok = story.character_image_tokens(char_ids, ctx, T, dtype, device)
+        cidx = {c: i for i, c in enumerate(char_ids)}
+        batches = []
+        for b0 in range(0, len(jobs), cb):
+            jb = jobs[b0:b0 + cb]
+            enc = story.job_conditioning(jb, shared, img_tok, cidx, ctx, dtype, device)
+            lat = story.job_latents(jb, adapter)
+            batches.append((enc, lat))
+        prepared.append(batches)
+    torch.cuda.synchronize()
+
+    finals = torch.zeros((jobs_per_story, cfg.in_channels, 64, 64), dtype=torch.float32, device=device)
+
+    def run_story(batches):
+        for bi, (enc, lat) in enumerate(batches):
+            engine.set_conditioning(enc)
+            hist = engine.run(lat)
+            finals[bi * cb:(bi + 1) * cb].copy_(hist[-1])
+        return D.gather_latents(finals)
+
+    for s in range(args.warmup):
+        run_story(prepared[s])
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, n_steps_total):
+        gathered = run_story(prepared[s])
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, device)
+    assert torch.isfinite(gathered).all()
+
+    images = jobs_per_story * args.steps * world
+    value = images / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    cfg_calls = images * args.ddim_steps          # algorithmic units (batch-2 CFG UNet calls)
+    result = {
+        "metric": "512px 50-step char images/sec (node), CMIGBench 4-turn story",
+        "value": round(value, 4), "unit": "char_images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"SD-1.5 512x512, 4-turn story x 2 characters = 8 char images per step per GPU, {args.ddim_steps} DDIM "
+                               f"steps, CFG 7.5, IP-Adapter 77+4 tokens scale 0.4, {args.dtype}, random-init weights",
+                   "plan": args.plan, "char_batch": cb, "cfg_batch": 2 * cb, "ddim_steps": args.ddim_steps,
+                   "parallelism": f"dialogue-sharded x{world} (RCCL broadcast + all_gather only)"},
+        "whole_job_tflops": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12, 2),
+        "whole_job_mfma_frac": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            result["roofline"] = roofline_leg(unet, engine)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if D.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,8 +61,9 @@ const char* tg_last_error(void);
  *         pad-1 convolution with `stride` 1|2, optionally on the nearest-neighbour x2 upsampled input
  *         (`upsample`=1, Upsample2D); W is [N, 9*(c0+c1)] tap-major (ky, kx, c).  M = batch*out_h*out_w.
  * Epilogue (all optional, fp32):  v = acc + bias[n] + bvec[m / rows_per_batch, n] + res[m, n];
- *         v = act(v) * out_scale;  act in TG_ACT_*;  or GEGLU (geglu=1: N counts a|gate pairs, W rows are
- *         [a(0..N/2) ; gate(0..N/2)] as in GEGLU.proj, out is [M, N/2] = a * gelu(gate)).
+ *         v = act(v) * out_scale;  act in TG_ACT_*;  or GEGLU (geglu=1, bias only): W rows (and bias) are PACKED
+ *         per 64-row group as [a(32) ; gate(32)] (theatergen_amd.weights_pack.pack_geglu of GEGLU.proj), N % 64 == 0,
+ *         out is [M, N/2] = (a + b_a) * gelu(gate + b_g) * out_scale: the [M, N] pre-activation never reaches HBM.
  * Output: out[m * ldc + n] for n < n_split (n_split <= 0: all); columns n >= n_split are written
  *         TRANSPOSED per batch item, out_t[(b * (N - n_split) + n - n_split) * ldt + (m % rows_per_batch)]
  *         (the V^T operand of tg_attention).
@@ -106,6 +107,8 @@ typedef struct {
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
 int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
+/* the tile (tokens x channels) and K-split the heuristic picks for a descriptor (bench / profiling attribution) */
+int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused flash-style attention with up to two independently-normalised K/V segments:

@@ -131,6 +131,24 @@ def test_gemm_epilogues(dtype):
     assert (out_t[:, :, rows:] == 0).all()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 1280, 320), (4096, 2560, 320), (130, 512, 64)])
+def test_gemm_fused_geglu(dtype, shape):
+    """FF1 + GEGLU in one launch (packed a|gate weight rows) == Linear -> chunk -> a * gelu(gate)."""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_geglu
+    dev = _dev()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(N + K)
+    a, w, b = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K)), rnd((N,), dtype, g)
+    y = a.float() @ w.float().t() + b.float()
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    wp, bp = pack_geglu(w, b)
+    out = ops.gemm(a.to(dev), wp.to(dev), M, N, K, bias=bp.to(dev), geglu=True)
+    assert out.shape == (M, N // 2)
+    check(out, ref, dtype, f"fused geglu {shape}")
+
+
 CONV_CASES = [
     # batch, h, w, cin, c1, cout, stride, upsample
     (2, 16, 16, 64, 0, 64, 1, False), (2, 16, 16, 128, 0, 64, 2, False), (1, 8, 8, 64, 0, 128, 1, True),

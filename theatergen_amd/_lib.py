@@ -44,6 +44,7 @@ SIGNATURES = {
     "tg_last_error": (C.c_char_p, []),
     "tg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "tg_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
+    "tg_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp]),
     "tg_attention": (i32, [C.POINTER(AttnDesc), vp]),
     "tg_attn_probs": (i32, [i32, i32, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, f32, vp, i32, vp, vp]),
     "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),
@@ -76,6 +77,10 @@ def lib():
             raise RuntimeError(
                 f"theatergen_amd: HIP library not found at {LIB_PATH}; build it with "
                 "`python -m theatergen_amd.build` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7) and this library needs the same
+        # SONAME: torch must be loaded FIRST so both share ONE HIP runtime (streams, device memory).  Loaded the
+        # other way round the process ends up with two runtimes and the second reports "no ROCm-capable device".
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)      # AttributeError if a declared symbol is not exported

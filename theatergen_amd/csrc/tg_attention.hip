@@ -24,7 +24,7 @@ constexpr int KV = 64;        // keys per tile
 constexpr int VT_LDP = KV + 8;  // V^T tile row pitch (elements)
 
 struct AttnParams {
-  int heads, hd, n_q;
+  int heads, hd, n_q, n_qblk;
   const void* q; long q_ld, q_bs;
   const void* k0; long k0_ld, k0_bs;
   const void* vt0; long vt0_ld, vt0_bs;
@@ -53,9 +53,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
   T* sV = sK + KV * K_LDP;                       // [DV][VT_LDP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order (speed only): block b runs on XCD b % 8; give each XCD a contiguous chunk of the
+  // (batch, head, q-block) space so that all q-blocks of one (batch, head) share K / V^T through ONE private L2.
+  int lbid;
+  {
+    const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;
+    lbid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  }
+  const int qblk = lbid % p.n_qblk;
+  const int h = (lbid / p.n_qblk) % p.heads, b = lbid / (p.n_qblk * p.heads);
   const int HD = p.hd;
-  const long qrow = (long)blockIdx.x * 128 + wave * 32 + l31;
+  const long qrow = (long)qblk * 128 + wave * 32 + l31;
   const bool q_ok = qrow < p.n_q;
 
   // Q fragments (B operand): this lane's query row, d = ks*16 + hi*8 .. +8
@@ -264,8 +272,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 template <typename T, int DPAD, int DV>
 int launch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
   const size_t lds = ((size_t)KV * (DPAD + 8) + (size_t)DV * VT_LDP) * sizeof(T);
-  dim3 grid((unsigned)((d->n_q + 127) / 128), (unsigned)d->heads, (unsigned)d->batch);
-  hipLaunchKernelGGL((attention_kernel<T, DPAD, DV>), grid, dim3(256), lds, st, p);
+  AttnParams pp = p;
+  pp.n_qblk = (d->n_q + 127) / 128;
+  dim3 grid((unsigned)(pp.n_qblk * d->heads * d->batch));
+  hipLaunchKernelGGL((attention_kernel<T, DPAD, DV>), grid, dim3(256), lds, st, pp);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

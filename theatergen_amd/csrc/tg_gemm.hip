@@ -21,6 +21,8 @@
 
 namespace {
 
+inline bool use_v1_flag(const tg_gemm_desc* d) { return (d->force_tile & 16) != 0; }
+
 constexpr int BK = 64;
 constexpr int LDP = BK + 8;  // LDS row pitch in elements (144 B)
 
@@ -38,6 +40,7 @@ struct GemmParams {
   const void* res;
   long ldres;
   int act;
+  int geglu;
   float out_scale;
   void* out;
   long ldc;
@@ -96,6 +99,143 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, long m, lon
   }
 }
 
+// XCD-aware tile order (speed only, never correctness): the dispatcher places block b on XCD b % 8, each XCD has a
+// private 4 MiB L2.  With the natural order the tiles that share an activation row-slab (same tile_m, different
+// tile_n) land on different XCDs and every L2 fetches the slab again from the fabric (measured: 44 % L2 miss rate,
+// ~3.9 TB/s of miss traffic on the 64x64 320->320 conv).  Remap so that XCD x owns a CONTIGUOUS chunk of logical
+// tiles (bijective for any grid size): neighbours in (tile_m, tile_n) order run on the same L2 at the same time.
+__device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + (bid >> 3);
+}
+
+// Whole-wave-tile epilogue.  All bias / per-batch vector / residual loads of one 32-token row block are issued
+// back to back BEFORE any of them is consumed (one latency exposure per row block instead of one per 4 outputs),
+// then activation / scale / 8-byte stores.  lane&31 = token row, 4 consecutive registers = 4 consecutive channels.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int split) {
+  typedef typename Vec<T>::v4 V4;
+  if (p.splits > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = m_base + 32 * i;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long n4 = n_base + 32 * j + 8 * g;
+          if (m < p.M && n4 < p.N) {
+            f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(p.ws + ((long)split * p.M + m) * p.N + n4) = o;
+          }
+        }
+    }
+    return;
+  }
+  if constexpr (TN == 2) {
+    if (p.geglu) {
+      // fused GEGLU (models/attention.py:337-338): W rows are packed [a(32) ; gate(32)] per 64-column group, so this
+      // wave holds a[c] in tile j = 0 and gate[c] in tile j = 1 for the same 32 channels, in the same lane/register:
+      // out[m, c] = (a + bias_a) * gelu(gate + bias_g), written to a [M, N/2] tensor — the [M, N] pre-activation
+      // never exists in HBM.
+      const T* biasp = reinterpret_cast<const T*>(p.bias);
+      const long hi4 = n_base & 31;                 // 4 * (lane >> 5)
+      const long nA = n_base - hi4;                 // first packed column of the a-block (multiple of 64)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long m = m_base + 32 * i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long na = nA + hi4 + 8 * g;         // packed column of a; gate sits 32 further
+          if (na + 32 >= p.N) continue;
+          V4 ba, bg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
+          if (biasp != nullptr) {
+            ba = *reinterpret_cast<const V4*>(biasp + na);
+            bg = *reinterpret_cast<const V4*>(biasp + na + 32);
+          }
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[i][0][4 * g + e] + to_f32<T>(ba[e]);
+            const float gt = acc[i][1][4 * g + e] + to_f32<T>(bg[e]);
+            o[e] = from_f32<T>(a * gelu_erf_f(gt) * p.out_scale);
+          }
+          *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + (nA >> 1) + hi4 + 8 * g) = o;
+        }
+      }
+      return;
+    }
+  }
+  const T* biasp = reinterpret_cast<const T*>(p.bias);
+  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
+  const T* resp = reinterpret_cast<const T*>(p.res);
+  V4 zero4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) zero4[e] = from_f32<T>(0.f);
+  V4 bias4[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long n4 = n_base + 32 * j + 8 * g;
+      bias4[j][g] = (biasp != nullptr && n4 < p.N) ? *reinterpret_cast<const V4*>(biasp + n4) : zero4;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long m = m_base + 32 * i;
+    const bool m_ok = m < p.M;
+    long b = 0;
+    if (bvecp != nullptr || p.n_split > 0) b = (m_ok ? m : 0) / p.rows_per_batch;
+    V4 add4[TN][4], res4[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long n4 = n_base + 32 * j + 8 * g;
+        const bool ok = m_ok && n4 < p.N;
+        add4[j][g] = (bvecp != nullptr && ok) ? *reinterpret_cast<const V4*>(bvecp + b * p.ldbvec + n4) : zero4;
+        res4[j][g] = (resp != nullptr && ok) ? *reinterpret_cast<const V4*>(resp + m * p.ldres + n4) : zero4;
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long n4 = n_base + 32 * j + 8 * g;
+        if (!(m_ok && n4 < p.N)) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = acc[i][j][4 * g + e] + to_f32<T>(bias4[j][g][e]) + to_f32<T>(add4[j][g][e]) + to_f32<T>(res4[j][g][e]);
+        if (p.act == TG_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        } else if (p.act == TG_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        if (p.n_split > 0 && n4 >= p.n_split) {
+          T* o = reinterpret_cast<T*>(p.out_t);
+          const long tok = m - b * p.rows_per_batch;
+          const long nt = p.N - p.n_split;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[(b * nt + (n4 + e - p.n_split)) * p.ldt + tok] = from_f32<T>(v[e]);
+        } else {
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+          *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + n4) = o;
+        }
+      }
+  }
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int TM = BM / (WAVES_M * 32);
@@ -114,8 +254,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int wave = tid >> 6;
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
-  const int tile_n = blockIdx.x % p.tiles_n;
-  const int tile_m = blockIdx.x / p.tiles_n;
+  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % p.tiles_n;
+  const int tile_m = lbid / p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const long n0 = (long)tile_n * BN;
   const int split = blockIdx.z;
@@ -260,28 +401,208 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
   }
 
-  // ---- epilogue: lane&31 = token, regs = channels
-  const int hi = lane >> 5;
+  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), split);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v2: operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip,
+// no ds_write pass).  v1's staging costs 32 KB of ds_write_b128 per 128x128x64 tile (~415 LDS cycles at ~79 B/clk)
+// next to 256 cycles of fragment reads: with 512 MFMA cycles per tile per SIMD the LDS pipe, not the matrix pipe, was
+// the bound.  LDS image: unpadded 128-byte rows (the DMA destination is lane-linear), XOR-swizzled in 16-byte slots
+// with key = (row >> 1) & 7; the swizzle is applied on the per-lane SOURCE address and again on the fragment read
+// (cdna guide rule 21), which makes the 16-lane ds_read_b128 groups conflict-free.  Out-of-range rows / conv padding
+// read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
+__device__ __attribute__((aligned(256))) unsigned char tg_zero_page[256];
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmParams p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
+  constexpr int NDMA = BM / (8 * NW) + BN / (8 * NW);   // LDS-DMA instructions per wave per K-tile (constant: invalid rows fetch the zero page)
+  constexpr int TM = BM / (WAVES_M * 32);
+  constexpr int TN = BN / (WAVES_N * 32);
+  constexpr int XJ = BM / (8 * NW);   // DMA instructions per wave per K-tile for the activation tile (8 rows each)
+  constexpr int WJ = BN / (8 * NW);
+  typedef typename Vec<T>::v8 V8;
+  static_assert(NW % 2 == 0 && XJ >= 1 && WJ >= 1, "tile / wave layout");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sX = reinterpret_cast<T*>(smem);                 // [2][BM][64]
+  T* sW = sX + STAGES * BM * BK;                      // [STAGES][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % p.tiles_n;
+  const int tile_m = lbid / p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const long n0 = (long)tile_n * BN;
+  const int split = blockIdx.z;
+  const int nkt_total = (int)((p.K + BK - 1) / BK);
+  const int kt_begin = split * p.kt_per_split;
+  int kt_end = kt_begin + p.kt_per_split;
+  if (kt_end > nkt_total) kt_end = nkt_total;
+  const int nkt = kt_end - kt_begin;
+
+  // DMA lane geometry: instruction q covers tile rows [8q, 8q+8); lane -> (row 8q + lane/8, 16-byte slot lane%8)
+  const int lrow = lane >> 3;
+  const int slot = lane & 7;
+  const int wkey = (4 * (wave & 1) + (lane >> 4)) & 7;   // ((8q + lane/8) >> 1) & 7 with q = j*NW + wave
+  const int chunk = slot ^ wkey;                          // global 16-byte chunk this lane fetches into its slot
+
+  const T* A0 = reinterpret_cast<const T*>(p.a0);
+  const T* A1 = reinterpret_cast<const T*>(p.a1);
+  const T* Wp = reinterpret_cast<const T*>(p.w);
+  const T* zero = reinterpret_cast<const T*>(tg_zero_page);
+  const int ctot = p.c0 + p.c1;
+
+  long xbase[XJ], xrow[XJ];
+  int x_oy[XJ], x_ox[XJ], x_ob[XJ];
+  bool x_ok[XJ];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long m = m0 + (wave_m * TM + i) * 32 + (lane & 31);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const long nb = n0 + (wave_n * TN + j) * 32 + 4 * hi;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long n4 = nb + 8 * g;
-        if (p.splits > 1) {
-          if (m < p.M && n4 < p.N) {
-            f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(p.ws + ((long)split * p.M + m) * p.N + n4) = o;
-          }
-        } else {
-          epilogue_store4<T>(p, m, n4, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-      }
+  for (int j = 0; j < XJ; ++j) {
+    const long m = m0 + (j * NW + wave) * 8 + lrow;
+    x_ok[j] = m < p.M;
+    xbase[j] = m * p.c0;
+    xrow[j] = m;
+    if (!CONV && p.a_rpb > 0) { const long bb = m / p.a_rpb; xbase[j] = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
+    if (CONV) {
+      const long mm = x_ok[j] ? m : 0;
+      const int hw = p.out_h * p.out_w;
+      x_ob[j] = (int)(mm / hw);
+      const int r = (int)(mm - (long)x_ob[j] * hw);
+      x_oy[j] = r / p.out_w;
+      x_ox[j] = r - x_oy[j] * p.out_w;
     }
   }
+  const T* wrow[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const long n = n0 + (j * NW + wave) * 8 + lrow;
+    wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
+  }
+
+  auto dma = [&](const T* src, T* lds_row_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
+  };
+
+  auto issue_tile = [&](int kt, int buf) {
+    const long k0 = (long)kt * BK;
+    const long kc = k0 + chunk * 8;
+    const bool kok = kc < p.K;
+    T* dx = sX + buf * BM * BK;
+    T* dw = sW + buf * BN * BK;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const T* src = (kok && wrow[j] != nullptr) ? wrow[j] + kc : zero;
+      dma(src, dw + (j * NW + wave) * 8 * BK);
+    }
+    if (!CONV) {
+      const T* base = A0;
+      long pitch = p.c0;
+      long kk = kc;
+      const bool second = A1 != nullptr && k0 >= p.c0;
+      if (second) { base = A1; pitch = p.c1; kk = kc - p.c0; }
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const long off = second ? xrow[j] * pitch : xbase[j];
+        const T* src = (kok && x_ok[j]) ? base + off + kk : zero;
+        dma(src, dx + (j * NW + wave) * 8 * BK);
+      }
+    } else {
+      const int tap = (int)(k0 / ctot);
+      int cc = (int)(k0 - (long)tap * ctot);
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const T* base = A0;
+      int pitch = p.c0;
+      if (cc >= p.c0) { base = A1; pitch = p.c1; cc -= p.c0; }
+      cc += chunk * 8;
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        int iy, ix;
+        bool ok = x_ok[j];
+        if (!p.upsample) {
+          iy = x_oy[j] * p.stride + ky - 1;
+          ix = x_ox[j] * p.stride + kx - 1;
+          ok = ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        } else {
+          const int uy = x_oy[j] + ky - 1, ux = x_ox[j] + kx - 1;
+          ok = ok && uy >= 0 && uy < 2 * p.in_h && ux >= 0 && ux < 2 * p.in_w;
+          iy = uy >> 1;
+          ix = ux >> 1;
+        }
+        const T* src = ok ? base + ((long)(x_ob[j] * p.in_h + iy) * p.in_w + ix) * pitch + cc : zero;
+        dma(src, dx + (j * NW + wave) * 8 * BK);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    // counted waits: after issuing up to PF tiles ahead, a wave only waits until the NEXT tile's DMA has landed
+    // (vmcnt(NDMA * tiles still allowed in flight)); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+      if (s < nkt) issue_tile(kt_begin + s, s);
+    if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int rkey = (l31 >> 1) & 7;
+    int buf = 0;
+    for (int it = 0; it < nkt; ++it) {
+      const T* bx = sX + buf * BM * BK + (wave_m * TM * 32 + l31) * BK;
+      const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
+      // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
+      // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
+      // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
+      V8 xf[BK / 16][TM], wf[BK / 16][TN];
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int so = ((2 * ks + hi) ^ rkey) * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BK + so);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BK + so);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
+      if (it + PF < nkt) {
+        int nb = buf + PF;
+        if (nb >= STAGES) nb -= STAGES;
+        issue_tile(kt_begin + it + PF, nb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
+      // keep the MFMA chain ABOVE the wait: an asm "memory" clobber does not order register-only MFMAs, and hipcc
+      // otherwise hoists `s_waitcnt vmcnt(0); s_barrier` in front of them, exposing the whole DMA latency per tile
+      __builtin_amdgcn_sched_barrier(0);
+      // tile it+1 must have landed; tiles it+2 .. it+PF (if issued) may stay in flight
+      if (PF >= 2 && it + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+  }
+
+  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), split);
 }
 
 template <typename T>
@@ -298,39 +619,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 }
 
 struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}};
-constexpr int kNumTiles = 4;
+const TileCfg kTiles[] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {256, 128}, {128, 128}, {256, 128}, {256, 256}, {256, 128}};
+constexpr int kNumTiles = 9;   // ids 5.. = experimental variants (forced only): stage counts, 256x256 (8 waves of 128x64), 256x128 (4 waves of 128x64)
+// force_tile: low 4 bits = 1 + tile id (0 = heuristic); bit 4 (16) = use the v1 register-staged kernel
+inline bool use_v1(const tg_gemm_desc* d) { return (d->force_tile & 16) != 0; }
 
 struct Plan { int tile; int splits; int kt_per_split; long tiles_m, tiles_n; };
 
 Plan make_plan(const tg_gemm_desc* d) {
+  // Measured on MI355X over the UNet's shapes (scripts/dev_gemm_bench.py): the 128x128 tile with 2 blocks per CU is
+  // the best or within a few % of the best everywhere, including small grids; every larger tile loses occupancy and
+  // split-K (fp32 partials + a reduce launch) never paid off, so it is only taken when forced (tests) — except for
+  // skinny problems where one dimension is <= 64.
   const long M = d->M, N = d->N, K = d->K;
   const int nkt = (int)((K + BK - 1) / BK);
-  Plan best{};
-  double best_cost = 1e300;
-  for (int t = 0; t < kNumTiles; ++t) {
-    if (d->force_tile > 0 && d->force_tile - 1 != t) continue;
-    const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
-    const long tiles = tm * tn;
-    const int lds = 2 * (kTiles[t].bm + kTiles[t].bn) * LDP * 2;
-    const int wg_per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : 2);
-    const long slots = 256L * wg_per_cu;
-    for (int s = 1; s <= 32; s = (s < 4 ? s + 1 : s * 2)) {
-      if (d->force_split_k > 0 && s != d->force_split_k) continue;
-      if (d->force_split_k <= 0 && s > 1 && nkt / s < 6) break;
-      const int kps = (nkt + s - 1) / s;
-      const int real_s = (nkt + kps - 1) / kps;
-      if (real_s != s) continue;
-      const long wgs = tiles * s;
-      const double rounds = (double)((wgs + slots - 1) / slots);
-      // relative MFMA efficiency of a tile config (bigger tiles amortise LDS traffic better)
-      const double eff = (t == 0) ? 1.0 : (t == 1 ? 0.62 : 0.8);
-      double cost = rounds * wg_per_cu * (double)kTiles[t].bm * kTiles[t].bn * (kps * BK + 96) / eff;
-      if (s > 1) cost += 2.5 * (double)M * N * s * 4.0 / 256.0 * 6.0;  // fp32 partial write+read
-      if (cost < best_cost) { best_cost = cost; best = Plan{t, s, kps, tm, tn}; }
-    }
+  int t = 0;
+  if (N <= 64 && M > 64) t = 2;        // 128 x 64
+  else if (M <= 64 && N > 64) t = 3;   // 64 x 128
+  else if (M <= 64 && N <= 64) t = 1;  // 64 x 64
+  const int forced = d->force_tile & 15;
+  if (forced > 0) t = forced - 1;
+  if (t >= kNumTiles) t = 0;
+  if (use_v1(d) && t >= 4) t = 0;
+  int s = d->force_split_k > 0 ? d->force_split_k : 1;
+  if (s > nkt) s = nkt;
+  int kps = (nkt + s - 1) / s;
+  s = (nkt + kps - 1) / kps;
+  const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
+  return Plan{t, s, kps, tm, tn};
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T);
+  dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), 1, (unsigned)pl.splits);
+  if (d->mode == 1) {
+    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, true, STAGES>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
+  } else {
+    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, false, STAGES>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
   }
-  return best;
+  TG_LAUNCH_CHECK();
+  if (pl.splits > 1) {
+    long total = p.M * (p.N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p);
+    TG_LAUNCH_CHECK();
+  }
+  return TG_OK;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -369,7 +711,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.w = d->w; p.M = d->M; p.N = d->N; p.K = d->K;
   p.bias = d->bias; p.bvec = d->bvec; p.ldbvec = d->ldbvec;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
-  p.res = d->res; p.ldres = d->ldres; p.act = d->act; p.out_scale = d->out_scale;
+  p.res = d->res; p.ldres = d->ldres; p.act = d->act; p.geglu = d->geglu; p.out_scale = d->out_scale;
   p.out = d->out; p.ldc = d->ldc; p.n_split = d->n_split; p.out_t = d->out_t; p.ldt = d->ldt;
   p.ws = reinterpret_cast<float*>(d->workspace);
   p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; p.tiles_n = (int)pl.tiles_n;
@@ -378,6 +720,19 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= (int64_t)pl.splits * d->M * d->N * 4, TG_ERR_ARG,
              "tg_gemm: split-K needs %lld workspace bytes, got %lld", (long long)pl.splits * d->M * d->N * 4,
              (long long)d->workspace_bytes);
+  }
+  if (!use_v1(d)) {
+    switch (pl.tile) {
+      case 0: return launch_cfg2<T, 128, 128, 2, 2, 2>(d, p, pl, st);
+      case 1: return launch_cfg2<T, 64, 64, 2, 2, 3>(d, p, pl, st);
+      case 2: return launch_cfg2<T, 128, 64, 4, 1, 3>(d, p, pl, st);
+      case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
+      case 4: return launch_cfg2<T, 256, 128, 4, 2, 3>(d, p, pl, st);
+      case 5: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);
+      case 6: return launch_cfg2<T, 256, 128, 4, 2, 2>(d, p, pl, st);
+      case 7: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);
+      default: return launch_cfg2<T, 256, 128, 2, 2, 2>(d, p, pl, st);
+    }
   }
   switch (pl.tile) {
     case 0: return launch_cfg<T, 128, 128, 2, 2>(d, p, pl, st);
@@ -395,7 +750,13 @@ int validate(const tg_gemm_desc* d) {
            (long long)d->M, (long long)d->N, (long long)d->K);
   TG_CHECK(d->N % 4 == 0 && d->K % 8 == 0, TG_ERR_ARG, "tg_gemm: N %% 4 and K %% 8 required (N=%lld K=%lld)",
            (long long)d->N, (long long)d->K);
-  TG_CHECK(d->geglu == 0, TG_ERR_UNSUPPORTED, "tg_gemm: fused GEGLU epilogue not available; use tg_geglu");
+  if (d->geglu) {
+    TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
+             TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
+    const int ft = d->force_tile & 15;
+    TG_CHECK(!use_v1_flag(d) && (ft == 0 || ft == 1 || ft == 6 || ft == 7), TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
+    TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
+  }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
   if (d->a1) TG_CHECK(d->c0 % BK == 0, TG_ERR_ARG, "tg_gemm: two-source A needs c0 %% 64 == 0 (c0=%d)", d->c0);
   if (d->mode == 1) {
@@ -422,6 +783,16 @@ int validate(const tg_gemm_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
+  int rc = validate(d);
+  if (rc != TG_OK) return rc;
+  Plan pl = make_plan(d);
+  if (tile_m) *tile_m = kTiles[pl.tile].bm;
+  if (tile_n) *tile_n = kTiles[pl.tile].bn;
+  if (splits) *splits = pl.splits;
+  return TG_OK;
+}
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;

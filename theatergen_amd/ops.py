@@ -47,7 +47,7 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -69,9 +69,9 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.res = _ptr(res)
     d.ldres = int(res.stride(0)) if res is not None else 0
     d.act = act
-    d.geglu = 0
+    d.geglu = 1 if geglu else 0
     d.out_scale = float(out_scale)
-    n_main = n_split if n_split > 0 else N
+    n_main = n_split if n_split > 0 else (N // 2 if geglu else N)
     if out is None:
         out = torch.empty((M, n_main), dtype=a0.dtype, device=a0.device)
     d.out = _ptr(out)
@@ -89,8 +89,37 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         ws = workspace(need, a0.device)
         d.workspace = ws.data_ptr()
         d.workspace_bytes = ws.numel() * 4
+    if _gemm_profile is None:
+        _lib.check(L.tg_gemm(C.byref(d), _stream()))
+        return out
+    # profiling mode (bench.py roofline leg): HIP events on the launch stream around this one launch
+    tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.check(L.tg_gemm(C.byref(d), _stream()))
+    e1.record()
+    _gemm_profile.append(dict(kernel=f"gemm_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>", splits=sp.value,
+                              M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1)))
     return out
+
+
+_gemm_profile = None
+
+
+def gemm_profile_start():
+    global _gemm_profile
+    _gemm_profile = []
+
+
+def gemm_profile_stop():
+    """-> list of per-launch records with ``ms`` filled in (call after torch.cuda.synchronize())."""
+    global _gemm_profile
+    recs, _gemm_profile = _gemm_profile, None
+    for r in recs or []:
+        e0, e1 = r.pop("events")
+        r["ms"] = e0.elapsed_time(e1)
+    return recs or []
 
 
 def linear(x, w, bias=None, **kw):

@@ -27,7 +27,7 @@ import torch.nn as nn
 from . import ops
 from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor
 from .config import UNetConfig
-from .weights_pack import pack_conv1x1, pack_conv3x3
+from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu
 
 
 class DeviceSchedule:
@@ -147,10 +147,17 @@ class FeedForward(nn.Module):
         super().__init__()
         inner = dim * mult
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
+        self._p = _Packed()
 
     def run(self, x2d, residual):
-        f = ops.linear(x2d, self.net[0].proj.weight, self.net[0].proj.bias)
-        g = ops.geglu(f)
+        proj = self.net[0].proj
+        M, K = x2d.shape
+        if M > 64 and (proj.weight.shape[0] // 2) % 32 == 0:
+            # GEGLU fused into the C -> 8C GEMM epilogue: the [M, 8C] pre-activation is never written
+            wp, bp = self._p.get("geglu", [proj.weight, proj.bias], lambda: pack_geglu(proj.weight.detach(), proj.bias.detach()))
+            g = ops.gemm(x2d, wp, M, wp.shape[0], K, bias=bp, geglu=True)
+        else:
+            g = ops.geglu(ops.linear(x2d, proj.weight, proj.bias))
         return ops.linear(g, self.net[2].weight, self.net[2].bias, res=residual)
 
 

@@ -15,3 +15,18 @@ def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
 
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], w.shape[1]).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor = None):
+    """GEGLU.proj weight [2*inner, C] = [a ; gate] (reference models/attention.py:328, 337) -> rows interleaved in groups
+    of 32: [a(0:32) ; gate(0:32) ; a(32:64) ; gate(32:64) ; ...] so that one wave of tg_gemm holds a[c] and gate[c] of
+    the same channel in the same lane (fused GEGLU epilogue).  ``inner`` must be a multiple of 32."""
+    two_inner = w.shape[0]
+    inner = two_inner // 2
+    assert inner % 32 == 0
+    a, g = w[:inner], w[inner:]
+    wp = torch.stack([a.reshape(inner // 32, 32, -1), g.reshape(inner // 32, 32, -1)], dim=1).reshape(two_inner, -1).contiguous()
+    bp = None
+    if b is not None:
+        bp = torch.stack([b[:inner].reshape(inner // 32, 32), b[inner:].reshape(inner // 32, 32)], dim=1).reshape(two_inner).contiguous()
+    return wp, bp
