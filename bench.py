@@ -74,6 +74,9 @@ def roofline_leg(unet, engine):
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) * 1e3
         recs = ops.gemm_profile_stop()
+    if os.environ.get("TG_DUMP_RECS"):
+        with open(os.environ["TG_DUMP_RECS"], "w") as f:
+            json.dump(recs, f)
     by = {}
     for r in recs:
         k = by.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0))

@@ -1,0 +1,158 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/theatergen_hip.h declares (no compute
+calls), and the host-side logic (scheduler tables, box geometry, phrase indices, parameter tables, processor
+wiring, workload generation, sharding) matches the oracle / the golden vectors from the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from theatergen_amd import _lib, build
+    header = open(os.path.join(ROOT, "include", "theatergen_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(tg_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    h = _lib.lib()          # binds every symbol: AttributeError if one is missing
+    for name in declared:
+        assert getattr(h, name) is not None
+    assert h.tg_version() >= 100
+    assert h.tg_last_error() is not None
+
+
+def test_argument_errors_map_to_runtime_error():
+    """Validation happens on the host side of the ABI, before any launch: works without a GPU."""
+    import ctypes as C
+    from theatergen_amd import _lib
+    h = _lib.lib()
+    d = _lib.GemmDesc()
+    rc = h.tg_gemm(C.byref(d), None)
+    assert rc == -1 and b"tg_gemm" in h.tg_last_error()
+    with pytest.raises(RuntimeError, match="theatergen_hip error"):
+        _lib.check(rc)
+    a = _lib.AttnDesc()
+    assert h.tg_attention(C.byref(a), None) == -1
+
+
+def test_no_cpu_fallback():
+    from theatergen_amd import ops
+    x = torch.zeros(8, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.linear(x, torch.zeros(64, 64, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.layernorm(x, None, None)
+
+
+def test_ddim_tables_match_oracle():
+    from oracle.ddim import DDIMSchedule
+    from theatergen_amd.scheduler import DDIMScheduler
+    for steps in (50, 20, 30):
+        o, s = DDIMSchedule(), DDIMScheduler()
+        o.set_timesteps(steps)
+        s.set_timesteps(steps)
+        assert torch.equal(o.timesteps, s.timesteps)
+        coef = s.coef_table()
+        for i, t in enumerate(o.timesteps.tolist()):
+            a_t, a_prev = o.coeffs(t)
+            want = torch.stack([a_t ** 0.5, (1 - a_t) ** 0.5, a_prev ** 0.5, (1 - a_prev) ** 0.5])
+            assert torch.equal(coef[i], want.float())
+    s50 = DDIMScheduler()
+    s50.set_timesteps(50)
+    assert s50.timesteps[0].item() == 981 and s50.timesteps[-1].item() == 1     # steps_offset = 1 (generate.py:68-76)
+
+
+def test_geometry_host_functions_vs_reference_golden():
+    from theatergen_amd import utils as U
+    gold = _load("geometry_latents")
+    boxes = gold["geo.boxes"].tolist()
+    sp = []
+    for b in boxes:
+        for (H, W) in ((64, 64), (16, 16), (8, 8), (96, 96)):
+            sp.append(list(U.scale_proportion(b, H, W)) + list(U.scale_proportion(b, H, W, use_legacy=True)))
+    assert np.array_equal(np.array(sp), gold["geo.scale_proportion"])
+    assert np.array_equal(np.stack([U.proportion_to_mask(b, 64, 64, device="cpu").numpy() for b in boxes]), gold["geo.mask64"])
+    cen = [U.get_centered_box(b) for b in boxes[:3]] + [U.get_centered_box(b, horizontal_center_only=False) for b in boxes[:3]] \
+        + [U.get_centered_box(b, horizontal_center_only=False, vertical_placement="floor_padding", floor_padding=0.05) for b in boxes[:3]]
+    np.testing.assert_allclose(np.array(cen), gold["geo.centered"], rtol=0, atol=0)
+    masks = [torch.from_numpy(m) for m in gold["geo.masks"]]
+    assert np.array_equal(np.array([U.binary_mask_to_box(m) for m in masks]), gold["geo.mask_box"])
+    assert np.array_equal(torch.stack([U.binary_mask_to_box_mask(m, to_device=False) for m in masks]).numpy(), gold["geo.mask_box_mask"])
+    np.testing.assert_allclose(np.array([U.binary_mask_to_center(m, normalize=True) for m in masks]), gold["geo.mask_center"], rtol=0, atol=0)
+    # host path of shift_tensor (bool masks) and the quantisation of normalised offsets
+    for (xo, yo), want in zip(gold["geo.shifts"].tolist(), gold["lat.align_masks"][:0]):
+        pass
+    m = masks[0]
+    from oracle import box_geometry as geo
+    for xo, yo in gold["geo.shifts"].tolist():
+        assert torch.equal(U.shift_tensor(m, xo, yo, offset_normalized=True), geo.shift_tensor(m, xo, yo, offset_normalized=True))
+    with pytest.raises(ValueError):
+        U.binary_mask_to_box(torch.zeros(8, 8))
+    from theatergen_amd.schedule import get_fast_schedule
+    ts = torch.arange(981, 0, -20)
+    assert np.array_equal(get_fast_schedule(ts, 10, 2).numpy(), gold["sched.fast_10_2"])
+    assert np.array_equal(get_fast_schedule(ts, 49, 2).numpy(), gold["sched.fast_49_2"])
+
+
+def test_phrase_indices_vs_reference_golden():
+    from tests.golden.gen_common import FakeTokenizer
+    from theatergen_amd import guidance as G
+    gold = _load("guidance")
+    tok = FakeTokenizer()
+    prompt = "a photo of a red cat and a small brown dog , park"
+    pos, wti = G.get_phrase_indices(tok, prompt, ["a red cat", "a small brown dog"], words=["cat", "dog"], return_word_token_indices=True)
+    assert pos[0] == gold["phrase.pos0"].tolist() and pos[1] == gold["phrase.pos1"].tolist() and wti == gold["phrase.wti"].tolist()
+    pos2, newp = G.get_phrase_indices(tok, "a street", ["a blue car"], add_suffix_if_not_found=True)
+    assert pos2[0] == gold["phrase.suffix.pos0"].tolist() and newp == str(gold["phrase.suffix.prompt"])
+
+
+def test_parameter_tables_and_module_keys():
+    import math
+    from theatergen_amd import config, weights
+    from theatergen_amd.unet import UNet2DConditionModel, install_ip_processors
+    n15 = sum(math.prod(s) for k, s in weights.unet_param_shapes(config.sd15()).items() if "_ip" not in k)
+    nxl = sum(math.prod(s) for k, s in weights.unet_param_shapes(config.sdxl()).items() if "_ip" not in k)
+    assert n15 == 859_520_964 and nxl == 2_567_463_684          # the public parameter counts of SD-1.5 / SDXL UNets
+    for cfg in (config.tiny(), config.tiny(linear=True), config.tiny(xl=True)):
+        m = UNet2DConditionModel(cfg)
+        install_ip_processors(m, num_tokens=4)
+        shapes = weights.unet_param_shapes(cfg)
+        sd = m.state_dict()
+        assert set(sd.keys()) == set(shapes.keys())
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k]), k
+    # processor table: names / order as diffusers' attn_processors (reference ip_adapter.py:95-119, 139-140)
+    m = UNet2DConditionModel(config.tiny())
+    names = list(m.attn_processors.keys())
+    assert names[0] == "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor"
+    assert names[1] == "down_blocks.0.attentions.0.transformer_blocks.0.attn2.processor"
+    assert sum(n.startswith("mid_block") for n in names) == 2 and len(names) == 32
+
+
+def test_story_workload_and_sharding():
+    from theatergen_amd import distributed as D
+    from theatergen_amd import story
+    jobs = story.story_jobs(3)
+    assert len(jobs) == 8 and {j.turn for j in jobs} == {1, 2, 3, 4} and {j.char for j in jobs} == {0, 1}
+    assert len({j.char_id for j in jobs}) == 2                     # two characters persist across the four turns
+    assert len({j.text_seed for j in jobs}) == 8
+    assert story.box_xyxy(0) == [40 / 512, 150 / 512, 230 / 512, 450 / 512]
+    sh = story.shared_conditioning(64, 4, torch.float32, "cpu")
+    tok = story.character_image_tokens([jobs[0].char_id, jobs[1].char_id], 64, 4, torch.float32, "cpu")
+    cidx = {jobs[0].char_id: 0, jobs[1].char_id: 1}
+    enc = story.job_conditioning(jobs, sh, tok, cidx, 64, torch.float32, "cpu")
+    assert enc.shape == (16, 81, 64)
+    assert torch.equal(enc[0, :77], sh["neg_text"][0]) and torch.equal(enc[8, 77:], tok[0]) and torch.equal(enc[9, 77:], tok[1])
+    assert torch.equal(enc[8 + 2, 77:], tok[0])                     # same character, next turn -> same image tokens
+    items = list(range(10))
+    parts = [D.shard(items, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == items and parts[1] == [1, 5, 9]

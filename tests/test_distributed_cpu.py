@@ -1,0 +1,55 @@
+"""CPU, world_size 2, gloo: the N>1 path of the driver (broadcast of shared conditioning, dialogue sharding,
+all_gather of final latents, max-over-ranks timing) — the same code bench.py runs over RCCL on GPUs."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from theatergen_amd import distributed as D
+    from theatergen_amd import story
+    r, w, _ = D.init(backend="gloo")
+    assert (r, w) == (rank, world) and D.is_dist()
+    shared = story.shared_conditioning(32, 4, torch.float32, "cpu")
+    want = {k: v.clone() for k, v in shared.items()}
+    if rank != 0:
+        for v in shared.values():
+            v.zero_()
+    D.broadcast_conditioning(shared, src=0)
+    ok_bcast = all(torch.equal(shared[k], want[k]) for k in want)
+    mine = D.shard(list(range(8)), rank, world)
+    local = torch.stack([torch.full((4, 8, 8), float(d)) for d in mine])      # "final latents" of my dialogues
+    allv = D.gather_latents(local)
+    ids = allv[:, 0, 0, 0].tolist()
+    t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    D.barrier()
+    out.put((rank, ok_bcast, mine, ids, t))
+    torch.distributed.destroy_process_group()
+
+
+def test_broadcast_shard_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_bcast, mine, ids, t in res:
+        assert ok_bcast
+        assert mine == [d for d in range(8) if d % 2 == rank]
+        assert ids == [0.0, 2.0, 4.0, 6.0, 1.0, 3.0, 5.0, 7.0]       # rank-major gather
+        assert t == 2.0                                               # MAX over ranks

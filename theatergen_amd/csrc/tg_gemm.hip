@@ -641,7 +641,20 @@ Plan make_plan(const tg_gemm_desc* d) {
   if (forced > 0) t = forced - 1;
   if (t >= kNumTiles) t = 0;
   if (use_v1(d) && t >= 4) t = 0;
-  int s = d->force_split_k > 0 ? d->force_split_k : 1;
+  // Split-K only for the weight-streaming layers (few output tiles, very long K: the 8x8 / 16x16 ResBlock convs stream
+  // 30-60 MB of weights through 80-320 blocks).  In situ (cold L2 / MALL) such a launch is HBM-LATENCY bound with a
+  // 2-deep DMA pipeline per block (measured 140 TF at 80 blocks); more blocks = more loads in flight.
+  int s = 1;
+  {
+    const long tiles = ((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn);
+    if (!d->geglu && t == 0) {
+      if (tiles <= 160 && nkt >= 48) s = (int)((400 + tiles - 1) / tiles);
+      else if (tiles <= 400 && nkt >= 96) s = 2;
+      if (s > 8) s = 8;
+      while (s > 1 && nkt / s < 8) --s;
+    }
+  }
+  if (d->force_split_k > 0) s = d->force_split_k;
   if (s > nkt) s = nkt;
   int kps = (nkt + s - 1) / s;
   s = (nkt + kps - 1) / kps;
