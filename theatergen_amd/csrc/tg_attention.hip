@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     }
   };
 
-  // scores of one 64-key tile for this lane's query, already scaled to log2 units and masked
+  // RAW scores of one 64-key tile for this lane's query (the softmax scale is folded into the exp2 argument by one
+  // fma per element); keys >= len are masked to -inf only on a ragged tile, full tiles take no compare/select at all.
   auto scores = [&](f32x16 (&s)[2], int len, int kv0) {
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt) {
@@ -148,11 +149,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         V8 kf = *reinterpret_cast<const V8*>(kr + ks * 16);
         s[kvt] = mfma32(kf, qf[ks], s[kvt]);
       }
+    }
+    if (kv0 + KV > len) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kv0 + kvt * 32 + mfma32_row(r, lane);
-        s[kvt][r] = kv < len ? s[kvt][r] * p.scale_log2 : -INFINITY;
-      }
+      for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvt * 32 + mfma32_row(r, lane);
+          if (kv >= len) s[kvt][r] = -INFINITY;
+        }
     }
   };
 
@@ -197,23 +202,31 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     else if (p.len1 > 0) load_regs(p.k1, p.k1_ld, p.k1_bs, p.vt1, p.vt1_ld, p.vt1_bs, p.len1, 0);
     f32x16 s[2];
     scores(s, p.len0, t * KV);
+    // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
+    // v_exp_f32 directly (__builtin_amdgcn_exp2f): arguments are <= 0, results in (0, 1], exp2(-inf) = 0 — none of
+    // exp2f()'s denormal-range rescaling (v_ldexp + compares + selects per element) is needed.
     const float m_new = fmaxf(m_run, tile_max(s));
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+    const float mc = m_new * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(s[kvt][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc));
         s[kvt][r] = e;
         ps += e;
       }
     l_run = l_run * alpha + ps;
+    // exact skip of the O rescale: when no lane of the wave raised its running max, alpha == 1 everywhere
+    // (after the first few tiles this is the common case; it saves 32 accumulator reads + muls + writes per tile)
+    if (__any(m_new > m_run)) {
+#pragma unroll
+      for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+    }
     m_run = m_new;
-#pragma unroll
-    for (int t2 = 0; t2 < DT; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
     pv(s);
   }
   {
@@ -232,13 +245,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     __syncthreads();
     f32x16 s[2];
     scores(s, p.len1, 0);
-    const float m1 = tile_max(s);
+    const float mc1 = tile_max(s) * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(s[kvt][r] - m1);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc1));
         s[kvt][r] = e;
         ps += e;
       }
