@@ -79,7 +79,7 @@ def bench_conv(h, cin, cout, variants, c1=0, stride=1, up=False):
 
 
 if __name__ == "__main__":
-    variants = [("auto", 0), ("128s2", 1), ("256x128_8w", 7), ("256x256_8w", 8), ("256x128_4w", 9), ("64s3", 2)]
+    variants = [("auto(halo)", 0), ("128s2", 1)]
     if "--quick" in sys.argv:
         variants = [("auto", 0), ("v1_128", 17), ("v2_128", 1), ("v2_256x128", 5)]
     bench_conv(64, 320, 320, variants)

@@ -154,6 +154,9 @@ CONV_CASES = [
     (2, 16, 16, 64, 0, 64, 1, False), (2, 16, 16, 128, 0, 64, 2, False), (1, 8, 8, 64, 0, 128, 1, True),
     (2, 8, 8, 128, 64, 128, 1, False), (2, 64, 64, 320, 0, 320, 1, False), (3, 5, 7, 64, 0, 64, 1, False),
     (2, 7, 7, 64, 0, 64, 2, False), (2, 8, 8, 1280, 1280, 1280, 1, False),
+    # LDS-halo kernel (stride 1, width 16/32/64, M >= 4096): all three widths, two-source concat, ragged N
+    (16, 16, 16, 128, 0, 192, 1, False), (4, 32, 32, 64, 64, 128, 1, False), (1, 64, 64, 64, 0, 320, 1, False),
+    (2, 64, 64, 128, 64, 64, 1, False),
 ]
 
 

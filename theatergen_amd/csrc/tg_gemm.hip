@@ -414,21 +414,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
 __device__ __attribute__((aligned(256))) unsigned char tg_zero_page[256];
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
-  constexpr int NDMA = BM / (8 * NW) + BN / (8 * NW);   // LDS-DMA instructions per wave per K-tile (constant: invalid rows fetch the zero page)
+  constexpr int CH = BKT / 8;                 // 16-byte chunks per LDS row (8 at BK = 64, 4 at BK = 32)
+  constexpr int RPI = 64 / CH;                // tile rows covered by one 1-KiB DMA instruction (8 or 16)
+  constexpr int KSH = CH == 8 ? 1 : 2;        // swizzle key = (row >> KSH) & (CH - 1): conflict-free ds_read_b128 groups
+  constexpr int NDMA = BM / (RPI * NW) + BN / (RPI * NW);   // LDS-DMA instructions per wave per K-tile (constant: invalid rows fetch the zero page)
   constexpr int TM = BM / (WAVES_M * 32);
   constexpr int TN = BN / (WAVES_N * 32);
-  constexpr int XJ = BM / (8 * NW);   // DMA instructions per wave per K-tile for the activation tile (8 rows each)
-  constexpr int WJ = BN / (8 * NW);
+  constexpr int XJ = BM / (RPI * NW);   // DMA instructions per wave per K-tile for the activation tile
+  constexpr int WJ = BN / (RPI * NW);
+  static_assert(BKT == 64 || BKT == 32, "BK");
   typedef typename Vec<T>::v8 V8;
   static_assert(NW % 2 == 0 && XJ >= 1 && WJ >= 1, "tile / wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sX = reinterpret_cast<T*>(smem);                 // [2][BM][64]
-  T* sW = sX + STAGES * BM * BK;                      // [STAGES][BN][64]
+  T* sW = sX + STAGES * BM * BKT;                     // [STAGES][BN][BKT]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -441,16 +445,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   const long m0 = (long)tile_m * BM;
   const long n0 = (long)tile_n * BN;
   const int split = blockIdx.z;
-  const int nkt_total = (int)((p.K + BK - 1) / BK);
+  const int nkt_total = (int)((p.K + BKT - 1) / BKT);
   const int kt_begin = split * p.kt_per_split;
   int kt_end = kt_begin + p.kt_per_split;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
 
-  // DMA lane geometry: instruction q covers tile rows [8q, 8q+8); lane -> (row 8q + lane/8, 16-byte slot lane%8)
-  const int lrow = lane >> 3;
-  const int slot = lane & 7;
-  const int wkey = (4 * (wave & 1) + (lane >> 4)) & 7;   // ((8q + lane/8) >> 1) & 7 with q = j*NW + wave
+  // DMA lane geometry: instruction q covers tile rows [RPI*q, RPI*q + RPI); lane -> (row RPI*q + lane/CH, slot lane%CH)
+  const int lrow = lane / CH;
+  const int slot = lane & (CH - 1);
+  // key of row RPI*q + lrow, q = j*NW + wave: BK=64: ((8q + lrow) >> 1) & 7 = (4(wave&1) + lane/16) & 7;  BK=32: (lane/16) & 3
+  const int wkey = CH == 8 ? ((4 * (wave & 1) + (lane >> 4)) & 7) : ((lane >> 4) & 3);
   const int chunk = slot ^ wkey;                          // global 16-byte chunk this lane fetches into its slot
 
   const T* A0 = reinterpret_cast<const T*>(p.a0);
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   bool x_ok[XJ];
 #pragma unroll
   for (int j = 0; j < XJ; ++j) {
-    const long m = m0 + (j * NW + wave) * 8 + lrow;
+    const long m = m0 + (j * NW + wave) * RPI + lrow;
     x_ok[j] = m < p.M;
     xbase[j] = m * p.c0;
     xrow[j] = m;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   const T* wrow[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; ++j) {
-    const long n = n0 + (j * NW + wave) * 8 + lrow;
+    const long n = n0 + (j * NW + wave) * RPI + lrow;
     wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
   }
 
@@ -491,15 +496,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   };
 
   auto issue_tile = [&](int kt, int buf) {
-    const long k0 = (long)kt * BK;
+    const long k0 = (long)kt * BKT;
     const long kc = k0 + chunk * 8;
     const bool kok = kc < p.K;
-    T* dx = sX + buf * BM * BK;
-    T* dw = sW + buf * BN * BK;
+    T* dx = sX + buf * BM * BKT;
+    T* dw = sW + buf * BN * BKT;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const T* src = (kok && wrow[j] != nullptr) ? wrow[j] + kc : zero;
-      dma(src, dw + (j * NW + wave) * 8 * BK);
+      dma(src, dw + (j * NW + wave) * RPI * BKT);
     }
     if (!CONV) {
       const T* base = A0;
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
       for (int j = 0; j < XJ; ++j) {
         const long off = second ? xrow[j] * pitch : xbase[j];
         const T* src = (kok && x_ok[j]) ? base + off + kk : zero;
-        dma(src, dx + (j * NW + wave) * 8 * BK);
+        dma(src, dx + (j * NW + wave) * RPI * BKT);
       }
     } else {
       const int tap = (int)(k0 / ctot);
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
           ix = ux >> 1;
         }
         const T* src = ok ? base + ((long)(x_ob[j] * p.in_h + iy) * p.in_w + ix) * pitch + cc : zero;
-        dma(src, dx + (j * NW + wave) * 8 * BK);
+        dma(src, dx + (j * NW + wave) * RPI * BKT);
       }
     }
   };
@@ -560,22 +565,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
     __builtin_amdgcn_s_barrier();
     const int l31 = lane & 31;
     const int hi = lane >> 5;
-    const int rkey = (l31 >> 1) & 7;
+    const int rkey = (l31 >> KSH) & (CH - 1);
     int buf = 0;
     for (int it = 0; it < nkt; ++it) {
-      const T* bx = sX + buf * BM * BK + (wave_m * TM * 32 + l31) * BK;
-      const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
+      const T* bx = sX + buf * BM * BKT + (wave_m * TM * 32 + l31) * BKT;
+      const T* bw = sW + buf * BN * BKT + (wave_n * TN * 32 + l31) * BKT;
       // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
       // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
       // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
-      V8 xf[BK / 16][TM], wf[BK / 16][TN];
+      V8 xf[BKT / 16][TM], wf[BKT / 16][TN];
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
+      for (int ks = 0; ks < BKT / 16; ++ks) {
         const int so = ((2 * ks + hi) ^ rkey) * 8;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BK + so);
+        for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BK + so);
+        for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
       }
       __builtin_amdgcn_sched_barrier(0);
       // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks)
+      for (int ks = 0; ks < BKT / 16; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -605,6 +610,191 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), split);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// conv3x3 with an LDS-STAGED HALO WINDOW (stride 1, pad 1, image width 16 / 32 / 64).
+// The implicit-GEMM kernel above fetches every activation row 9 times (once per tap) through L2; the GEMM family is
+// bound by L2 -> LDS operand delivery (profiles/r1_gemm_findings.md), so here a block = 128 output pixels = TH full
+// image rows stages the (TH+2) x (W+2) input halo of ONE 64-channel chunk in LDS once and serves all 9 taps from
+// it: the MFMA B-operand (lane = pixel) is read at slab row (py+ky)*(W+2) + px+kx.  K runs chunk-major / tap-minor;
+// only the 128x64 weight tile streams per K-step (double-buffered).  Activation L2 traffic drops 9x, total operand
+// traffic per FLOP by ~1.7x.  Same swizzle, same accumulator layout and the same epilogue as the GEMM kernel
+// (full-width rows make the block's pixels contiguous in the token-major tensor).
+template <typename T, int WI>
+__global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, WAVES_N = 2;
+  constexpr int TH = BM / WI, SW = WI + 2, SLAB = (TH + 2) * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
+  constexpr int WJ = BN / (8 * NW);
+  typedef typename Vec<T>::v8 V8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sS = reinterpret_cast<T*>(smem);                 // [NI*8][64]   halo slab of the current channel chunk
+  T* sW = sS + NI * 8 * BK;                           // [2][BN][64]  weight tiles (double-buffered)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % p.tiles_n;
+  const int tile_m = lbid / p.tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const long n0 = (long)tile_n * BN;
+  const int H = p.in_h;
+  const int img = (int)(m0 / ((long)H * WI));
+  const int y0 = (int)((m0 - (long)img * H * WI) / WI);
+
+  const int lrow = lane >> 3;
+  const int slot = lane & 7;
+  const int wkey = (4 * (wave & 1) + (lane >> 4)) & 7;
+  const int chunk = slot ^ wkey;
+
+  const T* A0 = reinterpret_cast<const T*>(p.a0);
+  const T* A1 = reinterpret_cast<const T*>(p.a1);
+  const T* Wp = reinterpret_cast<const T*>(p.w);
+  const T* zero = reinterpret_cast<const T*>(tg_zero_page);
+  const int ctot = p.c0 + p.c1;
+  const int nchunks = ctot / BK;
+
+  int spix[SJ];                                       // input pixel feeding this lane's slab row (-1: zero padding)
+#pragma unroll
+  for (int j = 0; j < SJ; ++j) {
+    const int sr = (j * NW + wave) * 8 + lrow;
+    const int sy = sr / SW, sx = sr - sy * SW;
+    const int iy = y0 - 1 + sy, ix = sx - 1;
+    const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI && (m0 < p.M);
+    spix[j] = ok ? (img * H + iy) * WI + ix : -1;
+  }
+  const T* wrow[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const long n = n0 + (j * NW + wave) * 8 + lrow;
+    wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
+  }
+
+  auto dma = [&](const T* src, T* lds_row_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
+  };
+  auto issue_slab = [&](int cc) {
+    int c = cc * BK;
+    const T* base = A0;
+    int pitch = p.c0;
+    if (c >= p.c0) { base = A1; pitch = p.c1; c -= p.c0; }
+    c += chunk * 8;
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+      if (j * NW + wave < NI) {
+        const T* src = spix[j] >= 0 ? base + (long)spix[j] * pitch + c : zero;
+        dma(src, sS + (j * NW + wave) * 8 * BK);
+      }
+    }
+  };
+  auto issue_w = [&](int cc, int tap, int buf) {
+    const long kc = (long)tap * ctot + cc * BK + chunk * 8;
+    T* dw = sW + buf * BN * BK;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const T* src = wrow[j] != nullptr ? wrow[j] + kc : zero;
+      dma(src, dw + (j * NW + wave) * 8 * BK);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int rkey = (l31 >> 1) & 7;
+  int sr0[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pm = wave_m * TM * 32 + i * 32 + l31;
+    sr0[i] = (pm / WI) * SW + (pm % WI);
+  }
+
+  issue_slab(0);
+  issue_w(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int nkt = nchunks * 9;
+  int cc = 0, tap = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
+    V8 xf[BK / 16][TM], wf[BK / 16][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int sr = sr0[i] + ky * SW + kx;
+      const int key = (sr >> 1) & 7;
+      const T* bx = sS + sr * BK;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) xf[ks][i] = *reinterpret_cast<const V8*>(bx + ((2 * ks + hi) ^ key) * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int so = ((2 * ks + hi) ^ rkey) * 8;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BK + so);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int ncc = cc, ntap = tap + 1;
+    if (ntap == 9) { ntap = 0; ncc = cc + 1; }
+    if (kt + 1 < nkt) {
+      if (ntap == 0) {
+        // the next K-step starts a new channel chunk: every wave must have its tap-8 fragments in registers before
+        // the slab is overwritten; the slab DMA then overlaps this step's 16 MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_slab(ncc);
+      }
+      issue_w(ncc, ntap, buf ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cc = ncc;
+    tap = ntap;
+  }
+
+  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), 0);
+}
+
+template <typename T, int WI>
+int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
+  constexpr int TH = 128 / WI, SLAB = (TH + 2) * (WI + 2), NI = (SLAB + 7) / 8;
+  const size_t lds = ((size_t)NI * 8 * BK + 2 * 128 * BK) * sizeof(T);
+  auto k = conv_halo_kernel<T, WI>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+inline bool halo_eligible(const tg_gemm_desc* d) {
+  if (d->mode != 1 || d->stride != 1 || d->upsample || (d->force_tile & 15) != 0 || (d->force_tile & 16) || d->force_split_k > 1) return false;
+  if (d->in_w != 16 && d->in_w != 32 && d->in_w != 64) return false;
+  const int th = 128 / d->in_w;
+  if (d->in_h % th != 0 || d->M % 128 != 0) return false;
+  if (d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0)) return false;
+  return d->M >= 4096;      // small-M layers are weight-streaming bound: split-K implicit GEMM serves them better
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const long n4s = p.N / 4;
@@ -618,9 +808,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{128, 128}, {64, 64}, {128, 64}, {64, 128}, {256, 128}, {128, 128}, {256, 128}, {256, 256}, {256, 128}};
-constexpr int kNumTiles = 9;   // ids 5.. = experimental variants (forced only): stage counts, 256x256 (8 waves of 128x64), 256x128 (4 waves of 128x64)
+struct TileCfg { int bm, bn, bk; };
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {256, 128, 64}, {128, 128, 64}, {256, 128, 64},
+                          {256, 256, 64}, {256, 128, 64}, {256, 128, 32}, {256, 128, 32}, {256, 256, 32}, {128, 128, 32}};
+constexpr int kNumTiles = 13;  // ids 4.. = experimental variants (forced only): stage counts, 256-wide tiles, BK = 32
 // force_tile: low 4 bits = 1 + tile id (0 = heuristic); bit 4 (16) = use the v1 register-staged kernel
 inline bool use_v1(const tg_gemm_desc* d) { return (d->force_tile & 16) != 0; }
 
@@ -632,7 +823,6 @@ Plan make_plan(const tg_gemm_desc* d) {
   // split-K (fp32 partials + a reduce launch) never paid off, so it is only taken when forced (tests) — except for
   // skinny problems where one dimension is <= 64.
   const long M = d->M, N = d->N, K = d->K;
-  const int nkt = (int)((K + BK - 1) / BK);
   int t = 0;
   if (N <= 64 && M > 64) t = 2;        // 128 x 64
   else if (M <= 64 && N > 64) t = 3;   // 64 x 128
@@ -641,6 +831,8 @@ Plan make_plan(const tg_gemm_desc* d) {
   if (forced > 0) t = forced - 1;
   if (t >= kNumTiles) t = 0;
   if (use_v1(d) && t >= 4) t = 0;
+  const int bk = kTiles[t].bk;
+  const int nkt = (int)((K + bk - 1) / bk);
   // Split-K only for the weight-streaming layers (few output tiles, very long K: the 8x8 / 16x16 ResBlock convs stream
   // 30-60 MB of weights through 80-320 blocks).  In situ (cold L2 / MALL) such a launch is HBM-LATENCY bound with a
   // 2-deep DMA pipeline per block (measured 140 TF at 80 blocks); more blocks = more loads in flight.
@@ -662,17 +854,17 @@ Plan make_plan(const tg_gemm_desc* d) {
   return Plan{t, s, kps, tm, tn};
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKT = 64>
 int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(T);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), 1, (unsigned)pl.splits);
   if (d->mode == 1) {
-    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, true, STAGES>;
+    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, true, STAGES, BKT>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
   } else {
-    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, false, STAGES>;
+    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, false, STAGES, BKT>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
@@ -729,10 +921,18 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.ws = reinterpret_cast<float*>(d->workspace);
   p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; p.tiles_n = (int)pl.tiles_n;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !halo_eligible(d)) {
     TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= (int64_t)pl.splits * d->M * d->N * 4, TG_ERR_ARG,
              "tg_gemm: split-K needs %lld workspace bytes, got %lld", (long long)pl.splits * d->M * d->N * 4,
              (long long)d->workspace_bytes);
+  }
+  if (halo_eligible(d)) {
+    p.splits = 1;
+    p.tiles_n = (int)((d->N + 127) / 128);
+    const long tiles = (d->M / 128) * p.tiles_n;
+    if (d->in_w == 64) return launch_halo<T, 64>(p, tiles, st);
+    if (d->in_w == 32) return launch_halo<T, 32>(p, tiles, st);
+    return launch_halo<T, 16>(p, tiles, st);
   }
   if (!use_v1(d)) {
     switch (pl.tile) {
@@ -744,7 +944,11 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
       case 5: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);
       case 6: return launch_cfg2<T, 256, 128, 4, 2, 2>(d, p, pl, st);
       case 7: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);
-      default: return launch_cfg2<T, 256, 128, 2, 2, 2>(d, p, pl, st);
+      case 8: return launch_cfg2<T, 256, 128, 2, 2, 2>(d, p, pl, st);
+      case 9: return launch_cfg2<T, 256, 128, 2, 2, 3, 32>(d, p, pl, st);    // 4 waves of 128x64, BK 32, 72 KB -> 2 blocks / CU
+      case 10: return launch_cfg2<T, 256, 128, 2, 2, 2, 32>(d, p, pl, st);   // 48 KB -> 3 blocks / CU
+      case 11: return launch_cfg2<T, 256, 256, 2, 4, 3, 32>(d, p, pl, st);   // 8 waves of 128x64, 96 KB
+      default: return launch_cfg2<T, 128, 128, 2, 2, 4, 32>(d, p, pl, st);   // 4 stages of 16 KB: 3 tiles in flight, 2 blocks / CU
     }
   }
   switch (pl.tile) {
@@ -800,6 +1004,12 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
+  if (halo_eligible(d)) {   // LDS-halo conv kernel: 128x128 tile, reported with splits = 0
+    if (tile_m) *tile_m = 128;
+    if (tile_n) *tile_n = 128;
+    if (splits) *splits = 0;
+    return TG_OK;
+  }
   Plan pl = make_plan(d);
   if (tile_m) *tile_m = kTiles[pl.tile].bm;
   if (tile_n) *tile_n = kTiles[pl.tile].bn;
@@ -809,6 +1019,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
+  if (halo_eligible(d)) return 0;
   Plan pl = make_plan(d);
   return pl.splits > 1 ? (int64_t)pl.splits * d->M * d->N * 4 : 0;
 }

@@ -99,7 +99,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     e0.record()
     _lib.check(L.tg_gemm(C.byref(d), _stream()))
     e1.record()
-    _gemm_profile.append(dict(kernel=f"gemm_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>", splits=sp.value,
+    kname = "conv_halo_kernel<128x128>" if sp.value == 0 else f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
+    _gemm_profile.append(dict(kernel=kname, splits=sp.value,
                               M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1)))
     return out
 
