@@ -157,6 +157,8 @@ CONV_CASES = [
     # LDS-halo kernel (stride 1, width 16/32/64, M >= 4096): all three widths, two-source concat, ragged N
     (16, 16, 16, 128, 0, 192, 1, False), (4, 32, 32, 64, 64, 128, 1, False), (1, 64, 64, 64, 0, 320, 1, False),
     (2, 64, 64, 128, 64, 64, 1, False),
+    # LDS-halo kernel on the nearest-x2 upsampled input (output widths 64 / 32 / 16)
+    (1, 32, 32, 64, 0, 128, 1, True), (4, 16, 16, 128, 0, 64, 1, True), (16, 8, 8, 64, 0, 192, 1, True),
 ]
 
 

@@ -619,10 +619,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
 // only the 128x64 weight tile streams per K-step (double-buffered).  Activation L2 traffic drops 9x, total operand
 // traffic per FLOP by ~1.7x.  Same swizzle, same accumulator layout and the same epilogue as the GEMM kernel
 // (full-width rows make the block's pixels contiguous in the token-major tensor).
-template <typename T, int WI>
+// UPS = true: the same for Upsample2D (nearest x2 then conv3x3): WI is the OUTPUT width, the slab holds the
+// (TH/2 + 2) x (WI/2 + 2) INPUT pixels the block's upsampled window maps to (input pixel = upsampled coordinate >> 1).
+template <typename T, int WI, bool UPS>
 __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, WAVES_N = 2;
-  constexpr int TH = BM / WI, SW = WI + 2, SLAB = (TH + 2) * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
+  constexpr int TH = BM / WI, WIN = UPS ? WI / 2 : WI, SW = WIN + 2, SROWS = UPS ? TH / 2 + 2 : TH + 2;
+  constexpr int SLAB = SROWS * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
   constexpr int WJ = BN / (8 * NW);
   typedef typename Vec<T>::v8 V8;
 
@@ -640,9 +643,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   const int tile_m = lbid / p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const long n0 = (long)tile_n * BN;
-  const int H = p.in_h;
-  const int img = (int)(m0 / ((long)H * WI));
-  const int y0 = (int)((m0 - (long)img * H * WI) / WI);
+  const int H = p.in_h;                               // INPUT height (output height = 2H when UPS)
+  const int HO = UPS ? 2 * H : H;
+  const int img = (int)(m0 / ((long)HO * WI));
+  const int y0 = (int)((m0 - (long)img * HO * WI) / WI);
+  const int iy0 = UPS ? y0 / 2 - 1 : y0 - 1;          // input row held by slab row 0
 
   const int lrow = lane >> 3;
   const int slot = lane & 7;
@@ -661,9 +666,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   for (int j = 0; j < SJ; ++j) {
     const int sr = (j * NW + wave) * 8 + lrow;
     const int sy = sr / SW, sx = sr - sy * SW;
-    const int iy = y0 - 1 + sy, ix = sx - 1;
-    const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI && (m0 < p.M);
-    spix[j] = ok ? (img * H + iy) * WI + ix : -1;
+    const int iy = iy0 + sy, ix = sx - 1;
+    const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WIN && (m0 < p.M);
+    spix[j] = ok ? (img * H + iy) * WIN + ix : -1;
   }
   const T* wrow[WJ];
 #pragma unroll
@@ -711,11 +716,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   const int l31 = lane & 31;
   const int hi = lane >> 5;
   const int rkey = (l31 >> 1) & 7;
-  int sr0[TM];
+  int ppy[TM], ppx[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pm = wave_m * TM * 32 + i * 32 + l31;
-    sr0[i] = (pm / WI) * SW + (pm % WI);
+    ppy[i] = pm / WI;
+    ppx[i] = pm % WI;
   }
 
   issue_slab(0);
@@ -732,7 +738,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     V8 xf[BK / 16][TM], wf[BK / 16][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int sr = sr0[i] + ky * SW + kx;
+      const int sr = UPS ? (((ppy[i] + ky - 1) >> 1) + 1) * SW + ((ppx[i] + kx - 1) >> 1) + 1
+                         : (ppy[i] + ky) * SW + ppx[i] + kx;
       const int key = (sr >> 1) & 7;
       const T* bx = sS + sr * BK;
 #pragma unroll
@@ -774,11 +781,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), 0);
 }
 
-template <typename T, int WI>
+template <typename T, int WI, bool UPS>
 int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
-  constexpr int TH = 128 / WI, SLAB = (TH + 2) * (WI + 2), NI = (SLAB + 7) / 8;
+  constexpr int TH = 128 / WI, SLAB = UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2), NI = (SLAB + 7) / 8;
   const size_t lds = ((size_t)NI * 8 * BK + 2 * 128 * BK) * sizeof(T);
-  auto k = conv_halo_kernel<T, WI>;
+  auto k = conv_halo_kernel<T, WI, UPS>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, st, p);
@@ -787,10 +794,10 @@ int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || d->upsample || (d->force_tile & 15) != 0 || (d->force_tile & 16) || d->force_split_k > 1) return false;
-  if (d->in_w != 16 && d->in_w != 32 && d->in_w != 64) return false;
-  const int th = 128 / d->in_w;
-  if (d->in_h % th != 0 || d->M % 128 != 0) return false;
+  if (d->mode != 1 || d->stride != 1 || (d->force_tile & 15) != 0 || (d->force_tile & 16) || d->force_split_k > 1) return false;
+  if (d->out_w != 16 && d->out_w != 32 && d->out_w != 64) return false;
+  const int th = 128 / d->out_w;
+  if (d->out_h % th != 0 || d->M % 128 != 0) return false;
   if (d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0)) return false;
   return d->M >= 4096;      // small-M layers are weight-streaming bound: split-K implicit GEMM serves them better
 }
@@ -930,9 +937,14 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     p.splits = 1;
     p.tiles_n = (int)((d->N + 127) / 128);
     const long tiles = (d->M / 128) * p.tiles_n;
-    if (d->in_w == 64) return launch_halo<T, 64>(p, tiles, st);
-    if (d->in_w == 32) return launch_halo<T, 32>(p, tiles, st);
-    return launch_halo<T, 16>(p, tiles, st);
+    if (d->upsample) {
+      if (d->out_w == 64) return launch_halo<T, 64, true>(p, tiles, st);
+      if (d->out_w == 32) return launch_halo<T, 32, true>(p, tiles, st);
+      return launch_halo<T, 16, true>(p, tiles, st);
+    }
+    if (d->out_w == 64) return launch_halo<T, 64, false>(p, tiles, st);
+    if (d->out_w == 32) return launch_halo<T, 32, false>(p, tiles, st);
+    return launch_halo<T, 16, false>(p, tiles, st);
   }
   if (!use_v1(d)) {
     switch (pl.tile) {
