@@ -52,6 +52,7 @@ struct GemmParams {
   int kt_per_split;
   int tiles_n;
   long a_rpb, a_bs;
+  int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
 };
 
 template <typename T>
@@ -233,6 +234,134 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
           *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + n4) = o;
         }
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-transposed epilogue.  In the MFMA accumulator layout a lane owns ONE token row and 4 consecutive channels per
+// register quad, so the direct epilogue above issues 8-byte stores to 32 different 128-byte lines per instruction
+// (and the same pattern for residual loads): 16 K line accesses per CU per tile round, ~8.7 us of fixed cost per
+// 128x128 tile (K sweep in profiles/r1_gemm_findings.md) — more than the K loop itself when K <= 640.  Here each wave
+// bounces its fp32 accumulators through a private LDS scratch (the operand stages are dead after the K loop's last
+// barrier) and comes back with lane = (row, 8-channel piece): bias / per-batch vector / residual are 16-byte loads,
+// the store is 16 bytes per lane, 8 full 128-byte lines per wave-instruction.  Arithmetic and its order are
+// unchanged (fp32: acc + bias + bvec + res, activation, scale, one rounding), so results are bit-identical to the
+// direct epilogue.  Columns that go to the transposed output (out_t, lane = token is already coalesced there) and
+// split-K partials keep the direct path.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
+                                                  float* scr, int split) {
+  typedef typename Vec<T>::v4 V4;
+  typedef typename Vec<T>::v8 V8;
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (p.splits > 1 || !p.epi_lds || (p.n_split > 0 && n_wave >= p.n_split)) {
+    epilogue_tile<T, TM, TN>(p, acc, m_wave + l31, n_wave + 4 * hi, split);
+    return;
+  }
+  T* outp = reinterpret_cast<T*>(p.out);
+  const T* biasp = reinterpret_cast<const T*>(p.bias);
+  if constexpr (TN == 2) {
+    if (p.geglu) {
+      constexpr int RS = 36;
+      const int c = lane & 3, r0 = lane >> 2;       // 4 pieces x 16 rows per pass over the [32][32] result
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long na = n_wave + 4 * hi + 8 * g;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (na + 32 < p.N) {
+            V4 ba, bg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
+            if (biasp != nullptr) {
+              ba = *reinterpret_cast<const V4*>(biasp + na);
+              bg = *reinterpret_cast<const V4*>(biasp + na + 32);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = acc[i][0][4 * g + e] + to_f32<T>(ba[e]);
+              const float gt = acc[i][1][4 * g + e] + to_f32<T>(bg[e]);
+              o[e] = a * gelu_erf_f(gt) * p.out_scale;
+            }
+          }
+          *reinterpret_cast<f32x4*>(scr + l31 * RS + 8 * g + 4 * hi) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = it * 16 + r0;
+          const long m = m_wave + 32 * i + r;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
+          const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
+          if (m < p.M && n_wave + c * 8 + 32 < p.N) {
+            V8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = from_f32<T>(lo[e]); o[4 + e] = from_f32<T>(hi4[e]); }
+            *reinterpret_cast<V8*>(outp + m * p.ldc + (n_wave >> 1) + c * 8) = o;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
+  constexpr int W = TN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
+  const int c = lane % P, r0 = lane / P;
+  const long n = n_wave + c * 8;
+  const bool n_ok = n < p.N;
+  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
+  const T* resp = reinterpret_cast<const T*>(p.res);
+  V8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = from_f32<T>(0.f);
+  const V8 bias8 = (biasp != nullptr && n_ok) ? *reinterpret_cast<const V8*>(biasp + n) : zero8;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(scr + l31 * RS + 32 * j + 8 * g + 4 * hi) = o;
+      }
+    __builtin_amdgcn_wave_barrier();
+    V8 add8[NPASS], res8[NPASS];
+    f32x4 lo[NPASS], hi4[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int r = it * RPP + r0;
+      const long m = m_wave + 32 * i + r;
+      const bool ok = m < p.M && n_ok;
+      lo[it] = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
+      hi4[it] = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
+      const long b = (bvecp != nullptr && ok) ? m / p.rows_per_batch : 0;
+      add8[it] = (bvecp != nullptr && ok) ? *reinterpret_cast<const V8*>(bvecp + b * p.ldbvec + n) : zero8;
+      res8[it] = (resp != nullptr && ok) ? *reinterpret_cast<const V8*>(resp + m * p.ldres + n) : zero8;
+    }
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int r = it * RPP + r0;
+      const long m = m_wave + 32 * i + r;
+      if (!(m < p.M && n_ok)) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[it][e]; v[4 + e] = hi4[it][e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] + to_f32<T>(bias8[e]) + to_f32<T>(add8[it][e]) + to_f32<T>(res8[it][e]);
+      if (p.act == TG_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+      } else if (p.act == TG_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+      }
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e] * p.out_scale);
+      *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -607,7 +736,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
     }
   }
 
-  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), split);
+  epilogue_tile_lds<T, TM, TN>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                              reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), split);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -778,7 +908,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     tap = ntap;
   }
 
-  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), 0);
+  epilogue_tile_lds<T, TM, TN>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                              reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), 0);
 }
 
 template <typename T, int WI, bool UPS>
@@ -928,6 +1059,12 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.ws = reinterpret_cast<float*>(d->workspace);
   p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; p.tiles_n = (int)pl.tiles_n;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
+                (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
+                (d->n_split == 0 || d->n_split % 64 == 0);
+  }
   if (pl.splits > 1 && !halo_eligible(d)) {
     TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= (int64_t)pl.splits * d->M * d->N * 4, TG_ERR_ARG,
              "tg_gemm: split-K needs %lld workspace bytes, got %lld", (long long)pl.splits * d->M * d->N * 4,
