@@ -21,10 +21,7 @@
 
 namespace {
 
-inline bool use_v1_flag(const tg_gemm_desc* d) { return (d->force_tile & 16) != 0; }
-
 constexpr int BK = 64;
-constexpr int LDP = BK + 8;  // LDS row pitch in elements (144 B)
 
 struct GemmParams {
   const void* a0;
@@ -312,12 +309,46 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
   const bool n_ok = n < p.N;
   const T* bvecp = reinterpret_cast<const T*>(p.bvec);
   const T* resp = reinterpret_cast<const T*>(p.res);
+  // the epilogue is VALU-issue bound (it ran ~2.5 K instructions per wave and cost more than the K loop at K = 320):
+  // everything wave-uniform is hoisted or branched on, per element only the adds that are really needed remain.
+  // Skipped terms are exact no-ops (x + 0, x * 1), so every variant rounds the same fp32 value.
+  const bool has_add = bvecp != nullptr, has_res = resp != nullptr;
+  const bool unit_scale = p.out_scale == 1.f;
+  float bias_f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
+  if (biasp != nullptr && n_ok) {
+    const V8 b8 = *reinterpret_cast<const V8*>(biasp + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
+  }
   V8 zero8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero8[e] = from_f32<T>(0.f);
-  const V8 bias8 = (biasp != nullptr && n_ok) ? *reinterpret_cast<const V8*>(biasp + n) : zero8;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // residual / per-batch-vector loads first: their latency overlaps the LDS bounce
+    V8 add8[NPASS], res8[NPASS];
+    const long m_first = m_wave + 32 * i + r0;
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) { add8[it] = zero8; res8[it] = zero8; }
+    if (has_add) {
+#pragma unroll
+      for (int it = 0; it < NPASS; ++it) {
+        const long m = m_first + it * RPP;
+        const bool ok = m < p.M && n_ok;
+        const long b = ok ? m / p.rows_per_batch : 0;
+        if (ok) add8[it] = *reinterpret_cast<const V8*>(bvecp + b * p.ldbvec + n);
+      }
+    }
+    if (has_res) {
+      const T* rp = resp + m_first * p.ldres + n;
+#pragma unroll
+      for (int it = 0; it < NPASS; ++it) {
+        const bool ok = m_first + it * RPP < p.M && n_ok;
+        if (ok) res8[it] = *reinterpret_cast<const V8*>(rp + (long)it * RPP * p.ldres);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -326,29 +357,24 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
         *reinterpret_cast<f32x4*>(scr + l31 * RS + 32 * j + 8 * g + 4 * hi) = o;
       }
     __builtin_amdgcn_wave_barrier();
-    V8 add8[NPASS], res8[NPASS];
-    f32x4 lo[NPASS], hi4[NPASS];
+    T* op = outp + m_first * p.ldc + n;
 #pragma unroll
     for (int it = 0; it < NPASS; ++it) {
       const int r = it * RPP + r0;
-      const long m = m_wave + 32 * i + r;
-      const bool ok = m < p.M && n_ok;
-      lo[it] = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
-      hi4[it] = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
-      const long b = (bvecp != nullptr && ok) ? m / p.rows_per_batch : 0;
-      add8[it] = (bvecp != nullptr && ok) ? *reinterpret_cast<const V8*>(bvecp + b * p.ldbvec + n) : zero8;
-      res8[it] = (resp != nullptr && ok) ? *reinterpret_cast<const V8*>(resp + m * p.ldres + n) : zero8;
-    }
-#pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      const int r = it * RPP + r0;
-      const long m = m_wave + 32 * i + r;
-      if (!(m < p.M && n_ok)) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
+      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
+      if (!(m_first + it * RPP < p.M && n_ok)) continue;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[it][e]; v[4 + e] = hi4[it][e]; }
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias_f[e]; v[4 + e] = hi4[e] + bias_f[4 + e]; }
+      if (has_add) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] + to_f32<T>(bias8[e]) + to_f32<T>(add8[it][e]) + to_f32<T>(res8[it][e]);
+        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(add8[it][e]);
+      }
+      if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
+      }
       if (p.act == TG_ACT_SILU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
@@ -356,181 +382,17 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
       }
+      if (!unit_scale) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+      }
       V8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e] * p.out_scale);
-      *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e]);
+      *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
     }
     __builtin_amdgcn_wave_barrier();
   }
-}
-
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int TM = BM / (WAVES_M * 32);
-  constexpr int TN = BN / (WAVES_N * 32);
-  constexpr int XR = BM / 32;  // 16-B loads per thread for the activation tile
-  constexpr int WR = BN / 32;
-  typedef typename Vec<T>::v8 V8;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sX = reinterpret_cast<T*>(smem);                 // [2][BM][LDP]
-  T* sW = sX + 2 * BM * LDP;                          // [2][BN][LDP]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wave_m = wave / WAVES_N;
-  const int wave_n = wave % WAVES_N;
-  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
-  const int tile_n = lbid % p.tiles_n;
-  const int tile_m = lbid / p.tiles_n;
-  const long m0 = (long)tile_m * BM;
-  const long n0 = (long)tile_n * BN;
-  const int split = blockIdx.z;
-  const int nkt_total = (int)((p.K + BK - 1) / BK);
-  const int kt_begin = split * p.kt_per_split;
-  int kt_end = kt_begin + p.kt_per_split;
-  if (kt_end > nkt_total) kt_end = nkt_total;
-  const int nkt = kt_end - kt_begin;
-
-  const int chunk = tid & 7;
-  const int lrow = tid >> 3;  // 0..31
-
-  const T* A0 = reinterpret_cast<const T*>(p.a0);
-  const T* A1 = reinterpret_cast<const T*>(p.a1);
-  const T* Wp = reinterpret_cast<const T*>(p.w);
-  const int ctot = p.c0 + p.c1;
-
-  // per-thread row bookkeeping for the activation gather
-  long xbase[XR];   // plain: element offset of the row in source 0
-  long xrow[XR];
-  int x_oy[XR], x_ox[XR], x_ob[XR];
-  bool x_ok[XR];
-#pragma unroll
-  for (int i = 0; i < XR; ++i) {
-    long m = m0 + lrow + 32 * i;
-    x_ok[i] = m < p.M;
-    xbase[i] = m * p.c0;
-    xrow[i] = m;
-    if (!CONV && p.a_rpb > 0) { const long bb = m / p.a_rpb; xbase[i] = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
-    if (CONV) {
-      long mm = x_ok[i] ? m : 0;
-      int hw = p.out_h * p.out_w;
-      x_ob[i] = (int)(mm / hw);
-      int r = (int)(mm - (long)x_ob[i] * hw);
-      x_oy[i] = r / p.out_w;
-      x_ox[i] = r - x_oy[i] * p.out_w;
-    }
-  }
-
-  u32x4 xreg[XR], wreg[WR];
-
-  auto load_tile = [&](int kt) {
-    const long k0 = (long)kt * BK;
-    const long kc = k0 + chunk * 8;
-    // ---- weights
-    {
-      const bool kok = kc < p.K;
-#pragma unroll
-      for (int i = 0; i < WR; ++i) {
-        long n = n0 + lrow + 32 * i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (kok && n < p.N) v = *reinterpret_cast<const u32x4*>(Wp + n * p.K + kc);
-        wreg[i] = v;
-      }
-    }
-    // ---- activations
-    if (!CONV) {
-      const T* src = A0;
-      long pitch = p.c0;
-      long kk = kc;
-      bool kok = kc < p.K;
-      const bool second = A1 != nullptr && k0 >= p.c0;
-      if (second) { src = A1; pitch = p.c1; kk = kc - p.c0; }
-#pragma unroll
-      for (int i = 0; i < XR; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        const long off = second ? xrow[i] * pitch : xbase[i];
-        if (kok && x_ok[i]) v = *reinterpret_cast<const u32x4*>(src + off + kk);
-        xreg[i] = v;
-      }
-    } else {
-      const int tap = (int)(k0 / ctot);
-      int cc = (int)(k0 - (long)tap * ctot);
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const T* src = A0;
-      int pitch = p.c0;
-      if (cc >= p.c0) { src = A1; pitch = p.c1; cc -= p.c0; }
-      cc += chunk * 8;
-#pragma unroll
-      for (int i = 0; i < XR; ++i) {
-        int iy, ix;
-        bool ok = x_ok[i];
-        if (!p.upsample) {
-          iy = x_oy[i] * p.stride + ky - 1;
-          ix = x_ox[i] * p.stride + kx - 1;
-          ok = ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        } else {
-          int uy = x_oy[i] + ky - 1, ux = x_ox[i] + kx - 1;
-          ok = ok && uy >= 0 && uy < 2 * p.in_h && ux >= 0 && ux < 2 * p.in_w;
-          iy = uy >> 1;
-          ix = ux >> 1;
-        }
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const u32x4*>(src + ((long)(x_ob[i] * p.in_h + iy) * p.in_w + ix) * pitch + cc);
-        xreg[i] = v;
-      }
-    }
-  };
-
-  auto store_tile = [&](int buf) {
-    T* dx = sX + buf * BM * LDP;
-    T* dw = sW + buf * BN * LDP;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) *reinterpret_cast<u32x4*>(dx + (lrow + 32 * i) * LDP + chunk * 8) = xreg[i];
-#pragma unroll
-    for (int i = 0; i < WR; ++i) *reinterpret_cast<u32x4*>(dw + (lrow + 32 * i) * LDP + chunk * 8) = wreg[i];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (nkt > 0) {
-    load_tile(kt_begin);
-    store_tile(0);
-    __syncthreads();
-    const int frow = lane & 31;
-    const int fk = (lane >> 5) * 8;
-    for (int it = 0; it < nkt; ++it) {
-      const int buf = it & 1;
-      if (it + 1 < nkt) load_tile(kt_begin + it + 1);
-      const T* bx = sX + buf * BM * LDP + (wave_m * TM * 32 + frow) * LDP + fk;
-      const T* bw = sW + buf * BN * LDP + (wave_n * TN * 32 + frow) * LDP + fk;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        V8 xf[TM], wf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const V8*>(bx + i * 32 * LDP + ks * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const V8*>(bw + j * 32 * LDP + ks * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
-      }
-      if (it + 1 < nkt) store_tile(buf ^ 1);
-      __syncthreads();
-    }
-  }
-
-  epilogue_tile<T, TM, TN>(p, acc, m0 + wave_m * TM * 32 + (lane & 31), n0 + wave_n * TN * 32 + 4 * (lane >> 5), split);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -925,7 +787,7 @@ int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || (d->force_tile & 15) != 0 || (d->force_tile & 16) || d->force_split_k > 1) return false;
+  if (d->mode != 1 || d->stride != 1 || d->force_tile != 0 || d->force_split_k > 1) return false;
   if (d->out_w != 16 && d->out_w != 32 && d->out_w != 64) return false;
   const int th = 128 / d->out_w;
   if (d->out_h % th != 0 || d->M % 128 != 0) return false;
@@ -947,11 +809,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 }
 
 struct TileCfg { int bm, bn, bk; };
-const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {256, 128, 64}, {128, 128, 64}, {256, 128, 64},
-                          {256, 256, 64}, {256, 128, 64}, {256, 128, 32}, {256, 128, 32}, {256, 256, 32}, {128, 128, 32}};
-constexpr int kNumTiles = 13;  // ids 4.. = experimental variants (forced only): stage counts, 256-wide tiles, BK = 32
-// force_tile: low 4 bits = 1 + tile id (0 = heuristic); bit 4 (16) = use the v1 register-staged kernel
-inline bool use_v1(const tg_gemm_desc* d) { return (d->force_tile & 16) != 0; }
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}};
+constexpr int kNumTiles = 5;  // id 4 = 128x128 with 3 stages (forced only)
+// force_tile: 1 + tile id (0 = heuristic)
 
 struct Plan { int tile; int splits; int kt_per_split; long tiles_m, tiles_n; };
 
@@ -968,7 +828,6 @@ Plan make_plan(const tg_gemm_desc* d) {
   const int forced = d->force_tile & 15;
   if (forced > 0) t = forced - 1;
   if (t >= kNumTiles) t = 0;
-  if (use_v1(d) && t >= 4) t = 0;
   const int bk = kTiles[t].bk;
   const int nkt = (int)((K + bk - 1) / bk);
   // Split-K only for the weight-streaming layers (few output tiles, very long K: the 8x8 / 16x16 ResBlock convs stream
@@ -1006,32 +865,6 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
     hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
-  }
-  TG_LAUNCH_CHECK();
-  if (pl.splits > 1) {
-    long total = p.M * (p.N / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p);
-    TG_LAUNCH_CHECK();
-  }
-  return TG_OK;
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(T);
-  dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), 1, (unsigned)pl.splits);
-  if (d->mode == 1) {
-    auto k = gemm_kernel<T, BM, BN, WM, WN, true>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
-  } else {
-    auto k = gemm_kernel<T, BM, BN, WM, WN, false>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   }
   TG_LAUNCH_CHECK();
   if (pl.splits > 1) {
@@ -1083,28 +916,12 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     if (d->out_w == 32) return launch_halo<T, 32, false>(p, tiles, st);
     return launch_halo<T, 16, false>(p, tiles, st);
   }
-  if (!use_v1(d)) {
-    switch (pl.tile) {
-      case 0: return launch_cfg2<T, 128, 128, 2, 2, 2>(d, p, pl, st);
-      case 1: return launch_cfg2<T, 64, 64, 2, 2, 3>(d, p, pl, st);
-      case 2: return launch_cfg2<T, 128, 64, 4, 1, 3>(d, p, pl, st);
-      case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
-      case 4: return launch_cfg2<T, 256, 128, 4, 2, 3>(d, p, pl, st);
-      case 5: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);
-      case 6: return launch_cfg2<T, 256, 128, 4, 2, 2>(d, p, pl, st);
-      case 7: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);
-      case 8: return launch_cfg2<T, 256, 128, 2, 2, 2>(d, p, pl, st);
-      case 9: return launch_cfg2<T, 256, 128, 2, 2, 3, 32>(d, p, pl, st);    // 4 waves of 128x64, BK 32, 72 KB -> 2 blocks / CU
-      case 10: return launch_cfg2<T, 256, 128, 2, 2, 2, 32>(d, p, pl, st);   // 48 KB -> 3 blocks / CU
-      case 11: return launch_cfg2<T, 256, 256, 2, 4, 3, 32>(d, p, pl, st);   // 8 waves of 128x64, 96 KB
-      default: return launch_cfg2<T, 128, 128, 2, 2, 4, 32>(d, p, pl, st);   // 4 stages of 16 KB: 3 tiles in flight, 2 blocks / CU
-    }
-  }
   switch (pl.tile) {
-    case 0: return launch_cfg<T, 128, 128, 2, 2>(d, p, pl, st);
-    case 1: return launch_cfg<T, 64, 64, 2, 2>(d, p, pl, st);
-    case 2: return launch_cfg<T, 128, 64, 4, 1>(d, p, pl, st);
-    default: return launch_cfg<T, 64, 128, 1, 4>(d, p, pl, st);
+    case 0: return launch_cfg2<T, 128, 128, 2, 2, 2>(d, p, pl, st);
+    case 1: return launch_cfg2<T, 64, 64, 2, 2, 3>(d, p, pl, st);
+    case 2: return launch_cfg2<T, 128, 64, 4, 1, 3>(d, p, pl, st);
+    case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
+    default: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
   }
 }
 
@@ -1120,7 +937,7 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
              TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
     const int ft = d->force_tile & 15;
-    TG_CHECK(!use_v1_flag(d) && (ft == 0 || ft == 1 || ft == 6 || ft == 7), TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
+    TG_CHECK(ft == 0 || ft == 1 || ft == 5, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
     TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
   }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
