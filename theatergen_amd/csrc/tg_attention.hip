@@ -21,7 +21,15 @@
 namespace {
 
 constexpr int KV = 64;        // keys per tile
-constexpr int VT_LDP = KV + 8;  // V^T tile row pitch (elements)
+
+// LDS-DMA sources for out-of-range pieces: head-dim / key padding reads zeros; the "ones row" (below) reads 1.0
+__device__ __attribute__((aligned(256))) unsigned char attn_zero_page[256];
+#define TG_R8(x) x, x, x, x, x, x, x, x
+__device__ __attribute__((aligned(256))) const unsigned short attn_ones_bf16[64] = {TG_R8(TG_R8(0x3F80))};
+__device__ __attribute__((aligned(256))) const unsigned short attn_ones_f16[64] = {TG_R8(TG_R8(0x3C00))};
+template <typename T> __device__ __forceinline__ const T* ones_page();
+template <> __device__ __forceinline__ const bf16_t* ones_page<bf16_t>() { return reinterpret_cast<const bf16_t*>(attn_ones_bf16); }
+template <> __device__ __forceinline__ const f16_t* ones_page<f16_t>() { return reinterpret_cast<const f16_t*>(attn_ones_f16); }
 
 struct AttnParams {
   int heads, hd, n_q, n_qblk;
@@ -37,22 +45,31 @@ struct AttnParams {
   void* out; long out_ld, out_bs;
 };
 
-template <typename T, int DPAD, int DV>
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+// Data path: K tile = NP panels of [64 keys][64 d] and V^T tile = [DV d][64 keys], both as 128-byte LDS rows filled by
+// LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write pass) with the GEMM's XOR swizzle (16-byte slot ^
+// ((row >> 1) & 7), applied on the source address and again on the fragment read).  Two stages: the DMA of tile t+1
+// is in flight while tile t is multiplied, one barrier per tile.
+// ONES (variants whose DV exceeds the head dim): V^T row DV-1 is fed from a page of 1.0, so the PV MFMA itself
+// accumulates the softmax denominator l = sum_k p[k] in accumulator row DV-1 (rescaled with O for free) and the 32
+// per-tile v_add_f32 of the row sum disappear — the loop is VALU-bound (32 v_exp_f32 at quarter rate + ~100 other
+// VALU ops against 14 MFMAs per wave-tile at head dim 40), so every removed VALU instruction counts.
+template <typename T, int DPAD, int DV, bool ONES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 3 : (DV <= 96 ? 2 : 1)))) void attention_kernel(AttnParams p) {
   typedef typename Vec<T>::v8 V8;
   typedef typename Vec<T>::v4 V4;
-  constexpr int K_LDP = DPAD + 8;
-  constexpr int KCH = DPAD / 8;                 // 16-B chunks per K row
-  constexpr int K_ITEMS = (KV * KCH + 255) / 256;
-  constexpr int V_ITEMS = (DV * (KV / 8) + 255) / 256;
+  constexpr int NP = (DPAD + 63) / 64;          // K panels
   constexpr int NKS = DPAD / 16;
   constexpr int DT = DV / 32;
+  constexpr int KJ = NP * 2;                    // K DMA instructions per wave per tile (8 rows x 8 slots each)
+  constexpr int VJ = DV / 32;                   // V^T DMA instructions per wave per tile
+  constexpr int K_ELEMS = NP * 64 * 64;
+  constexpr int STAGE = K_ELEMS + DV * 64;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sK = reinterpret_cast<T*>(smem);            // [KV][K_LDP]
-  T* sV = sK + KV * K_LDP;                       // [DV][VT_LDP]
+  T* sbase = reinterpret_cast<T*>(smem);         // [2][ K: NP x 64 x 64 | V^T: DV x 64 ]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware block order (speed only): block b runs on XCD b % 8; give each XCD a contiguous chunk of the
   // (batch, head, q-block) space so that all q-blocks of one (batch, head) share K / V^T through ONE private L2.
   int lbid;
@@ -88,65 +105,58 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  u32x4 kreg[K_ITEMS], vreg[V_ITEMS];
-
-  auto load_regs = [&](const void* kbase, long k_ld, long k_bs, const void* vbase, long vt_ld, long vt_bs, int len, int kv0) {
-    const T* kp = reinterpret_cast<const T*>(kbase) + (long)b * k_bs + (long)h * HD;
-    const T* vp = reinterpret_cast<const T*>(vbase) + (long)b * vt_bs + (long)h * HD * vt_ld;
+  // ---- LDS-DMA tile loader
+  const int lrow = lane >> 3, slot = lane & 7;
+  const T* zero = reinterpret_cast<const T*>(attn_zero_page);
+  auto dma = [&](const T* src, T* lds_row_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
+  };
+  auto issue = [&](const T* kb, long k_ld, const T* vb, long vt_ld, int len, int kv0, int stage) {
+    T* sK = sbase + stage * STAGE;
+    T* sV = sK + K_ELEMS;
 #pragma unroll
-    for (int i = 0; i < K_ITEMS; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / KCH, ch = idx - row * KCH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < KV * KCH && kv0 + row < len && ch * 8 < HD) v = *reinterpret_cast<const u32x4*>(kp + (long)(kv0 + row) * k_ld + ch * 8);
-      kreg[i] = v;
+    for (int j = 0; j < KJ; ++j) {
+      const int q = j * 4 + wave;                       // rows [8q, 8q+8) of the panel stack
+      const int prow = 8 * q + lrow;
+      const int r = prow & 63, panel = prow >> 6;
+      const int d0 = panel * 64 + ((slot ^ ((r >> 1) & 7)) << 3);
+      const bool ok = d0 < HD && kv0 + r < len;
+      dma(ok ? kb + (long)(kv0 + r) * k_ld + d0 : zero, sK + q * 512);
     }
 #pragma unroll
-    for (int i = 0; i < V_ITEMS; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx >> 3, ch = idx & 7;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      const int c0 = kv0 + ch * 8;
-      if (idx < DV * 8 && row < HD && c0 < len) {
-        v = *reinterpret_cast<const u32x4*>(vp + (long)row * vt_ld + c0);
-        if (c0 + 8 > len) {  // partial chunk: padding columns may hold anything -> force exact zeros
-          V8 e = __builtin_bit_cast(V8, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (c0 + j >= len) e[j] = from_f32<T>(0.f);
-          v = __builtin_bit_cast(u32x4, e);
-        }
-      }
-      vreg[i] = v;
+    for (int j = 0; j < VJ; ++j) {
+      const int q = j * 4 + wave;
+      const int d = 8 * q + lrow;
+      const int c0 = kv0 + ((slot ^ ((d >> 1) & 7)) << 3);
+      const T* src = (d < HD && c0 < len) ? vb + (long)d * vt_ld + c0 : zero;
+      if (ONES && d == DV - 1) src = ones_page<T>();
+      dma(src, sV + q * 512);
+    }
+  };
+  // a 16-byte V^T chunk that straddles `len` brought columns >= len along (they may hold anything, and 0 * NaN = NaN
+  // in the PV MFMA): zero them in LDS.  Only ragged tiles (text 77 = 64 + 13 keys, 4 image tokens) take this path.
+  auto fixup_v = [&](int rem, int stage) {
+    T* sV = sbase + stage * STAGE + K_ELEMS;
+    if (tid < DV && tid < HD) {
+      const int d = tid, ch = rem >> 3;
+      T* rowp = sV + d * 64 + ((ch ^ ((d >> 1) & 7)) << 3);
+      for (int c = rem & 7; c < 8; ++c) rowp[c] = from_f32<T>(0.f);
     }
   };
 
-  auto store_lds = [&]() {
-#pragma unroll
-    for (int i = 0; i < K_ITEMS; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / KCH, ch = idx - row * KCH;
-      if (idx < KV * KCH) *reinterpret_cast<u32x4*>(sK + row * K_LDP + ch * 8) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < V_ITEMS; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx >> 3, ch = idx & 7;
-      if (idx < DV * 8) *reinterpret_cast<u32x4*>(sV + row * VT_LDP + ch * 8) = vreg[i];
-    }
-  };
-
+  const int skey = (l31 >> 1) & 7;                       // swizzle key of this lane's fragment rows
   // RAW scores of one 64-key tile for this lane's query (the softmax scale is folded into the exp2 argument by one
   // fma per element); keys >= len are masked to -inf only on a ragged tile, full tiles take no compare/select at all.
-  auto scores = [&](f32x16 (&s)[2], int len, int kv0) {
+  auto scores = [&](f32x16 (&s)[2], const T* sK, int len, int kv0) {
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kvt][r] = 0.f;
-      const T* kr = sK + (kvt * 32 + l31) * K_LDP + hi * 8;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        V8 kf = *reinterpret_cast<const V8*>(kr + ks * 16);
+        const T* kr = sK + (ks >> 2) * 4096 + (kvt * 32 + l31) * 64 + ((((ks & 3) * 2 + hi) ^ skey) << 3);
+        V8 kf = *reinterpret_cast<const V8*>(kr);
         s[kvt] = mfma32(kf, qf[ks], s[kvt]);
       }
     }
@@ -170,19 +180,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     return fmaxf(mx, __shfl_xor(mx, 32, 64));
   };
 
-  // O^T += V^T * P^T for one tile; P^T comes straight from the score registers
-  auto pv = [&](const f32x16 (&s)[2]) {
+  // O^T += V^T * P^T for one tile; P^T comes straight from the score registers: chunk c covers keys
+  // kvt*32 + 16*cc + {4*hi .. +3, 8 + 4*hi .. +3}, i.e. 8 bytes at offset 8*hi of two neighbouring 16-byte slots
+  auto pv = [&](const f32x16 (&s)[2], const T* sV) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int kvt = c >> 1, cc = c & 1;
       V8 pf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[kvt][8 * cc + j]);
-      const T* vr = sV + l31 * VT_LDP + kvt * 32 + 16 * cc + 4 * hi;
+      const int s0 = 4 * kvt + 2 * cc;
+      const T* vr = sV + l31 * 64 + 4 * hi;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        V4 lo = *reinterpret_cast<const V4*>(vr + t * 32 * VT_LDP);
-        V4 hi4 = *reinterpret_cast<const V4*>(vr + t * 32 * VT_LDP + 8);
+        V4 lo = *reinterpret_cast<const V4*>(vr + t * 32 * 64 + ((s0 ^ skey) << 3));
+        V4 hi4 = *reinterpret_cast<const V4*>(vr + t * 32 * 64 + (((s0 + 1) ^ skey) << 3));
         V8 vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
@@ -191,17 +203,27 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     }
   };
 
+  const T* kb0 = reinterpret_cast<const T*>(p.k0) + (long)b * p.k0_bs + (long)h * HD;
+  const T* vb0 = reinterpret_cast<const T*>(p.vt0) + (long)b * p.vt0_bs + (long)h * HD * p.vt0_ld;
+  const T* kb1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + (long)h * HD;
+  const T* vb1 = reinterpret_cast<const T*>(p.vt1) + (long)b * p.vt1_bs + (long)h * HD * p.vt1_ld;
+
   // ---------------- segment 0: online softmax over len0 keys
   const int nt0 = (p.len0 + KV - 1) / KV;
-  load_regs(p.k0, p.k0_ld, p.k0_bs, p.vt0, p.vt0_ld, p.vt0_bs, p.len0, 0);
+  issue(kb0, p.k0_ld, vb0, p.vt0_ld, p.len0, 0, 0);
   for (int t = 0; t < nt0; ++t) {
-    __syncthreads();
-    store_lds();
-    __syncthreads();
-    if (t + 1 < nt0) load_regs(p.k0, p.k0_ld, p.k0_bs, p.vt0, p.vt0_ld, p.vt0_bs, p.len0, (t + 1) * KV);
-    else if (p.len1 > 0) load_regs(p.k1, p.k1_ld, p.k1_bs, p.vt1, p.vt1_ld, p.vt1_bs, p.len1, 0);
+    const int st = t & 1, kv0 = t * KV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kv0 + KV > p.len0 && ((p.len0 - kv0) & 7)) {
+      fixup_v(p.len0 - kv0, st);
+      __syncthreads();
+    }
+    if (t + 1 < nt0) issue(kb0, p.k0_ld, vb0, p.vt0_ld, p.len0, kv0 + KV, st ^ 1);
+    else if (p.len1 > 0) issue(kb1, p.k1_ld, vb1, p.vt1_ld, p.len1, 0, st ^ 1);
+    const T* sK = sbase + st * STAGE;
     f32x16 s[2];
-    scores(s, p.len0, t * KV);
+    scores(s, sK, p.len0, kv0);
     // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
     // v_exp_f32 directly (__builtin_amdgcn_exp2f): arguments are <= 0, results in (0, 1], exp2(-inf) = 0 — none of
     // exp2f()'s denormal-range rescaling (v_ldexp + compares + selects per element) is needed.
@@ -215,9 +237,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc));
         s[kvt][r] = e;
-        ps += e;
+        if (!ONES) ps += e;
       }
-    l_run = l_run * alpha + ps;
+    if (!ONES) l_run = l_run * alpha + ps;
     // exact skip of the O rescale: when no lane of the wave raised its running max, alpha == 1 everywhere
     // (after the first few tiles this is the common case; it saves 32 accumulator reads + muls + writes per tile)
     if (__any(m_new > m_run)) {
@@ -227,10 +249,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
     }
     m_run = m_new;
-    pv(s);
+    pv(s, sK + K_ELEMS);
   }
   {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (ONES) {
+      // accumulator row DV-1 = tile DT-1, register 15 of the lanes with hi = 1
+      const float c = hi ? o[DT - 1][15] : 0.f;
+      l_tot = c + __shfl_xor(c, 32, 64);
+    } else {
+      l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.f / l_tot;
 #pragma unroll
     for (int t2 = 0; t2 < DT; ++t2)
@@ -240,11 +269,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 
   // ---------------- segment 1 (single tile, own softmax), folded in with weight w1 / l1
   if (p.len1 > 0) {
-    __syncthreads();
-    store_lds();
-    __syncthreads();
+    const int st = nt0 & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (p.len1 < KV && (p.len1 & 7)) {
+      fixup_v(p.len1, st);
+      __syncthreads();
+    }
+    const T* sK = sbase + st * STAGE;
     f32x16 s[2];
-    scores(s, p.len1, 0);
+    scores(s, sK, p.len1, 0);
     const float mc1 = tile_max(s) * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
@@ -261,7 +295,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kvt][r] *= f;
-    pv(s);
+    pv(s, sK + K_ELEMS);
   }
 
   // ---------------- store: O^T regs -> out[b, q, h*HD + d], 4 consecutive d per 8-byte store
@@ -282,28 +316,33 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
   }
 }
 
-template <typename T, int DPAD, int DV>
+template <typename T, int DPAD, int DV, bool ONES>
 int launch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
-  const size_t lds = ((size_t)KV * (DPAD + 8) + (size_t)DV * VT_LDP) * sizeof(T);
+  constexpr int NP = (DPAD + 63) / 64;
+  const size_t lds = (size_t)2 * (NP * 64 * 64 + DV * 64) * sizeof(T);
   AttnParams pp = p;
   pp.n_qblk = (d->n_q + 127) / 128;
   dim3 grid((unsigned)(pp.n_qblk * d->heads * d->batch));
-  hipLaunchKernelGGL((attention_kernel<T, DPAD, DV>), grid, dim3(256), lds, st, pp);
+  auto k = attention_kernel<T, DPAD, DV, ONES>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, pp);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }
 
 template <typename T>
 int dispatch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
+  // ONES variants need a spare V^T row (DV > head dim): 40 -> (48, 64), 80 -> (80, 96), <= 16 -> (16, 32)
   const int hd = d->head_dim;
-  if (hd <= 16) return launch_attn<T, 16, 32>(d, p, st);
-  if (hd <= 32) return launch_attn<T, 32, 32>(d, p, st);
-  if (hd <= 48) return launch_attn<T, 48, 64>(d, p, st);
-  if (hd <= 64) return launch_attn<T, 64, 64>(d, p, st);
-  if (hd <= 80) return launch_attn<T, 80, 96>(d, p, st);
-  if (hd <= 96) return launch_attn<T, 96, 96>(d, p, st);
-  if (hd <= 128) return launch_attn<T, 128, 128>(d, p, st);
-  return launch_attn<T, 160, 160>(d, p, st);
+  if (hd <= 16) return launch_attn<T, 16, 32, true>(d, p, st);
+  if (hd <= 32) return launch_attn<T, 32, 32, false>(d, p, st);
+  if (hd <= 48) return launch_attn<T, 48, 64, true>(d, p, st);
+  if (hd <= 64) return launch_attn<T, 64, 64, false>(d, p, st);
+  if (hd <= 80) return launch_attn<T, 80, 96, true>(d, p, st);
+  if (hd <= 96) return launch_attn<T, 96, 96, false>(d, p, st);
+  if (hd <= 128) return launch_attn<T, 128, 128, false>(d, p, st);
+  return launch_attn<T, 160, 160, false>(d, p, st);
 }
 
 // ---- attention-probability export (save_attn_to_dict side channel): one wave per query row --------------
