@@ -251,6 +251,166 @@ inline int grid_for(long n, int per_thread = 1) {
   return (int)b;
 }
 
+// ---- fast paths for the UNet's two thin convolutions (the generic kernels above stay as the fallback) -----------
+// conv_in (4 -> 320 at SD-1.5): fp32 weights transposed to [K][cout] in LDS once per (persistent) block; a thread owns
+// 8 consecutive output channels of TWO neighbouring pixels, so one pair of ds_read_b128 weight reads feeds 16 FMAs
+// and the result leaves as one 16-byte store per pixel.  The generic kernel re-read every weight from global memory
+// for every pixel (137 us at 16 x 64 x 64; this one is write-bandwidth bound).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_fast_kernel(const void* sample, int src_dtype, int batch, int cin, int h, int w,
+                                                           const T* weight, const T* bias, int cout, T* out, int groups) {
+  typedef typename Vec<T>::v8 V8;
+  extern __shared__ float cin_smem[];
+  const int K = 9 * cin;
+  float* sw = cin_smem;                  // [K][cout]
+  float* patch = sw + K * cout;          // [groups * 2][K]
+  const int tid = threadIdx.x, G = cout >> 3;
+  for (int i = tid; i < K * cout; i += blockDim.x) {
+    const int n = i / K, k = i - n * K;
+    sw[k * cout + n] = to_f32<T>(weight[i]);
+  }
+  const long npix = (long)batch * h * w;
+  const int ppb = groups * 2;
+  const int g = tid / G, cg = tid - g * G;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (bias != nullptr && g < groups) ? to_f32<T>(bias[cg * 8 + e]) : 0.f;
+  for (long base = (long)blockIdx.x * ppb; base < npix; base += (long)gridDim.x * ppb) {
+    __syncthreads();
+    for (int i = tid; i < ppb * K; i += blockDim.x) {
+      const int lp = i / K, k = i - lp * K;
+      const long pix = base + lp;
+      float v = 0.f;
+      if (pix < npix) {
+        const int tap = k / cin, c = k - tap * cin;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int b = (int)(pix / (h * w));
+        const int r = (int)(pix - (long)b * h * w);
+        const int y = r / w + ky - 1, x = r % w + kx - 1;
+        if (y >= 0 && y < h && x >= 0 && x < w) v = load_src(sample, src_dtype, (((long)b * cin + c) * h + y) * w + x);
+      }
+      patch[i] = v;
+    }
+    __syncthreads();
+    if (g >= groups) continue;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0[e] = bias8[e]; a1[e] = bias8[e]; }
+    const float* p0 = patch + (2 * g) * K;
+    const float* p1 = p0 + K;
+    const float* wp = sw + cg * 8;
+    for (int k = 0; k < K; ++k) {
+      const f32x4 wlo = *reinterpret_cast<const f32x4*>(wp + k * cout);
+      const f32x4 whi = *reinterpret_cast<const f32x4*>(wp + k * cout + 4);
+      const float x0 = p0[k], x1 = p1[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = __builtin_fmaf(x0, wlo[e], a0[e]);
+        a0[4 + e] = __builtin_fmaf(x0, whi[e], a0[4 + e]);
+        a1[e] = __builtin_fmaf(x1, wlo[e], a1[e]);
+        a1[4 + e] = __builtin_fmaf(x1, whi[e], a1[4 + e]);
+      }
+    }
+    const long pix0 = base + 2 * g;
+    V8 o;
+    if (pix0 < npix) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(a0[e]);
+      *reinterpret_cast<V8*>(out + pix0 * cout + cg * 8) = o;
+    }
+    if (pix0 + 1 < npix) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(a1[e]);
+      *reinterpret_cast<V8*>(out + (pix0 + 1) * cout + cg * 8) = o;
+    }
+  }
+}
+
+__device__ __forceinline__ float dot8_acc(bf16x8 a, bf16x8 b, float acc) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x2 x = {a[2 * i], a[2 * i + 1]}, y = {b[2 * i], b[2 * i + 1]};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(x, y, acc, false);
+  }
+  return acc;
+}
+__device__ __forceinline__ float dot8_acc(f16x8 a, f16x8 b, float acc) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2 x = {a[2 * i], a[2 * i + 1]}, y = {b[2 * i], b[2 * i + 1]};
+    acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+  }
+  return acc;
+}
+
+// conv_out (320 -> 4): the whole [cout][9*cin] weight lives in LDS; a wave walks pixel PAIRS, its lanes split the 9*cin
+// reduction in 16-byte chunks and multiply with v_dot2 (no bf16 -> fp32 conversions), one weight read feeds both
+// pixels.  (The generic kernel: 274 us, every lane re-loading weights from global memory per chunk.)
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv_out_fast_kernel(const T* x, int batch, int cin, int h, int w, const T* weight,
+                                                            const T* bias, int cout, void* out, int out_f32) {
+  typedef typename Vec<T>::v8 V8;
+  extern __shared__ __attribute__((aligned(16))) char cout_smem[];
+  T* sw = reinterpret_cast<T*>(cout_smem);
+  const int K = 9 * cin, c8 = cin >> 3;
+  for (int i = threadIdx.x; i < cout * K / 8; i += blockDim.x)
+    reinterpret_cast<V8*>(sw)[i] = reinterpret_cast<const V8*>(weight)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long npix = (long)batch * h * w, npair = (npix + 1) >> 1;
+  const long nw = (long)gridDim.x * 4;
+  V8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = from_f32<T>(0.f);
+  for (long pp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pp < npair; pp += nw) {
+    const long pix0 = 2 * pp, pix1 = pix0 + 1;
+    const bool v1 = pix1 < npix;
+    const int b0 = (int)(pix0 / (h * w)), r0 = (int)(pix0 - (long)b0 * h * w);
+    const int y0 = r0 / w, x0 = r0 - y0 * w;
+    const long q1 = v1 ? pix1 : pix0;
+    const int b1 = (int)(q1 / (h * w)), r1 = (int)(q1 - (long)b1 * h * w);
+    const int y1 = r1 / w, x1 = r1 - y1 * w;
+    float acc0[COUT], acc1[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) { acc0[n] = 0.f; acc1[n] = 0.f; }
+    for (int i = lane; i < 9 * c8; i += 64) {
+      const int tap = i / c8, c = (i - tap * c8) << 3;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int ya = y0 + dy, xa = x0 + dx, yb = y1 + dy, xb = x1 + dx;
+      V8 va = zero8, vb = zero8;
+      if (ya >= 0 && ya < h && xa >= 0 && xa < w) va = *reinterpret_cast<const V8*>(x + (((long)b0 * h + ya) * w + xa) * cin + c);
+      if (v1 && yb >= 0 && yb < h && xb >= 0 && xb < w) vb = *reinterpret_cast<const V8*>(x + (((long)b1 * h + yb) * w + xb) * cin + c);
+#pragma unroll
+      for (int n = 0; n < COUT; ++n) {
+        if (n < cout) {
+          const V8 wv = *reinterpret_cast<const V8*>(sw + n * K + tap * cin + c);
+          acc0[n] = dot8_acc(va, wv, acc0[n]);
+          acc1[n] = dot8_acc(vb, wv, acc1[n]);
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) {
+      if (n >= cout) continue;
+      const float s0 = wave_sum(acc0[n]), s1 = wave_sum(acc1[n]);
+      if (lane == 0) {
+        const float bn = bias ? to_f32<T>(bias[n]) : 0.f;
+        const long o0 = (((long)b0 * cout + n) * h + y0) * w + x0;
+        const long o1 = (((long)b1 * cout + n) * h + y1) * w + x1;
+        if (out_f32) {
+          reinterpret_cast<float*>(out)[o0] = s0 + bn;
+          if (v1) reinterpret_cast<float*>(out)[o1] = s1 + bn;
+        } else {
+          reinterpret_cast<T*>(out)[o0] = from_f32<T>(s0 + bn);
+          if (v1) reinterpret_cast<T*>(out)[o1] = from_f32<T>(s1 + bn);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, NAME, GRID, BLOCK, LDS, ...)                                            \
@@ -296,6 +456,24 @@ extern "C" int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, 
   TG_CHECK(src_dtype >= 0 && src_dtype <= 2 && batch > 0 && cin > 0 && cin <= 16 && cout > 0, TG_ERR_ARG, "tg_conv_in: bad shape");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long npix = (long)batch * h * w;
+  {
+    // fast path: 8 output channels x 2 pixels per thread, fp32 weights resident in LDS
+    const int K = 9 * cin, G = cout / 8;
+    const int groups = G > 0 ? 256 / G : 0;
+    if (cout % 8 == 0 && groups >= 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      const size_t lds = ((size_t)K * cout + (size_t)groups * 2 * K) * sizeof(float);
+      if (lds <= 64 * 1024) {
+        long nb = (npix + groups * 2 - 1) / (groups * 2);
+        if (nb > 512) nb = 512;
+        if (dtype == TG_BF16)
+          hipLaunchKernelGGL(conv_in_fast_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), lds, st, sample, src_dtype, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, (bf16_t*)out, groups);
+        else
+          hipLaunchKernelGGL(conv_in_fast_kernel<f16_t>, dim3((unsigned)nb), dim3(256), lds, st, sample, src_dtype, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, (f16_t*)out, groups);
+        TG_LAUNCH_CHECK();
+        return TG_OK;
+      }
+    }
+  }
   const int ppb = 4;
   const size_t lds = (size_t)ppb * 9 * cin * sizeof(float);
   dim3 grid((unsigned)((npix + ppb - 1) / ppb));
@@ -313,6 +491,23 @@ extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t 
   TG_CHECK(batch > 0 && cin % 8 == 0 && cout > 0 && cout <= 8, TG_ERR_ARG, "tg_conv_out: bad shape cin=%d cout=%d", cin, cout);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long npix = (long)batch * h * w;
+  {
+    const size_t lds = (size_t)cout * 9 * cin * 2;
+    if (lds <= 64 * 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(weight) & 15) == 0) {
+      long nb = ((npix + 1) / 2 + 3) / 4;
+      if (nb > 1024) nb = 1024;
+      const dim3 g((unsigned)nb);
+      if (dtype == TG_BF16) {
+        if (cout <= 4) hipLaunchKernelGGL((conv_out_fast_kernel<bf16_t, 4>), g, dim3(256), lds, st, (const bf16_t*)x, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
+        else hipLaunchKernelGGL((conv_out_fast_kernel<bf16_t, 8>), g, dim3(256), lds, st, (const bf16_t*)x, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
+      } else {
+        if (cout <= 4) hipLaunchKernelGGL((conv_out_fast_kernel<f16_t, 4>), g, dim3(256), lds, st, (const f16_t*)x, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
+        else hipLaunchKernelGGL((conv_out_fast_kernel<f16_t, 8>), g, dim3(256), lds, st, (const f16_t*)x, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
+      }
+      TG_LAUNCH_CHECK();
+      return TG_OK;
+    }
+  }
   dim3 grid((unsigned)((npix + 3) / 4));
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(conv_out_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
