@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtheatergen_hip.so")
+# THEATERGEN_HIP_LIB: point at another build of the same C ABI (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2

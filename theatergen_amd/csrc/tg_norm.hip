@@ -1,9 +1,9 @@
 // GroupNorm (+SiLU) over token-major activations and LayerNorm per token row — HBM-bound kernels.
 // 16-byte (8 x bf16/f16) accesses per lane, channels contiguous -> fully coalesced rows.
 //
-// GroupNorm is three launches: (1) per-slab partial sum / sum-of-squares per (batch, group) — no atomics,
-// deterministic; (2) finalize mean / rstd per (batch, group) in fp64; (3) apply gamma/beta (+SiLU) and write
-// the normalised activations once.  The input may be the channel concat of two tensors (skip connection):
+// GroupNorm is two launches: (1) per-slab partial sum / sum-of-squares per (batch, group) — no atomics,
+// deterministic; (2) every block folds the partials of its batch item to mean / rstd in fp64 (fixed order), applies
+// gamma/beta (+SiLU) and writes the normalised activations once.  The input may be the channel concat of two tensors (skip connection):
 // groups may straddle the boundary (e.g. 1280 + 640 channels -> 60 channels per group).
 #include "tg_common.h"
 
@@ -89,11 +89,13 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
   }
 }
 
-// 256 threads per batch item: thread (part = t / 32, g = t % 32 + 32 * k) sums every 8th slab partial in fp64, the 8
-// parts are folded in a fixed order through LDS -> deterministic, and ~8x shorter than one thread per group.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(GnParams p) {
-  __shared__ double sh[8][64][2];
-  const int b = blockIdx.x;
+// mean / rstd of every (batch b, group) from the slab partials, by ALL 256 threads of the calling block: thread
+// (part = t / 32, g = t % 32 + 32 * k) sums every 8th slab partial in fp64, the 8 parts are folded in a fixed order
+// through LDS -> deterministic.  Runs as the prologue of the apply kernel (each block re-derives the 32 group
+// statistics of its batch item from <= 16 KB of L2-resident partials) instead of as a launch of its own: one launch
+// and ~5 us less per GroupNorm, 61 GroupNorms per UNet call.
+__device__ __forceinline__ void gn_block_stats(const GnParams& p, int b, float* s_stats /* [groups][2] in LDS */) {
+  __shared__ double sh[8][32][2];
   const int C = p.c0 + p.c1;
   const double cnt = (double)p.hw * (C / p.groups);
   const int part = threadIdx.x >> 5, gl = threadIdx.x & 31;
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnParams p) {
       const double mean = s / cnt;
       double var = q / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
-      p.stats[((long)b * p.groups + g) * 2] = (float)mean;
-      p.stats[((long)b * p.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+      s_stats[g * 2] = (float)mean;
+      s_stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     __syncthreads();
   }
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
   const long p_begin = (long)blk * per;
   long p_end = p_begin + per;
   if (p_end > p.hw) p_end = p.hw;
+  extern __shared__ float s_stats[];   // [groups][2]
+  gn_block_stats(p, b, s_stats);
   const int tx = threadIdx.x % p.cx;
   const int ty = threadIdx.x / p.cx;
   if (ty >= p.ry) return;
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
     for (int j = 0; j < 8; ++j) {
       const int ch = c * 8 + j;
       const int g = ch / cpg;
-      const float mean = p.stats[((long)b * p.groups + g) * 2];
-      const float rstd = p.stats[((long)b * p.groups + g) * 2 + 1];
+      const float mean = s_stats[g * 2];
+      const float rstd = s_stats[g * 2 + 1];
       const float ga = gam ? to_f32<T>(gam[ch]) : 1.f;
       const float be = bet ? to_f32<T>(bet[ch]) : 0.f;
       a[j] = rstd * ga;
@@ -275,10 +279,9 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
   if (dtype == TG_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(gn_partial_kernel<f16_t>, grid, dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, st, p);
-  TG_LAUNCH_CHECK();
-  if (dtype == TG_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, st, p);
+  const size_t lds_stats = (size_t)groups * 2 * sizeof(float);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), lds_stats, st, p);
+  else hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), lds_stats, st, p);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }
