@@ -112,7 +112,10 @@ __device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
 // Whole-wave-tile epilogue.  All bias / per-batch vector / residual loads of one 32-token row block are issued
 // back to back BEFORE any of them is consumed (one latency exposure per row block instead of one per 4 outputs),
 // then activation / scale / 8-byte stores.  lane&31 = token row, 4 consecutive registers = 4 consecutive channels.
-template <typename T, int TM, int TN>
+// EPI: 0 = linear epilogue only (bias / per-batch vector / residual / scale: every conv and most projections),
+// 1 = generic (activations, GEGLU), 2 = GEGLU only.  The activation code (erf polynomials, exp) is ~80 % of the
+// kernel's instructions; leaving it out of the kernels that never run it is worth ~6 % at K = 320 (code size).
+template <typename T, int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int split) {
   typedef typename Vec<T>::v4 V4;
   if (p.splits > 1) {
@@ -132,8 +135,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
     }
     return;
   }
-  if constexpr (TN == 2) {
-    if (p.geglu) {
+  if constexpr (TN == 2 && EPI != 0) {
+    if (EPI == 2 || p.geglu) {
       // fused GEGLU (models/attention.py:337-338): W rows are packed [a(32) ; gate(32)] per 64-column group, so this
       // wave holds a[c] in tile j = 0 and gate[c] in tile j = 1 for the same 32 channels, in the same lane/register:
       // out[m, c] = (a + bias_a) * gelu(gate + bias_g), written to a [M, N/2] tensor — the [M, N] pre-activation
@@ -209,12 +212,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[e] = acc[i][j][4 * g + e] + to_f32<T>(bias4[j][g][e]) + to_f32<T>(add4[j][g][e]) + to_f32<T>(res4[j][g][e]);
-        if (p.act == TG_ACT_SILU) {
+        if constexpr (EPI == 1) {
+          if (p.act == TG_ACT_SILU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-        } else if (p.act == TG_ACT_GELU) {
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (p.act == TG_ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+          }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
@@ -245,20 +250,20 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // unchanged (fp32: acc + bias + bvec + res, activation, scale, one rounding), so results are bit-identical to the
 // direct epilogue.  Columns that go to the transposed output (out_t, lane = token is already coalesced there) and
 // split-K partials keep the direct path.
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
                                                   float* scr, int split) {
   typedef typename Vec<T>::v4 V4;
   typedef typename Vec<T>::v8 V8;
   const int l31 = lane & 31, hi = lane >> 5;
   if (p.splits > 1 || !p.epi_lds || (p.n_split > 0 && n_wave >= p.n_split)) {
-    epilogue_tile<T, TM, TN>(p, acc, m_wave + l31, n_wave + 4 * hi, split);
+    epilogue_tile<T, TM, TN, EPI>(p, acc, m_wave + l31, n_wave + 4 * hi, split);
     return;
   }
   T* outp = reinterpret_cast<T*>(p.out);
   const T* biasp = reinterpret_cast<const T*>(p.bias);
-  if constexpr (TN == 2) {
-    if (p.geglu) {
+  if constexpr (TN == 2 && EPI != 0) {
+    if (EPI == 2 || p.geglu) {
       constexpr int RS = 36;
       const int c = lane & 3, r0 = lane >> 2;       // 4 pieces x 16 rows per pass over the [32][32] result
 #pragma unroll
@@ -375,12 +380,14 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
       }
-      if (p.act == TG_ACT_SILU) {
+      if constexpr (EPI == 1) {
+        if (p.act == TG_ACT_SILU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-      } else if (p.act == TG_ACT_GELU) {
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (p.act == TG_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+        }
       }
       if (!unit_scale) {
 #pragma unroll
@@ -405,7 +412,7 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 // read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
 __device__ __attribute__((aligned(256))) unsigned char tg_zero_page[256];
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
@@ -598,8 +605,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
     }
   }
 
-  epilogue_tile_lds<T, TM, TN>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                              reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), split);
+  epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                                   reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), split);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -770,8 +777,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     tap = ntap;
   }
 
-  epilogue_tile_lds<T, TM, TN>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                              reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), 0);
+  epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                                 reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), 0);
 }
 
 template <typename T, int WI, bool UPS>
@@ -787,7 +794,7 @@ int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || d->force_tile != 0 || d->force_split_k > 1) return false;
+  if (d->mode != 1 || d->stride != 1 || d->force_tile != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return false;
   if (d->out_w != 16 && d->out_w != 32 && d->out_w != 64) return false;
   const int th = 128 / d->out_w;
   if (d->out_h % th != 0 || d->M % 128 != 0) return false;
@@ -851,20 +858,29 @@ Plan make_plan(const tg_gemm_desc* d) {
   return Plan{t, s, kps, tm, tn};
 }
 
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int STAGES, int BKT, int EPI>
+void launch_glds(const GemmParams& p, dim3 grid, size_t lds, hipStream_t st) {
+  auto k = gemm_glds_kernel<T, BM, BN, WM, WN, CONV, STAGES, BKT, EPI>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKT = 64>
 int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
   const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(T);
   dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), 1, (unsigned)pl.splits);
+  // epilogue kind: 0 = linear only, 1 = generic (activation / GEGLU on any tile), 2 = GEGLU on the default plain tile
+  constexpr bool kMainTile = BM == 128 && BN == 128 && STAGES == 2;
+  const int epi = d->geglu ? ((kMainTile && d->mode != 1) ? 2 : 1) : (d->act == TG_ACT_NONE ? 0 : 1);
   if (d->mode == 1) {
-    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, true, STAGES, BKT>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
+    if (epi == 0) launch_glds<T, BM, BN, WM, WN, true, STAGES, BKT, 0>(p, grid, lds, st);
+    else launch_glds<T, BM, BN, WM, WN, true, STAGES, BKT, 1>(p, grid, lds, st);
   } else {
-    auto k = gemm_glds_kernel<T, BM, BN, WM, WN, false, STAGES, BKT>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, st, p);
+    if (epi == 0) launch_glds<T, BM, BN, WM, WN, false, STAGES, BKT, 0>(p, grid, lds, st);
+    else if (epi == 2) {
+      if constexpr (kMainTile) launch_glds<T, BM, BN, WM, WN, false, STAGES, BKT, 2>(p, grid, lds, st);
+    } else launch_glds<T, BM, BN, WM, WN, false, STAGES, BKT, 1>(p, grid, lds, st);
   }
   TG_LAUNCH_CHECK();
   if (pl.splits > 1) {
