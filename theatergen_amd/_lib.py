@@ -45,7 +45,7 @@ SIGNATURES = {
     "tg_last_error": (C.c_char_p, []),
     "tg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "tg_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
-    "tg_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp]),
+    "tg_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "tg_attention": (i32, [C.POINTER(AttnDesc), vp]),
     "tg_attn_probs": (i32, [i32, i32, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, f32, vp, i32, vp, vp]),
     "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),

@@ -45,12 +45,24 @@ struct GemmParams {
   void* out_t;
   long ldt;
   float* ws;
-  int splits;
+  int full_tiles;   // tiles [0, full_tiles) are computed whole; each later tile is cut into tail_s K-ranges
+  int tail_s;
+  int tile_bm, tile_bn;
   int kt_per_split;
   int tiles_n;
   long a_rpb, a_bs;
   int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
 };
+
+struct TileCfg { int bm, bn, bk; };
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}};
+constexpr int kNumTiles = 5;  // id 4 = 128x128 with 3 stages (forced only)
+// force_tile: 1 + tile id (0 = heuristic)
+
+// tile: kTiles id; the first `full` tiles are computed whole, each of the `tail` last tiles is cut into `s` K-ranges of
+// `kps` units (K-tiles, or 64-channel chunks for the halo kernel); grid = full + tail * s work items.
+struct Plan { int tile; bool halo; int full, tail, s, kps; long tiles_m, tiles_n; };
+
 
 template <typename T>
 __device__ __forceinline__ void epilogue_store4(const GemmParams& p, long m, long n4, float v0, float v1, float v2, float v3) {
@@ -116,21 +128,23 @@ __device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
 // 1 = generic (activations, GEGLU), 2 = GEGLU only.  The activation code (erf polynomials, exp) is ~80 % of the
 // kernel's instructions; leaving it out of the kernels that never run it is worth ~6 % at K = 320 (code size).
 template <typename T, int TM, int TN, int EPI>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int split) {
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int part,
+                                              long pm0, long pn0) {
   typedef typename Vec<T>::v4 V4;
-  if (p.splits > 1) {
+  if (part >= 0) {
+    // K-split tail tile: fp32 partial in tile-local layout ws[part][tile_bm][tile_bn]; the reduce kernel sums the
+    // tail_s partials of the tile in a fixed order and applies the epilogue
+    float* wsp = p.ws + (long)part * p.tile_bm * p.tile_bn;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const long m = m_base + 32 * i;
+      const long lr = m_base + 32 * i - pm0;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const long n4 = n_base + 32 * j + 8 * g;
-          if (m < p.M && n4 < p.N) {
-            f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(p.ws + ((long)split * p.M + m) * p.N + n4) = o;
-          }
+          const long lc = n_base + 32 * j + 8 * g - pn0;
+          f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(wsp + lr * p.tile_bn + lc) = o;
         }
     }
     return;
@@ -252,12 +266,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // split-K partials keep the direct path.
 template <typename T, int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr, int split) {
+                                                  float* scr, int part, long pm0, long pn0) {
   typedef typename Vec<T>::v4 V4;
   typedef typename Vec<T>::v8 V8;
   const int l31 = lane & 31, hi = lane >> 5;
-  if (p.splits > 1 || !p.epi_lds || (p.n_split > 0 && n_wave >= p.n_split)) {
-    epilogue_tile<T, TM, TN, EPI>(p, acc, m_wave + l31, n_wave + 4 * hi, split);
+  if (part >= 0 || !p.epi_lds || (p.n_split > 0 && n_wave >= p.n_split)) {
+    epilogue_tile<T, TM, TN, EPI>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0);
     return;
   }
   T* outp = reinterpret_cast<T*>(p.out);
@@ -437,15 +451,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
-  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
+  // work item -> (tile, K range): the first full_tiles blocks compute whole tiles (XCD-chunked order); the tail tiles
+  // are cut tail_s ways along K so that the last, partially filled round of the grid is spread over all CUs
+  int lbid, split = 0, part = -1;
+  if ((int)blockIdx.x < p.full_tiles) {
+    lbid = xcd_chunked_block_id(blockIdx.x, p.full_tiles);
+  } else {
+    const int j = (int)blockIdx.x - p.full_tiles;
+    lbid = p.full_tiles + j / p.tail_s;
+    split = j - (j / p.tail_s) * p.tail_s;
+    part = j;
+  }
   const int tile_n = lbid % p.tiles_n;
   const int tile_m = lbid / p.tiles_n;
   const long m0 = (long)tile_m * BM;
   const long n0 = (long)tile_n * BN;
-  const int split = blockIdx.z;
   const int nkt_total = (int)((p.K + BKT - 1) / BKT);
-  const int kt_begin = split * p.kt_per_split;
-  int kt_end = kt_begin + p.kt_per_split;
+  const int kt_begin = part >= 0 ? split * p.kt_per_split : 0;
+  int kt_end = part >= 0 ? kt_begin + p.kt_per_split : nkt_total;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
 
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   }
 
   epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                   reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), split);
+                                   reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -637,7 +660,15 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
-  const int lbid = xcd_chunked_block_id(blockIdx.x, gridDim.x);
+  int lbid, split = 0, part = -1;     // same work-item scheme as gemm_glds_kernel; the K split runs over channel chunks
+  if ((int)blockIdx.x < p.full_tiles) {
+    lbid = xcd_chunked_block_id(blockIdx.x, p.full_tiles);
+  } else {
+    const int j = (int)blockIdx.x - p.full_tiles;
+    lbid = p.full_tiles + j / p.tail_s;
+    split = j - (j / p.tail_s) * p.tail_s;
+    part = j;
+  }
   const int tile_n = lbid % p.tiles_n;
   const int tile_m = lbid / p.tiles_n;
   const long m0 = (long)tile_m * BM;
@@ -723,13 +754,18 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     ppx[i] = pm % WI;
   }
 
-  issue_slab(0);
-  issue_w(0, 0, 0);
+  // channel chunks of this work item (kt_per_split counts chunks here)
+  const int c_begin = part >= 0 ? split * p.kt_per_split : 0;
+  int c_end = part >= 0 ? c_begin + p.kt_per_split : nchunks;
+  if (c_end > nchunks) c_end = nchunks;
+
+  issue_slab(c_begin);
+  issue_w(c_begin, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  const int nkt = nchunks * 9;
-  int cc = 0, tap = 0;
+  const int nkt = (c_end - c_begin) * 9;
+  int cc = c_begin, tap = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -778,19 +814,35 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   }
 
   epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                 reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), 0);
+                                 reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
+}
+
+template <typename T>
+__global__ void splitk_reduce_kernel(GemmParams p);
+
+inline int64_t plan_workspace_bytes(const Plan& pl) {
+  return pl.s > 1 ? (int64_t)pl.tail * pl.s * kTiles[pl.tile].bm * kTiles[pl.tile].bn * 4 : 0;
+}
+
+template <typename T>
+int launch_reduce(const GemmParams& p, const Plan& pl, hipStream_t st) {
+  if (pl.s > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)pl.tail * 8), dim3(256), 0, st, p);
+    TG_LAUNCH_CHECK();
+  }
+  return TG_OK;
 }
 
 template <typename T, int WI, bool UPS>
-int launch_halo(const GemmParams& p, long tiles, hipStream_t st) {
+int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
   constexpr int TH = 128 / WI, SLAB = UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2), NI = (SLAB + 7) / 8;
   const size_t lds = ((size_t)NI * 8 * BK + 2 * 128 * BK) * sizeof(T);
   auto k = conv_halo_kernel<T, WI, UPS>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)(pl.full + pl.tail * pl.s)), dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();
-  return TG_OK;
+  return launch_reduce<T>(p, pl, st);
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
@@ -804,58 +856,75 @@ inline bool halo_eligible(const tg_gemm_desc* d) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
-  const long n4s = p.N / 4;
-  const long total = p.M * n4s;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const long m = idx / n4s;
-    const long n4 = (idx - m * n4s) * 4;
+  // 8 blocks per tail tile (row slices): sum its tail_s fp32 partials in split order, then the regular epilogue
+  const int t = blockIdx.x >> 3, slice = blockIdx.x & 7;
+  const int lbid = p.full_tiles + t;
+  const long m0 = (long)(lbid / p.tiles_n) * p.tile_bm, n0 = (long)(lbid % p.tiles_n) * p.tile_bn;
+  const int q4 = p.tile_bn / 4;
+  const int rows = p.tile_bm / 8;
+  const long tile_elems = (long)p.tile_bm * p.tile_bn;
+  const float* base = p.ws + (long)t * p.tail_s * tile_elems;
+  for (int q = threadIdx.x; q < rows * q4; q += blockDim.x) {
+    const int lr = slice * rows + q / q4, lc = (q % q4) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f32x4*>(p.ws + ((long)z * p.M + m) * p.N + n4);
-    epilogue_store4<T>(p, m, n4, s[0], s[1], s[2], s[3]);
+    for (int z = 0; z < p.tail_s; ++z) s += *reinterpret_cast<const f32x4*>(base + z * tile_elems + (long)lr * p.tile_bn + lc);
+    epilogue_store4<T>(p, m0 + lr, n0 + lc, s[0], s[1], s[2], s[3]);
   }
 }
 
-struct TileCfg { int bm, bn, bk; };
-const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}};
-constexpr int kNumTiles = 5;  // id 4 = 128x128 with 3 stages (forced only)
-// force_tile: 1 + tile id (0 = heuristic)
 
-struct Plan { int tile; int splits; int kt_per_split; long tiles_m, tiles_n; };
+inline bool halo_eligible(const tg_gemm_desc* d);
 
 Plan make_plan(const tg_gemm_desc* d) {
-  // Measured on MI355X over the UNet's shapes (scripts/dev_gemm_bench.py): the 128x128 tile with 2 blocks per CU is
-  // the best or within a few % of the best everywhere, including small grids; every larger tile loses occupancy and
-  // split-K (fp32 partials + a reduce launch) never paid off, so it is only taken when forced (tests) — except for
-  // skinny problems where one dimension is <= 64.
+  // Tile: measured on MI355X over the UNet's shapes (scripts/dev_gemm_bench.py) the 128x128 tile with 2 blocks per CU is
+  // the best or within a few % of the best everywhere; skinny problems (one dimension <= 64) take the matching tile.
   const long M = d->M, N = d->N, K = d->K;
+  const bool halo = halo_eligible(d);
   int t = 0;
-  if (N <= 64 && M > 64) t = 2;        // 128 x 64
-  else if (M <= 64 && N > 64) t = 3;   // 64 x 128
-  else if (M <= 64 && N <= 64) t = 1;  // 64 x 64
-  const int forced = d->force_tile & 15;
-  if (forced > 0) t = forced - 1;
-  if (t >= kNumTiles) t = 0;
-  const int bk = kTiles[t].bk;
-  const int nkt = (int)((K + bk - 1) / bk);
-  // Split-K only for the weight-streaming layers (few output tiles, very long K: the 8x8 / 16x16 ResBlock convs stream
-  // 30-60 MB of weights through 80-320 blocks).  In situ (cold L2 / MALL) such a launch is HBM-LATENCY bound with a
-  // 2-deep DMA pipeline per block (measured 140 TF at 80 blocks); more blocks = more loads in flight.
+  if (!halo) {
+    if (N <= 64 && M > 64) t = 2;        // 128 x 64
+    else if (M <= 64 && N > 64) t = 3;   // 64 x 128
+    else if (M <= 64 && N <= 64) t = 1;  // 64 x 64
+    if (d->force_tile > 0) t = d->force_tile - 1;
+    if (t >= kNumTiles || t < 0) t = 0;
+  }
+  const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
+  const long T = tm * tn;
+  // K units that a split may cut at, and the fewest a work item should keep
+  const int units = halo ? (int)((d->c0 + (d->a1 ? d->c1 : 0)) / BK) : (int)((K + kTiles[t].bk - 1) / kTiles[t].bk);
+  const int min_units = halo ? 2 : 8;
+  // Tail split.  The grid runs in rounds of S co-resident blocks (LDS-limited: 2 per CU for the 64 KB tiles).  A last
+  // round that fills only part of the chip (640 tiles on 512 slots: the 32x32 layers; 320 or 80 tiles: 16x16 / 8x8) can
+  // be cut along K so that its work spreads over every CU:
+  //     cost(c) = rounds(c) * (units / c * t_unit + t_fix) + t_reduce(c),   t_reduce = 6 us + 0.065 us per partial tile
+  // against the unsplit tail, which runs ~0.6x as long as a full round when at most one block per CU is left (no
+  // co-resident block to share the matrix pipe / L2 path with).  Constants from scripts/dev_gemm_ksweep.py and
+  // scripts/dev_split_ab.py on MI355X (us; only ratios matter).  In practice this splits the 8x8 weight-streaming
+  // convs (~6 ways: 204 -> 91 us), the K >= 11520 halo convs of the 32x32 / 16x16 levels (-16 .. -20 %) and the
+  // longest-K 8x8 projections; every other layer measured faster unsplit (partials cost more than the idle CUs).
+  long S = 512;
+  if (!halo && t == 1) S = 768;
+  if (!halo && t == 4) S = 256;
+  long full = (T / S) * S, rem = T - full;
   int s = 1;
-  {
-    const long tiles = ((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn);
-    if (!d->geglu && t == 0) {
-      if (tiles <= 160 && nkt >= 48) s = (int)((400 + tiles - 1) / tiles);
-      else if (tiles <= 400 && nkt >= 96) s = 2;
-      if (s > 8) s = 8;
-      while (s > 1 && nkt / s < 8) --s;
+  if (d->force_split_k > 0) {
+    full = 0; rem = T; s = d->force_split_k;
+  } else if (rem > 0 && !d->geglu && units >= 2 * min_units) {
+    const double t_unit = halo ? 9.0 : (d->mode == 1 ? 1.5 : 1.1), t_fix = 6.0;
+    double best = (units * t_unit + t_fix) * (2 * rem <= S ? 0.6 : 1.0);
+    for (int c = 2; c <= 8 && units / c >= min_units; ++c) {
+      const int kps = (units + c - 1) / c;
+      const long rounds = (rem * c + S - 1) / S;
+      const double cost = rounds * (kps * t_unit + t_fix) + 6.0 + 0.065 * (double)(rem * c);
+      if (cost < best * 0.95) { best = cost; s = c; }
     }
   }
-  if (d->force_split_k > 0) s = d->force_split_k;
-  if (s > nkt) s = nkt;
-  int kps = (nkt + s - 1) / s;
-  s = (nkt + kps - 1) / kps;
-  const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
-  return Plan{t, s, kps, tm, tn};
+  if (s > units) s = units;
+  if (s < 1) s = 1;
+  int kps = (units + s - 1) / s;
+  s = (units + kps - 1) / kps;
+  if (s <= 1) { s = 1; full = T; rem = 0; kps = units; }
+  return Plan{t, halo, (int)full, (int)rem, s, kps, tm, tn};
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int STAGES, int BKT, int EPI>
@@ -869,7 +938,7 @@ void launch_glds(const GemmParams& p, dim3 grid, size_t lds, hipStream_t st) {
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int BKT = 64>
 int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t st) {
   const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(T);
-  dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), 1, (unsigned)pl.splits);
+  dim3 grid((unsigned)(pl.full + pl.tail * pl.s));
   // epilogue kind: 0 = linear only, 1 = generic (activation / GEGLU on any tile), 2 = GEGLU on the default plain tile
   constexpr bool kMainTile = BM == 128 && BN == 128 && STAGES == 2;
   const int epi = d->geglu ? ((kMainTile && d->mode != 1) ? 2 : 1) : (d->act == TG_ACT_NONE ? 0 : 1);
@@ -883,14 +952,7 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
     } else launch_glds<T, BM, BN, WM, WN, false, STAGES, BKT, 1>(p, grid, lds, st);
   }
   TG_LAUNCH_CHECK();
-  if (pl.splits > 1) {
-    long total = p.M * (p.N / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, st, p);
-    TG_LAUNCH_CHECK();
-  }
-  return TG_OK;
+  return launch_reduce<T>(p, pl, st);
 }
 
 template <typename T>
@@ -906,7 +968,8 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.res = d->res; p.ldres = d->ldres; p.act = d->act; p.geglu = d->geglu; p.out_scale = d->out_scale;
   p.out = d->out; p.ldc = d->ldc; p.n_split = d->n_split; p.out_t = d->out_t; p.ldt = d->ldt;
   p.ws = reinterpret_cast<float*>(d->workspace);
-  p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; p.tiles_n = (int)pl.tiles_n;
+  p.full_tiles = pl.full; p.tail_s = pl.s; p.kt_per_split = pl.kps; p.tiles_n = (int)pl.tiles_n;
+  p.tile_bm = kTiles[pl.tile].bm; p.tile_bn = kTiles[pl.tile].bn;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -914,23 +977,20 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
-  if (pl.splits > 1 && !halo_eligible(d)) {
-    TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= (int64_t)pl.splits * d->M * d->N * 4, TG_ERR_ARG,
-             "tg_gemm: split-K needs %lld workspace bytes, got %lld", (long long)pl.splits * d->M * d->N * 4,
-             (long long)d->workspace_bytes);
+  {
+    const int64_t need = plan_workspace_bytes(pl);
+    TG_CHECK(need == 0 || (d->workspace != nullptr && d->workspace_bytes >= need), TG_ERR_ARG,
+             "tg_gemm: the K-split tail needs %lld workspace bytes, got %lld", (long long)need, (long long)d->workspace_bytes);
   }
-  if (halo_eligible(d)) {
-    p.splits = 1;
-    p.tiles_n = (int)((d->N + 127) / 128);
-    const long tiles = (d->M / 128) * p.tiles_n;
+  if (pl.halo) {
     if (d->upsample) {
-      if (d->out_w == 64) return launch_halo<T, 64, true>(p, tiles, st);
-      if (d->out_w == 32) return launch_halo<T, 32, true>(p, tiles, st);
-      return launch_halo<T, 16, true>(p, tiles, st);
+      if (d->out_w == 64) return launch_halo<T, 64, true>(p, pl, st);
+      if (d->out_w == 32) return launch_halo<T, 32, true>(p, pl, st);
+      return launch_halo<T, 16, true>(p, pl, st);
     }
-    if (d->out_w == 64) return launch_halo<T, 64, false>(p, tiles, st);
-    if (d->out_w == 32) return launch_halo<T, 32, false>(p, tiles, st);
-    return launch_halo<T, 16, false>(p, tiles, st);
+    if (d->out_w == 64) return launch_halo<T, 64, false>(p, pl, st);
+    if (d->out_w == 32) return launch_halo<T, 32, false>(p, pl, st);
+    return launch_halo<T, 16, false>(p, pl, st);
   }
   switch (pl.tile) {
     case 0: return launch_cfg2<T, 128, 128, 2, 2, 2>(d, p, pl, st);
@@ -983,27 +1043,20 @@ int validate(const tg_gemm_desc* d) {
 
 }  // namespace
 
-extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
+extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
-  if (halo_eligible(d)) {   // LDS-halo conv kernel: 128x128 tile, reported with splits = 0
-    if (tile_m) *tile_m = 128;
-    if (tile_n) *tile_n = 128;
-    if (splits) *splits = 0;
-    return TG_OK;
-  }
   Plan pl = make_plan(d);
   if (tile_m) *tile_m = kTiles[pl.tile].bm;
   if (tile_n) *tile_n = kTiles[pl.tile].bn;
-  if (splits) *splits = pl.splits;
+  if (splits) *splits = pl.s;
+  if (kernel_kind) *kernel_kind = pl.halo ? 2 : (d->mode == 1 ? 1 : 0);
   return TG_OK;
 }
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (halo_eligible(d)) return 0;
-  Plan pl = make_plan(d);
-  return pl.splits > 1 ? (int64_t)pl.splits * d->M * d->N * 4 : 0;
+  return plan_workspace_bytes(make_plan(d));
 }
 
 extern "C" int tg_gemm(const tg_gemm_desc* d, void* stream) {

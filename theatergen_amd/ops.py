@@ -93,13 +93,13 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         _lib.check(L.tg_gemm(C.byref(d), _stream()))
         return out
     # profiling mode (bench.py roofline leg): HIP events on the launch stream around this one launch
-    tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
-    _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp)))
+    tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.check(L.tg_gemm(C.byref(d), _stream()))
     e1.record()
-    kname = "conv_halo_kernel<128x128>" if sp.value == 0 else f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
+    kname = "conv_halo_kernel<128x128>" if kk.value == 2 else f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
     _gemm_profile.append(dict(kernel=kname, splits=sp.value,
                               M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1)))
     return out
