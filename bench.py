@@ -87,8 +87,20 @@ def roofline_leg(unet, engine):
     tot_ms = sum(v["ms"] for v in by.values())
     tot_fl = sum(v["flops"] for v in by.values())
     ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+    # process); algorithmic bytes (operands once + result once) from the live launch records for comparison
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
+    except (OSError, KeyError, ValueError):
+        pass
+    alg = sum(2.0 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"]) for r in recs if r["kernel"] == name) / top["launches"]
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "kernel": name, "launches_per_cfg_call": top["launches"],
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg),
+            "kernel": name, "launches_per_cfg_call": top["launches"],
             "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
             "flop_per_launch_avg": top["flops"] / top["launches"],
             "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ACT = int(os.environ.get('ACT', '0'))
+FT = int(os.environ.get('FT', '0'))
 from theatergen_amd import ops
 dev, dt = "cuda:0", torch.bfloat16
 def timeit(fn, iters=20):
@@ -16,6 +17,6 @@ for (M, N) in [(65536, 2560), (65536, 320)]:
     tiles = (M // 128) * ((N + 127) // 128)
     for K in [64, 320, 1280]:
         a = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt); b = torch.randn(N, device=dev).to(dt)
-        ms = timeit(lambda: ops.linear(a, w, b, act=ACT))
+        ms = timeit(lambda: ops.linear(a, w, b, act=ACT, force_tile=FT))
         rounds = tiles / 512
         print(f"M={M} N={N} K={K:5d} tiles={tiles} {2.0 * M * N * K / ms / 1e9:7.0f} TF {ms * 1e3:8.1f} us  per-tile-round {ms * 1e3 / max(rounds, 1):6.2f} us  ({K // 64} K-tiles)", flush=True)

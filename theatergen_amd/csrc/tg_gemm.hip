@@ -427,7 +427,7 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 __device__ __attribute__((aligned(256))) unsigned char tg_zero_page[256];
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
   constexpr int CH = BKT / 8;                 // 16-byte chunks per LDS row (8 at BK = 64, 4 at BK = 32)
@@ -439,6 +439,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_glds_kernel(GemmP
   constexpr int XJ = BM / (RPI * NW);   // DMA instructions per wave per K-tile for the activation tile
   constexpr int WJ = BN / (RPI * NW);
   static_assert(BKT == 64 || BKT == 32, "BK");
+  static_assert((size_t)NW * 32 * (TN * 32 + 4) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "epilogue scratch must fit the operand stages");
   typedef typename Vec<T>::v8 V8;
   static_assert(NW % 2 == 0 && XJ >= 1 && WJ >= 1, "tile / wave layout");
 
