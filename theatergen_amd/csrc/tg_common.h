@@ -43,8 +43,24 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 // 32x32 MFMA C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// SiLU = x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions):
+// the GroupNorm apply pass spends as long on VALU as on memory, every instruction per element counts.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// exact-erf GELU (F.gelu default, models/attention.py:337).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// far below bf16 / fp16 resolution): 1 rcp + 5 fma + 1 exp instead of libm's branchy erff — the fused GEGLU epilogue
+// runs this on every element of the largest GEMMs.  The negative branch uses erfc directly (no 1 - (1 - tiny)).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float half_erfc = 0.5f * poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 0.5 * erfc(|z|)
+  return x * (x >= 0.f ? 1.0f - half_erfc : half_erfc);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
