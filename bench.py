@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=3)
+    ap.add_argument("--stage2", action="store_true",
+                    help="NOT the north-star line: time the stage-2 step (ControlNet + IP-Adapter UNet, reference "
+                         "pipelines.py:759-835) on the same stories instead of the stage-1 per-character step")
     return ap.parse_args()
 
 
@@ -151,8 +154,18 @@ def main():
     cb = args.char_batch
     jobs_per_story = 8
     assert jobs_per_story % cb == 0, "--char-batch must divide 8"
+    controlnet = None
+    if args.stage2:
+        from theatergen_amd import weights
+        from theatergen_amd.controlnet import ControlNetModel
+        controlnet = ControlNetModel.from_state_dict(cfg, weights.random_controlnet_state_dict(cfg, seed=1), device=device,
+                                                     dtype=dtype, num_tokens=T)
     engine = DenoiseEngine(unet, None, n_img=cb, height=512, width=512, num_inference_steps=args.ddim_steps,
-                           guidance_scale=7.5, enc_len=77 + T)
+                           guidance_scale=7.5, enc_len=77 + T, controlnet=controlnet, controlnet_enc_len=77)
+    control_image = None
+    if args.stage2:
+        gctl = torch.Generator().manual_seed(1234)
+        control_image = torch.rand(1, 3, 512, 512, generator=gctl).repeat(2 * cb, 1, 1, 1).to(device=device, dtype=dtype)
 
     # shared conditioning: generated on rank 0, broadcast over RCCL (the only collective besides the final gather)
     shared = story.shared_conditioning(ctx, T, dtype, device)
@@ -184,6 +197,8 @@ def main():
     def run_story(batches):
         for bi, (enc, lat) in enumerate(batches):
             engine.set_conditioning(enc)
+            if args.stage2:
+                engine.set_control(enc[:, :77], control_image, 1.0)
             hist = engine.run(lat)
             finals[bi * cb:(bi + 1) * cb].copy_(hist[-1])
         return D.gather_latents(finals)
@@ -217,7 +232,12 @@ def main():
         "whole_job_tflops": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12, 2),
         "whole_job_mfma_frac": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
     }
-    if rank == 0 and world == 1:
+    if args.stage2:
+        result["metric"] = "512px 50-step stage-2 images/sec (ControlNet + IP-Adapter UNet per step)"
+        result["unit"] = "images/s"
+        result["config"]["workload"] += "; STAGE 2: SD-1.5 ControlNet (361 M params, control image 512x512, scale 1.0) runs every step before the UNet"
+        result.pop("whole_job_tflops"); result.pop("whole_job_mfma_frac")
+    if rank == 0 and world == 1 and not args.stage2:
         if not args.no_roofline:
             result["roofline"] = roofline_leg(unet, engine)
         if not args.no_cpu_baseline:

@@ -138,6 +138,43 @@ def test_parameter_tables_and_module_keys():
     assert sum(n.startswith("mid_block") for n in names) == 2 and len(names) == 32
 
 
+def test_controlnet_tables_and_oracle_cpu():
+    """Stage-2 ControlNet: parameter table == the public SD-1.5 ControlNet count, module keys == diffusers names, CN
+    processors installed on the cross-attention only; the oracle runs on CPU and a freshly initialised ControlNet
+    (zero convs) contributes exact zeros, with guess-mode / conditioning scales applied to random heads."""
+    import math
+    import torch
+    from oracle import controlnet as oc
+    from theatergen_amd import config, weights
+    from theatergen_amd.attention_processor import AttnProcessor, CNAttnProcessor
+    from theatergen_amd.controlnet import ControlNetModel, install_cn_processors
+    assert sum(math.prod(s) for s in weights.controlnet_param_shapes(config.sd15()).values()) == 361_279_120
+    cfg = config.tiny()
+    m = ControlNetModel(cfg)
+    shapes = weights.controlnet_param_shapes(cfg)
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert len(m.controlnet_down_blocks) == 12
+    procs = install_cn_processors(m, num_tokens=4)
+    assert all(isinstance(p, CNAttnProcessor) == n.endswith("attn2.processor") for n, p in procs.items())
+    assert all(isinstance(p, AttnProcessor) for n, p in procs.items() if n.endswith("attn1.processor"))
+    g = torch.Generator().manual_seed(0)
+    x, enc, cond = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 81, cfg.cross_attention_dim, generator=g), torch.rand(2, 3, 128, 128, generator=g)
+    fresh = {k: v.float() for k, v in sd.items()}
+    d, mid = oc.controlnet_forward(cfg, fresh, x, 500, enc, cond)
+    assert len(d) == 12 and all(float(t.abs().max()) == 0.0 for t in d) and float(mid.abs().max()) == 0.0
+    rnd = weights.random_controlnet_state_dict(cfg, seed=1)
+    d1, m1 = oc.controlnet_forward(cfg, rnd, x, 500, enc, cond, conditioning_scale=1.0)
+    d2, m2 = oc.controlnet_forward(cfg, rnd, x, 500, enc, cond, conditioning_scale=0.5)
+    assert torch.allclose(d2[3], 0.5 * d1[3]) and torch.allclose(m2, 0.5 * m1)
+    dg, mg = oc.controlnet_forward(cfg, rnd, x, 500, enc, cond, conditioning_scale=1.0, guess_mode=True)
+    scales = torch.logspace(-1, 0, 13)
+    assert torch.allclose(dg[0], d1[0] * scales[0]) and torch.allclose(mg, m1 * scales[-1])
+    assert float(d1[0].abs().max()) > 0
+
+
 def test_story_workload_and_sharding():
     from theatergen_amd import distributed as D
     from theatergen_amd import story

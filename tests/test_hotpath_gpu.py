@@ -302,6 +302,131 @@ def test_stage2_frozen_mask_loop_and_single_object_api():
     assert torch.equal(prepare_ip_embeds(text, neg, enc[1:2, 77:], enc[0:1, 77:]), enc)
 
 
+# ---- stage-2 ControlNet branch ---------------------------------------------------------
+def _build_controlnet(cfg, dtype, seed=3, cn=True, **kw):
+    from theatergen_amd import weights as W
+    from theatergen_amd.controlnet import ControlNetModel
+    sd = W.random_controlnet_state_dict(cfg, seed=seed)
+    sd_r = {k: v.to(dtype).float() for k, v in sd.items()}
+    net = ControlNetModel.from_state_dict(cfg, sd, device=DEV, dtype=dtype, cn_processors=cn, num_tokens=4, **kw)
+    return net, sd_r
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["cn", "attn", "guess", "pool"])
+def test_controlnet_tiny_vs_oracle(dtype, mode):
+    """ControlNetModel (conditioning embedding on a 128x128 control image, encoder half, zero convs, scaling modes)
+    against the CPU restatement; CNAttnProcessor (image tokens dropped) and the default processor."""
+    from oracle import controlnet as oc
+    from theatergen_amd import config
+    cfg = config.tiny()
+    net, sd_r = _build_controlnet(cfg, dtype, cn=(mode != "attn"), global_pool_conditions=(mode == "pool"))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    enc = torch.randn(2, 81, cfg.cross_attention_dim, generator=g) * 0.5
+    cond = torch.rand(2, 3, 128, 128, generator=g)
+    scale = 0.8
+    rd, rm = oc.controlnet_forward(cfg, sd_r, x.to(dtype).float(), 661, enc.to(dtype).float(), cond.to(dtype).float(), scale,
+                                   guess_mode=(mode == "guess"), cross_mode="attn" if mode == "attn" else "cn",
+                                   global_pool_conditions=(mode == "pool"))
+    down, mid = net(x.to(DEV, dtype), 661, enc.to(DEV, dtype), cond.to(DEV, dtype), conditioning_scale=scale,
+                    guess_mode=(mode == "guess"), return_dict=False)
+    assert len(down) == len(rd) == 12
+    tol = net_tol(dtype)
+    for i, (a, b) in enumerate(zip(down, rd)):
+        assert a.dtype == dtype
+        close(a, b, tol, f"controlnet {mode} down[{i}]")
+    close(mid, rm, tol, f"controlnet {mode} mid")
+    if mode == "cn":
+        # token-major hand-over == NCHW outputs, and the output object form
+        o = net(x.to(DEV, dtype), 661, enc.to(DEV, dtype), cond.to(DEV, dtype), conditioning_scale=scale)
+        same = all(torch.equal(p, q) for p, q in zip(o.down_block_res_samples, down)) and torch.equal(o.mid_block_res_sample, mid)
+        assert same
+        dtm, mtm = net(x.to(DEV, dtype), 661, enc.to(DEV, dtype), cond.to(DEV, dtype), conditioning_scale=scale,
+                       return_dict=False, token_major=True)
+        for a, b in zip(dtm, down):
+            same = torch.equal(a.t.reshape(a.b, a.h, a.w, a.c).permute(0, 3, 1, 2), b)
+            assert same
+        # a fresh ControlNet (zero convs) contributes exact zeros
+        from theatergen_amd.controlnet import ControlNetModel
+        fresh = ControlNetModel(cfg).to(DEV, dtype)
+        fd, fm = fresh(x.to(DEV, dtype), 661, enc.to(DEV, dtype), cond.to(DEV, dtype), return_dict=False)
+        zero = all(float(t.abs().max()) == 0.0 for t in fd) and float(fm.abs().max()) == 0.0
+        assert zero
+
+
+def test_controlnet_sd15_full_vs_oracle():
+    """The SD-1.5 ControlNet plan (361 M parameters) at 512x512: control image 2x3x512x512, 12 + 1 residuals."""
+    from oracle import controlnet as oc
+    from theatergen_amd import config
+    dtype = torch.bfloat16
+    cfg = config.sd15()
+    net, sd_r = _build_controlnet(cfg, dtype)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    enc = torch.randn(2, 77, 768, generator=g) * 0.5
+    cond = torch.rand(1, 3, 512, 512, generator=g).repeat(2, 1, 1, 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    rd, rm = oc.controlnet_forward(cfg, sd_r, x.to(dtype).float(), 401, enc.to(dtype).float(), cond.to(dtype).float(), 1.0, cross_mode="cn")
+    down, mid = net(x.to(DEV, dtype), 401, enc.to(DEV, dtype), cond.to(DEV, dtype), return_dict=False)
+    shapes = [tuple(t.shape) for t in down]
+    assert shapes == [tuple(t.shape) for t in rd] and shapes[0] == (2, 320, 64, 64) and shapes[-1] == (2, 1280, 8, 8)
+    for i, (a, b) in enumerate(zip(down, rd)):
+        close(a, b, net_tol(dtype), f"sd15 controlnet down[{i}]")
+    close(mid, rm, net_tol(dtype), "sd15 controlnet mid")
+
+
+def test_stage2_controlnet_loop_vs_oracle():
+    """Stage-2 step (reference pipelines.py:759-835): ControlNet(model_in, t, text, control image) -> UNet(model_in, t, ip
+    embeds, residuals) -> CFG + DDIM, 4 steps, graph replay == eager == oracle loop; control image refresh on a captured graph."""
+    from oracle import controlnet as oc
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from theatergen_amd import config
+    from theatergen_amd.pipelines import DenoiseEngine
+    dtype = torch.bfloat16
+    cfg = config.tiny()
+    unet, sd_u = _build(cfg, dtype)
+    net, sd_c = _build_controlnet(cfg, dtype)
+    g = torch.Generator().manual_seed(21)
+    n, steps, scale = 1, 4, 1.0
+    lat = torch.randn(n, 4, 16, 16, generator=g)
+    enc = torch.randn(2 * n, 81, cfg.cross_attention_dim, generator=g) * 0.5
+    text = enc[:, :77].clone()
+    conds = [torch.rand(1, 3, 128, 128, generator=g).repeat(2 * n, 1, 1, 1) for _ in range(2)]
+
+    def oracle_loop(cond):
+        osch = oddim.DDIMSchedule()
+        osch.set_timesteps(steps)
+        ref = lat.clone()
+        for t in osch.timesteps.tolist():
+            mi = torch.cat([ref] * 2).to(dtype).float()
+            rd, rm = oc.controlnet_forward(cfg, sd_c, mi, t, text.to(dtype).float(), cond.to(dtype).float(), scale, cross_mode="cn")
+            rd = [d.to(dtype).float() for d in rd]          # residuals are stored in the activation dtype
+            npred = ou.unet_forward(cfg, sd_u, mi, t, enc.to(dtype).float(), ip_scale=0.4,
+                                    down_block_additional_residuals=rd, mid_block_additional_residual=rm.to(dtype).float())
+            ref = oddim.step_epilogue(osch, npred, t, ref, 7.5)
+        return ref
+
+    hist = {}
+    for use_graph in (False, True):
+        eng = DenoiseEngine(unet, None, n_img=n, height=128, width=128, num_inference_steps=steps, guidance_scale=7.5,
+                            enc_len=81, use_graph=use_graph, controlnet=net, controlnet_enc_len=77)
+        eng.set_conditioning(enc.to(DEV, dtype))
+        eng.set_control(text.to(DEV, dtype), conds[0].to(DEV, dtype), scale)
+        h = eng.run(lat).clone()
+        close(h[-1], oracle_loop(conds[0]), net_tol(dtype), f"stage-2 controlnet loop graph={use_graph}")
+        hist[use_graph] = h
+        eng.set_control(text.to(DEV, dtype), conds[1].to(DEV, dtype), scale)     # new control image on the same engine / graph
+        h2 = eng.run(lat).clone()
+        close(h2[-1], oracle_loop(conds[1]), net_tol(dtype), f"stage-2 controlnet loop, refreshed image, graph={use_graph}")
+        differs = not torch.equal(h2[-1], h[-1])
+        assert differs
+        hist[(use_graph, 2)] = h2
+    same = torch.equal(hist[False], hist[True]) and torch.equal(hist[(False, 2)], hist[(True, 2)])
+    assert same, "stage-2 graph replay is not bit-identical to eager launches"
+
+
 def test_ip_adapter_surface():
     """set_ip_adapter name table, state-dict key layout, set_scale, get_image_embeds (reference ip_adapter.py:95-158)."""
     from theatergen_amd import config

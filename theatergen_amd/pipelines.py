@@ -47,8 +47,11 @@ class DenoiseEngine:
     ``torch.stack(latents_all)`` of reference pipelines.py:488 for every image of the batch."""
 
     def __init__(self, unet, scheduler=None, n_img=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
-                 enc_len=81, use_graph=True):
+                 enc_len=81, use_graph=True, controlnet=None, controlnet_enc_len=77):
         self.unet = unet
+        # stage 2 (reference pipelines.py:759-818): every step the ControlNet runs on the same model input with the TEXT
+        # embeddings and the (step-invariant) control image; its residuals enter the UNet call
+        self.controlnet = controlnet
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler(prediction_type=unet.config.prediction_type)
         self.n_img = n_img
         self.h, self.w = height // 8, width // 8
@@ -68,6 +71,11 @@ class DenoiseEngine:
         self.model_in = torch.zeros((2 * n_img, C, self.h, self.w), dtype=dt, device=dev)
         self.enc = torch.zeros((2 * n_img, enc_len, cfg.cross_attention_dim), dtype=dt, device=dev)
         self.history = torch.zeros((num_inference_steps + 1, n_img, C, self.h, self.w), dtype=torch.float32, device=dev)
+        self.cn_enc = self.cn_cond = None
+        self.cn_scale = 1.0
+        if controlnet is not None:
+            self.cn_enc = torch.zeros((2 * n_img, controlnet_enc_len, cfg.cross_attention_dim), dtype=dt, device=dev)
+            self.cn_cond = torch.zeros((2 * n_img, 3, height, width), dtype=dt, device=dev)
         self.frozen = None
         self.frozen_mask = None
         self.frozen_steps = 0
@@ -90,6 +98,19 @@ class DenoiseEngine:
                 for k, v in added_cond_kwargs.items():
                     self.added[k].copy_(v)
         self._refresh_kv()
+
+    def set_control(self, controlnet_prompt_embeds, control_image, conditioning_scale=1.0):
+        """ControlNet inputs of reference pipelines.py:761-778: text embeddings [2*n_img, L, D] (negatives first) and the
+        prepared control image [2*n_img, 3, H, W] in [0, 1]; both are copied into static buffers (graph replay) and the
+        conditioning embedding is recomputed once here, not once per step."""
+        if self.controlnet is None:
+            raise RuntimeError("DenoiseEngine was built without a controlnet")
+        self.cn_enc.copy_(controlnet_prompt_embeds)
+        self.cn_cond.copy_(control_image)
+        if self.graph is not None and float(conditioning_scale) != self.cn_scale:
+            self.graph = None          # the scale is a launch constant of the zero-conv epilogues
+        self.cn_scale = float(conditioning_scale)
+        self.controlnet.cond_embedding(self.cn_cond)
 
     def _refresh_kv(self):
         from .attention_processor import Attention, IPAttnProcessor
@@ -117,8 +138,13 @@ class DenoiseEngine:
 
     # ---- one step ---------------------------------------------------------------------------------------
     def _step(self):
+        down = mid = None
+        if self.controlnet is not None:
+            down, mid = self.controlnet(self.model_in, self.sched, self.cn_enc, self.cn_cond, conditioning_scale=self.cn_scale,
+                                        return_dict=False, token_major=True)
         noise_pred = self.unet(self.model_in, self.sched, self.enc, added_cond_kwargs=self.added, return_dict=False,
-                               out_dtype=torch.float32)[0]
+                               out_dtype=torch.float32, down_block_additional_residuals=down,
+                               mid_block_additional_residual=mid)[0]
         ops.step_epilogue(noise_pred, self.latents, self.g, self.coef, self.step_idx, advance=True,
                           prediction_type=self.pred_type, frozen=self.frozen,
                           frozen_mask=self.frozen_mask, frozen_steps=self.frozen_steps, history=self.history,

@@ -423,7 +423,12 @@ class UNet2DConditionModel(nn.Module):
         return emb, tproj
 
     def _residual(self, act: _Act, extra):
-        """ControlNet / adapter residual (NCHW tensor from a diffusers module) added to a token-major activation."""
+        """ControlNet / adapter residual added to a token-major activation: an NCHW tensor (diffusers module) or a
+        token-major ``_Act`` handed over by ``theatergen_amd.controlnet.ControlNetModel(token_major=True)``."""
+        if isinstance(extra, _Act):
+            if (extra.b, extra.h, extra.w, extra.c) != (act.b, act.h, act.w, act.c):
+                raise ValueError("ControlNet residual geometry mismatch")
+            return _Act(ops.add(act.t, extra.t), act.b, act.h, act.w, act.c)
         e = extra.to(act.t.dtype).contiguous()
         e_tok = ops.transpose(e, act.b, act.c, act.hw).reshape(act.b * act.hw, act.c)
         return _Act(ops.add(act.t, e_tok), act.b, act.h, act.w, act.c)

@@ -206,3 +206,42 @@ def random_resampler_state_dict(seed=0, **kw):
             fan_in = shape[-1] if name.endswith(".weight") else shapes[name[:-5] + ".weight"][-1]
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
     return sd
+
+
+def controlnet_param_shapes(cfg: UNetConfig, conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256)):
+    """diffusers ``ControlNetModel`` parameter names: the UNet's encoder half + ``controlnet_cond_embedding.*`` +
+    ``controlnet_down_blocks.N`` / ``controlnet_mid_block`` (1x1 convs)."""
+    s = OrderedDict()
+    for k, v in unet_param_shapes(cfg, ip_adapter=False).items():
+        if k.startswith(("conv_in.", "time_embedding.", "down_blocks.", "mid_block.")):
+            s[k] = v
+    boc = tuple(cfg.block_out_channels)
+    ce = tuple(conditioning_embedding_out_channels)
+    p = "controlnet_cond_embedding"
+    s[f"{p}.conv_in.weight"] = (ce[0], conditioning_channels, 3, 3)
+    s[f"{p}.conv_in.bias"] = (ce[0],)
+    for i in range(len(ce) - 1):
+        s[f"{p}.blocks.{2 * i}.weight"] = (ce[i], ce[i], 3, 3)
+        s[f"{p}.blocks.{2 * i}.bias"] = (ce[i],)
+        s[f"{p}.blocks.{2 * i + 1}.weight"] = (ce[i + 1], ce[i], 3, 3)
+        s[f"{p}.blocks.{2 * i + 1}.bias"] = (ce[i + 1],)
+    s[f"{p}.conv_out.weight"] = (boc[0], ce[-1], 3, 3)
+    s[f"{p}.conv_out.bias"] = (boc[0],)
+    lpb = cfg.per_block(cfg.layers_per_block)
+    chans = [boc[0]]
+    for i in range(len(boc)):
+        chans += [boc[i]] * lpb[i]
+        if i != len(boc) - 1:
+            chans.append(boc[i])
+    for i, c in enumerate(chans):
+        s[f"controlnet_down_blocks.{i}.weight"] = (c, c, 1, 1)
+        s[f"controlnet_down_blocks.{i}.bias"] = (c,)
+    s["controlnet_mid_block.weight"] = (boc[-1], boc[-1], 1, 1)
+    s["controlnet_mid_block.bias"] = (boc[-1],)
+    return s
+
+
+def random_controlnet_state_dict(cfg: UNetConfig, seed=0, dtype=torch.float32, **kw):
+    """Seeded init like ``random_unet_state_dict``; the zero-convs get RANDOM (non-zero) weights so that parity tests see
+    the whole branch (a freshly initialised ControlNet would output exact zeros)."""
+    return _fill(controlnet_param_shapes(cfg, **kw), seed, dtype)
