@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=3)
+    ap.add_argument("--with-vae", action="store_true",
+                    help="NOT the north-star line: also decode the 8 final latents of every story with the VAE (pipelines.py:468) "
+                         "inside the timed region, i.e. end-to-end decoded images/s")
     ap.add_argument("--stage2", action="store_true",
                     help="NOT the north-star line: time the stage-2 step (ControlNet + IP-Adapter UNet, reference "
                          "pipelines.py:759-835) on the same stories instead of the stage-1 per-character step")
@@ -162,6 +165,12 @@ def main():
                                                      dtype=dtype, num_tokens=T)
     engine = DenoiseEngine(unet, None, n_img=cb, height=512, width=512, num_inference_steps=args.ddim_steps,
                            guidance_scale=7.5, enc_len=77 + T, controlnet=controlnet, controlnet_enc_len=77)
+    vae = None
+    if args.with_vae:
+        from theatergen_amd import weights
+        from theatergen_amd.vae import AutoencoderKL, sd_vae_config
+        vcfg = sd_vae_config()
+        vae = AutoencoderKL.from_state_dict(vcfg, weights.random_vae_decoder_state_dict(vcfg, seed=2), device=device, dtype=dtype)
     control_image = None
     if args.stage2:
         gctl = torch.Generator().manual_seed(1234)
@@ -201,6 +210,10 @@ def main():
                 engine.set_control(enc[:, :77], control_image, 1.0)
             hist = engine.run(lat)
             finals[bi * cb:(bi + 1) * cb].copy_(hist[-1])
+        if vae is not None:
+            with torch.no_grad():
+                images_out = vae.decode_latents(finals)[0]
+            assert images_out.shape[-1] == 512
         return D.gather_latents(finals)
 
     for s in range(args.warmup):
@@ -232,12 +245,15 @@ def main():
         "whole_job_tflops": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12, 2),
         "whole_job_mfma_frac": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
     }
+    if args.with_vae:
+        result["metric"] = result["metric"] + " + VAE decode of every image"
+        result["config"]["workload"] += "; each final latent decoded to 512x512 by the SD VAE decoder (49.5 M params) inside the timed region"
     if args.stage2:
         result["metric"] = "512px 50-step stage-2 images/sec (ControlNet + IP-Adapter UNet per step)"
         result["unit"] = "images/s"
         result["config"]["workload"] += "; STAGE 2: SD-1.5 ControlNet (361 M params, control image 512x512, scale 1.0) runs every step before the UNet"
         result.pop("whole_job_tflops"); result.pop("whole_job_mfma_frac")
-    if rank == 0 and world == 1 and not args.stage2:
+    if rank == 0 and world == 1 and not args.stage2 and not args.with_vae:
         if not args.no_roofline:
             result["roofline"] = roofline_leg(unet, engine)
         if not args.no_cpu_baseline:

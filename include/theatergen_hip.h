@@ -176,6 +176,16 @@ int tg_add(int32_t dtype, const void* a, const void* b, int64_t n, void* out, vo
  * (attention_processor.py:318-320, 363-364) and ControlNet residual injection (models/unet_2d_condition.py:938-946). */
 int tg_transpose(int32_t dtype, const void* src, int32_t batch, int32_t rows, int32_t cols, void* dst, void* stream);
 
+/* VAE decode helpers (AutoencoderKL.decode as called at models/pipelines.py:468, 849-854; diffusers 0.21.4):
+ * tg_conv1x1_nchw : out[b, o, p] = bias[o] + sum_c w[o, c] * (in_scale * x[b, c, p]), fp32 NCHW, cin / cout <= 8
+ *                   (post_quant_conv with the `latents / vae.config.scaling_factor` division folded in)
+ * tg_softmax_rows : out[r, :] = softmax(scale * x[r, :]) per row (fp32 math), the single-head d = 512 attention of the
+ *                   VAE mid block is scores-GEMM -> this -> PV-GEMM (head dims > 160 are outside tg_attention) */
+int tg_conv1x1_nchw(const float* x, int32_t batch, int32_t cin, int32_t cout, int64_t hw, const float* weight,
+                    const float* bias, float in_scale, float* out, void* stream);
+int tg_softmax_rows(int32_t dtype, const void* x, int64_t rows, int32_t cols, int64_t ldx, float scale, void* out,
+                    int64_t ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * UNet boundary convolutions (tiny channel counts, direct):
  * tg_conv_in : sample NCHW [batch, cin, h, w] (src_dtype: 0 bf16, 1 f16, 2 f32) -> NHWC [batch, h*w, cout],

@@ -175,6 +175,29 @@ def test_controlnet_tables_and_oracle_cpu():
     assert float(d1[0].abs().max()) > 0
 
 
+def test_vae_decoder_tables_and_oracle_cpu():
+    """VAE decode: parameter table == the public SD VAE decoder count (+ post_quant_conv), module keys
+    == diffusers names, oracle decode shape / scaling-factor convention on CPU."""
+    import math
+    import torch
+    from oracle import vae as ov
+    from theatergen_amd import weights
+    from theatergen_amd.vae import AutoencoderKL, sd_vae_config, tiny_vae_config
+    assert sum(math.prod(s) for s in weights.vae_decoder_param_shapes(sd_vae_config()).values()) == 49_490_199
+    cfg = tiny_vae_config()
+    m = AutoencoderKL(cfg)
+    shapes = weights.vae_decoder_param_shapes(cfg)
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    rnd = weights.random_vae_decoder_state_dict(cfg, seed=2)
+    lat = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    img = ov.decode(cfg, rnd, lat)
+    assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
+    assert torch.allclose(ov.decode(cfg, rnd, lat * 2.0, scaling_factor=2 * cfg.scaling_factor), img, atol=1e-5)
+
+
 def test_story_workload_and_sharding():
     from theatergen_amd import distributed as D
     from theatergen_amd import story

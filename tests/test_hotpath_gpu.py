@@ -427,6 +427,70 @@ def test_stage2_controlnet_loop_vs_oracle():
     assert same, "stage-2 graph replay is not bit-identical to eager launches"
 
 
+# ---- VAE decode ------------------------------------------------------------------------
+def _build_vae(cfg, dtype, seed=2):
+    from theatergen_amd import weights as W
+    from theatergen_amd.vae import AutoencoderKL
+    sd = W.random_vae_decoder_state_dict(cfg, seed=seed)
+    sd_r = {k: v.to(dtype).float() for k, v in sd.items()}
+    sd_r["post_quant_conv.weight"], sd_r["post_quant_conv.bias"] = sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]  # fp32 on device too
+    return AutoencoderKL.from_state_dict(cfg, sd, device=DEV, dtype=dtype), sd_r
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vae_decode_tiny_vs_oracle(dtype):
+    """AutoencoderKL.decode: post_quant 1x1, conv_in, mid block with the single-head full-width attention (GEMM ->
+    row softmax -> GEMM), 4 up blocks with nearest-x2 upsample convs, GroupNorm+SiLU, conv_out; both call conventions."""
+    from oracle import vae as ov
+    from theatergen_amd.vae import tiny_vae_config
+    cfg = tiny_vae_config()
+    vae, sd_r = _build_vae(cfg, dtype)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(2, 4, 8, 8, generator=g) * cfg.scaling_factor
+    ref = ov.decode(cfg, sd_r, lat)
+    img = vae.decode_latents(lat.to(DEV))[0]
+    assert img.shape == (2, 3, 64, 64) and img.dtype == torch.float32
+    close(img, ref, net_tol(dtype), "vae decode_latents tiny")
+    img2 = vae.decode((lat / cfg.scaling_factor).to(DEV), return_dict=True).sample      # the reference's call convention
+    assert img2.dtype == dtype
+    close(img2, ref, net_tol(dtype), "vae decode tiny")
+
+
+def test_vae_softmax_rows_and_pointwise_kernels():
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for dtype in DTYPES:
+        x = (torch.randn(300, 4096, generator=g) * 3).to(dtype)
+        ref = torch.softmax(x.float() * 0.25, dim=-1)
+        xd = x.to(DEV)
+        out = ops.softmax_rows(xd, scale=0.25)
+        close(out, ref, 1e-2 if dtype == torch.bfloat16 else 2e-3, "softmax_rows")
+        ops.softmax_rows(xd, scale=0.25, out=xd)           # in place
+        same = torch.equal(xd, out)
+        assert same
+    z = torch.randn(3, 4, 16, 16, generator=g)
+    w, b = torch.randn(4, 4, generator=g), torch.randn(4, generator=g)
+    ref = torch.einsum("oc,bchw->bohw", w, z * 0.5) + b[None, :, None, None]
+    got = ops.conv1x1_nchw(z.to(DEV), w.to(DEV), b.to(DEV), 0.5)
+    close(got, ref, 1e-5, "conv1x1_nchw")
+
+
+def test_vae_decode_sd_full_vs_oracle():
+    """The SD-1.5 VAE decoder (49.5 M parameters): 64x64 latent -> 512x512 image (1.24 TMAC)."""
+    from oracle import vae as ov
+    from theatergen_amd.vae import sd_vae_config
+    dtype = torch.bfloat16
+    cfg = sd_vae_config()
+    vae, sd_r = _build_vae(cfg, dtype)
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 4, 64, 64, generator=g) * cfg.scaling_factor
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = ov.decode(cfg, sd_r, lat)
+    img = vae.decode_latents(lat.to(DEV))[0]
+    assert img.shape == (1, 3, 512, 512)
+    close(img, ref, net_tol(dtype), "sd vae decode 512x512")
+
+
 def test_ip_adapter_surface():
     """set_ip_adapter name table, state-dict key layout, set_scale, get_image_embeds (reference ip_adapter.py:95-158)."""
     from theatergen_amd import config

@@ -55,6 +55,8 @@ SIGNATURES = {
     "tg_act": (i32, [i32, vp, i64, i32, vp, vp]),
     "tg_add": (i32, [i32, vp, vp, i64, vp, vp]),
     "tg_transpose": (i32, [i32, vp, i32, i32, i32, vp, vp]),
+    "tg_conv1x1_nchw": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, vp, vp]),
+    "tg_softmax_rows": (i32, [i32, vp, i64, i32, i64, f32, vp, i64, vp]),
     "tg_conv_in": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     "tg_conv_out": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "tg_timestep_embedding": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp, i64, vp]),

@@ -411,6 +411,59 @@ __global__ __launch_bounds__(256) void conv_out_fast_kernel(const T* x, int batc
   }
 }
 
+// ---- VAE decode helpers -------------------------------------------------------
+// 1x1 convolution on a thin NCHW tensor (post_quant_conv 4 -> 4 with the 1 / scaling_factor of
+// `vae.decode(latents / vae.config.scaling_factor)`, models/pipelines.py:849-854, folded in): one thread per pixel.
+__global__ __launch_bounds__(256) void conv1x1_nchw_kernel(const float* x, int batch, int cin, int cout, long hw, const float* w,
+                                                           const float* bias, float in_scale, float* out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)batch * hw) return;
+  const long b = idx / hw, p = idx - b * hw;
+  float v[8];
+  for (int c = 0; c < cin; ++c) v[c] = x[(b * cin + c) * hw + p] * in_scale;
+  for (int o = 0; o < cout; ++o) {
+    float a = bias ? bias[o] : 0.f;
+    for (int c = 0; c < cin; ++c) a += w[o * cin + c] * v[c];
+    out[(b * cout + o) * hw + p] = a;
+  }
+}
+
+// row softmax in place semantics (out may alias x): one wave per row, fp32 math, scale applied to the logits.
+// Used by the VAE's single-head d = 512 attention (scores = GEMM, softmax here, PV = GEMM; head dims > 160 are outside
+// the fused flash kernel's register budget and the layer runs once per image, not per step).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* x, long rows, int cols, long ldx, float scale, T* out, long ldo) {
+  typedef typename Vec<T>::v8 V8;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  T* orow = out + row * ldo;
+  const int c8 = cols / 8;
+  float mx = -INFINITY;
+  for (int i = lane; i < c8; i += 64) {
+    V8 v = *reinterpret_cast<const V8*>(xr + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, to_f32<T>(v[j]));
+  }
+  mx = wave_max(mx) * scale;
+  const float c = scale * 1.4426950408889634f, mc = mx * 1.4426950408889634f;
+  float sum = 0.f;
+  for (int i = lane; i < c8; i += 64) {
+    V8 v = *reinterpret_cast<const V8*>(xr + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32<T>(v[j]), c, -mc));
+  }
+  const float inv = 1.f / wave_sum(sum);
+  for (int i = lane; i < c8; i += 64) {
+    V8 v = *reinterpret_cast<const V8*>(xr + i * 8);
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(to_f32<T>(v[j]), c, -mc)) * inv);
+    *reinterpret_cast<V8*>(orow + i * 8) = o;
+  }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, NAME, GRID, BLOCK, LDS, ...)                                            \
@@ -585,6 +638,30 @@ extern "C" int tg_transpose(int32_t dtype, const void* src, int32_t batch, int32
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   if (dtype == TG_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, rows, cols, (bf16_t*)dst);
   else hipLaunchKernelGGL(transpose_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)src, rows, cols, (f16_t*)dst);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_conv1x1_nchw(const float* x, int32_t batch, int32_t cin, int32_t cout, int64_t hw, const float* weight,
+                               const float* bias, float in_scale, float* out, void* stream) {
+  TG_CHECK(x && weight && out && batch > 0 && hw > 0 && cin > 0 && cin <= 8 && cout > 0 && cout <= 8 && x != out, TG_ERR_ARG,
+           "tg_conv1x1_nchw: bad args (cin, cout <= 8)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long n = (long)batch * hw;
+  hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, batch, cin, cout, (long)hw, weight, bias,
+                     in_scale, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_softmax_rows(int32_t dtype, const void* x, int64_t rows, int32_t cols, int64_t ldx, float scale, void* out,
+                               int64_t ldo, void* stream) {
+  TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0,
+           TG_ERR_ARG, "tg_softmax_rows: bad args (cols and pitches must be multiples of 8)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == TG_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (long)rows, cols, (long)ldx, scale, (bf16_t*)out, (long)ldo);
+  else hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, (long)rows, cols, (long)ldx, scale, (f16_t*)out, (long)ldo);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

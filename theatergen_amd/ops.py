@@ -226,6 +226,26 @@ def transpose(src, batch, rows, cols, out=None):
     return out
 
 
+def conv1x1_nchw(x, weight, bias, in_scale=1.0):
+    """fp32 NCHW thin 1x1 conv (VAE post_quant_conv): x [B, cin, h, w], weight [cout, cin] fp32"""
+    _need_cuda(x)
+    B, cin, h, w = x.shape
+    cout = weight.shape[0]
+    out = torch.empty((B, cout, h, w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tg_conv1x1_nchw(_ptr(x), B, cin, cout, h * w, _ptr(weight), _ptr(bias), float(in_scale), _ptr(out), _stream()))
+    return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    """row softmax of a 2-D [rows, cols] tensor (cols % 8 == 0); ``out`` may alias ``x``"""
+    _need_cuda(x)
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().tg_softmax_rows(_dt(x), _ptr(x), rows, cols, x.stride(0), float(scale), _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 _SRC = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
 

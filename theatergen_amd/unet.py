@@ -76,7 +76,8 @@ class ResnetBlock2D(nn.Module):
         self.groups, self.eps, self.output_scale_factor = groups, eps, output_scale_factor
         self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
-        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        # temb_channels None: the VAE's ResnetBlock2D(temb_channels=None) has no time projection
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
         self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
@@ -91,9 +92,12 @@ class ResnetBlock2D(nn.Module):
         w2 = self._p.get("c2", [self.conv2.weight], lambda: pack_conv3x3(self.conv2.weight.detach()))
         h = ops.groupnorm(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, silu=True,
                           x1=skip.t if skip is not None else None)
-        off, width = self.temb_slot
-        h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias, bvec=tproj[:, off:off + width],
-                        rows_per_batch=x.hw)
+        if tproj is not None:
+            off, width = self.temb_slot
+            h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias, bvec=tproj[:, off:off + width],
+                            rows_per_batch=x.hw)
+        else:
+            h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias)
         h = ops.groupnorm(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias, silu=True)
         if self.conv_shortcut is not None:
             ws = self._p.get("sc", [self.conv_shortcut.weight], lambda: pack_conv1x1(self.conv_shortcut.weight.detach()))

@@ -245,3 +245,54 @@ def random_controlnet_state_dict(cfg: UNetConfig, seed=0, dtype=torch.float32, *
     """Seeded init like ``random_unet_state_dict``; the zero-convs get RANDOM (non-zero) weights so that parity tests see
     the whole branch (a freshly initialised ControlNet would output exact zeros)."""
     return _fill(controlnet_param_shapes(cfg, **kw), seed, dtype)
+
+
+def vae_decoder_param_shapes(cfg):
+    """diffusers ``AutoencoderKL`` decoder-side parameter names (``post_quant_conv`` + ``decoder.*``)."""
+    s = OrderedDict()
+    boc = tuple(cfg.block_out_channels)
+    lc = cfg.latent_channels
+    s["post_quant_conv.weight"] = (lc, lc, 1, 1)
+    s["post_quant_conv.bias"] = (lc,)
+    s["decoder.conv_in.weight"] = (boc[-1], lc, 3, 3)
+    s["decoder.conv_in.bias"] = (boc[-1],)
+
+    def resnet(p, cin, cout):
+        s[p + ".norm1.weight"] = (cin,)
+        s[p + ".norm1.bias"] = (cin,)
+        s[p + ".conv1.weight"] = (cout, cin, 3, 3)
+        s[p + ".conv1.bias"] = (cout,)
+        s[p + ".norm2.weight"] = (cout,)
+        s[p + ".norm2.bias"] = (cout,)
+        s[p + ".conv2.weight"] = (cout, cout, 3, 3)
+        s[p + ".conv2.bias"] = (cout,)
+        if cin != cout:
+            s[p + ".conv_shortcut.weight"] = (cout, cin, 1, 1)
+            s[p + ".conv_shortcut.bias"] = (cout,)
+
+    c = boc[-1]
+    resnet("decoder.mid_block.resnets.0", c, c)
+    a = "decoder.mid_block.attentions.0"
+    s[a + ".group_norm.weight"] = (c,)
+    s[a + ".group_norm.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{a}.{n}.weight"] = (c, c)
+        s[f"{a}.{n}.bias"] = (c,)
+    resnet("decoder.mid_block.resnets.1", c, c)
+    prev = c
+    for i, out_c in enumerate(reversed(boc)):
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else out_c, out_c)
+        if i != len(boc) - 1:
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+        prev = out_c
+    s["decoder.conv_norm_out.weight"] = (boc[0],)
+    s["decoder.conv_norm_out.bias"] = (boc[0],)
+    s["decoder.conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3)
+    s["decoder.conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def random_vae_decoder_state_dict(cfg, seed=0, dtype=torch.float32):
+    return _fill(vae_decoder_param_shapes(cfg), seed, dtype)
