@@ -912,13 +912,18 @@ Plan make_plan(const tg_gemm_desc* d) {
     full = 0; rem = T; s = d->force_split_k;
   } else if (rem > 0 && !d->geglu && units >= 2 * min_units) {
     const double t_unit = halo ? 9.0 : (d->mode == 1 ? 1.5 : 1.1), t_fix = 6.0;
-    double best = (units * t_unit + t_fix) * (2 * rem <= S ? 0.6 : 1.0);
+    // an unsplit tail that leaves at most one block per CU runs faster than a full round — much faster for the GEMM and
+    // halo kernels (0.6x), hardly for the implicit-GEMM conv whose blocks are bound by their own DMA latency (0.85x)
+    const double unsplit = (units * t_unit + t_fix) * (2 * rem <= S ? ((!halo && d->mode == 1) ? 0.85 : 0.6) : 1.0);
+    double best = 1e30;
+    int best_c = 1;
     for (int c = 2; c <= 8 && units / c >= min_units; ++c) {
       const int kps = (units + c - 1) / c;
       const long rounds = (rem * c + S - 1) / S;
       const double cost = rounds * (kps * t_unit + t_fix) + 6.0 + 0.065 * (double)(rem * c);
-      if (cost < best * 0.95) { best = cost; s = c; }
+      if (cost < best) { best = cost; best_c = c; }
     }
+    if (best < unsplit * 0.95) s = best_c;          // a split must clearly pay for its partial traffic
   }
   if (s > units) s = units;
   if (s < 1) s = 1;
