@@ -886,6 +886,9 @@ Plan make_plan(const tg_gemm_desc* d) {
     if (N <= 64 && M > 64) t = 2;        // 128 x 64
     else if (M <= 64 && N > 64) t = 3;   // 64 x 128
     else if (M <= 64 && N <= 64) t = 1;  // 64 x 64
+    // few 128x128 tiles (the 8x8 level, M = 1024): 64x64 tiles put 4x as many blocks on the chip (3 per CU):
+    // 1024x1280x1280 22 -> 13 us, K = 5120 69 -> 39 us (scripts/dev_tile_sweep.py)
+    else if (d->mode == 0 && !d->geglu && ((M + 127) / 128) * ((N + 127) / 128) <= 128) t = 1;
     if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
