@@ -146,6 +146,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   };
 
   const int skey = (l31 >> 1) & 7;                       // swizzle key of this lane's fragment rows
+  // per-lane LDS element offsets of the fragment reads, computed ONCE (they only depend on the lane): inside the loop an
+  // access is (stage base + table entry + compile-time constant) instead of re-deriving xor / shift / add per read
+  int kofs[4], vofs[8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kofs[c] = l31 * 64 + (((2 * c + hi) ^ skey) << 3);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) vofs[c] = l31 * 64 + 4 * hi + ((c ^ skey) << 3);
   // RAW scores of one 64-key tile for this lane's query (the softmax scale is folded into the exp2 argument by one
   // fma per element); keys >= len are masked to -inf only on a ragged tile, full tiles take no compare/select at all.
   auto scores = [&](f32x16 (&s)[2], const T* sK, int len, int kv0) {
@@ -155,8 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
       for (int r = 0; r < 16; ++r) s[kvt][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const T* kr = sK + (ks >> 2) * 4096 + (kvt * 32 + l31) * 64 + ((((ks & 3) * 2 + hi) ^ skey) << 3);
-        V8 kf = *reinterpret_cast<const V8*>(kr);
+        V8 kf = *reinterpret_cast<const V8*>(sK + kofs[ks & 3] + ((ks >> 2) * 4096 + kvt * 32 * 64));
         s[kvt] = mfma32(kf, qf[ks], s[kvt]);
       }
     }
@@ -190,11 +196,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[kvt][8 * cc + j]);
       const int s0 = 4 * kvt + 2 * cc;
-      const T* vr = sV + l31 * 64 + 4 * hi;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        V4 lo = *reinterpret_cast<const V4*>(vr + t * 32 * 64 + ((s0 ^ skey) << 3));
-        V4 hi4 = *reinterpret_cast<const V4*>(vr + t * 32 * 64 + (((s0 + 1) ^ skey) << 3));
+        V4 lo = *reinterpret_cast<const V4*>(sV + vofs[s0] + t * 32 * 64);
+        V4 hi4 = *reinterpret_cast<const V4*>(sV + vofs[s0 + 1] + t * 32 * 64);
         V8 vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
