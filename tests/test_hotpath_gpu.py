@@ -212,6 +212,35 @@ def test_unet_sd15_full_vs_oracle(dtype):
     close(out, ref, net_tol(dtype), "sd15 unet")
 
 
+@pytest.mark.parametrize("plan", ["sd21", "sdxl"])
+def test_unet_other_baseline_plans_full_vs_oracle(plan):
+    """BASELINE.json configs[3] / configs[4] models at their native resolution, CFG batch 2: SD-2.1 (768x768 -> latent
+    96x96, heads 5/10/20/20 -> d = 64, ctx 1024, linear projections, 4 image tokens, bf16) and SDXL-base (1024x1024 ->
+    latent 128x128, 2.6 B parameters, text_time conditioning, IP-Adapter-Plus = 16 image tokens, fp16)."""
+    import gc as _gc
+    from oracle import unet as ou
+    from theatergen_amd import config
+    cfg = config.PLANS[plan]()
+    dtype, T = (torch.bfloat16, 4) if plan == "sd21" else (torch.float16, 16)
+    unet, sd_r = _build(cfg, dtype, T=T)
+    s = cfg.sample_size
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 4, s, s, generator=g)
+    enc = torch.randn(2, 77 + T, cfg.cross_attention_dim, generator=g) * 0.5
+    added = addr = addd = None
+    if cfg.addition_embed_type:
+        added = {"text_embeds": torch.randn(2, 1280, generator=g), "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]] * 2)}
+        addr = {"text_embeds": added["text_embeds"].to(dtype).float(), "time_ids": added["time_ids"]}
+        addd = {k: v.to(DEV) for k, v in added.items()}
+    out = unet(x.to(DEV, dtype), 621, enc.to(DEV, dtype), added_cond_kwargs=addd, out_dtype=torch.float32).sample.cpu()
+    del unet
+    _gc.collect()
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = ou.unet_forward(cfg, sd_r, x.to(dtype).float(), 621, enc.to(dtype).float(), ip_scale=0.4, num_tokens=T, added_cond_kwargs=addr)
+    close(out, ref, net_tol(dtype), f"{plan} unet full")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_denoise_engine_vs_oracle_loop(dtype):
     """5 DDIM steps, 2 character images batched (CFG batch 4), graph replay == eager == oracle loop."""
