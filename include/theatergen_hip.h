@@ -39,6 +39,7 @@ extern "C" {
 #define TG_ACT_NONE 0
 #define TG_ACT_SILU 1
 #define TG_ACT_GELU 2        /* exact (erf) GELU */
+#define TG_ACT_QUICK_GELU 3  /* x * sigmoid(1.702 x): OpenAI CLIP's activation (text / image encoders) */
 
 int tg_version(void);
 const char* tg_last_error(void);

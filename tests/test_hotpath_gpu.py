@@ -520,6 +520,64 @@ def test_vae_decode_sd_full_vs_oracle():
     close(img, ref, net_tol(dtype), "sd vae decode 512x512")
 
 
+# ---- CLIP image encoder -----------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["gelu", "quick_gelu"])
+def test_clip_vision_vs_transformers_golden(dtype, name):
+    """Native CLIPVisionModelWithProjection vs outputs captured from the installed transformers library (tiny models):
+    image_embeds, last_hidden_state, hidden_states[-2]; state-dict names are the library's."""
+    from tests.golden import make_clip_golden as mk
+    from theatergen_amd.clip import CLIPVisionConfig, CLIPVisionModelWithProjection
+    g = _load("clip_vision")
+    hid, inter, layers, heads, img, patch, proj, act = mk.CASES[name]
+    cfg = CLIPVisionConfig(hidden_size=hid, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                           image_size=img, patch_size=patch, projection_dim=proj, hidden_act=act, layer_norm_eps=1e-5)
+    sd = {k[len(name) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".w.")}
+    enc = CLIPVisionModelWithProjection.from_state_dict(cfg, sd, device=DEV, dtype=dtype)
+    out = enc(torch.from_numpy(g[name + ".x"]).to(DEV), output_hidden_states=True)
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    assert len(out.hidden_states) == layers + 1
+    close(out.image_embeds, g[name + ".image_embeds"], tol, f"clip {name} image_embeds")
+    close(out.last_hidden_state, g[name + ".last_hidden_state"], tol, f"clip {name} last_hidden_state")
+    close(out.hidden_states[-2], g[name + ".penultimate"], tol, f"clip {name} penultimate")
+
+
+def test_clip_vit_h14_full_vs_oracle_and_embedding_cache():
+    """The ViT-H/14 tower IP-Adapter uses (632 M parameters, 257 tokens, 16 heads x 80) against the pinned oracle, and the
+    per-character embedding cache."""
+    from oracle import clip as oc
+    from theatergen_amd.clip import CLIPVisionModelWithProjection, EmbeddingCache, vit_h14_config
+    dtype = torch.bfloat16
+    cfg = vit_h14_config()
+    torch.manual_seed(3)
+    m = CLIPVisionModelWithProjection(cfg)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 1 and "norm" in n_ and n_.endswith("weight"):
+                p_.copy_(1.0 + 0.1 * torch.randn_like(p_))
+            elif p_.dim() == 1:
+                p_.copy_(0.05 * torch.randn_like(p_))
+            elif "embedding" in n_:
+                p_.copy_(0.05 * torch.randn_like(p_))
+    sd_r = {k: v.to(dtype).float() for k, v in m.state_dict().items()}
+    enc = m.to(DEV, dtype)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = oc.clip_vision_forward(dict(hidden_size=1280, num_attention_heads=16, patch_size=14, hidden_act="gelu"), sd_r, x.to(dtype).float())
+    out = enc(x.to(DEV), output_hidden_states=True)
+    assert out.hidden_states[-2].shape == (2, 257, 1280) and out.image_embeds.shape == (2, 1024)
+    close(out.hidden_states[-2], ref["hidden_states"][-2], net_tol(dtype), "ViT-H penultimate")
+    close(out.image_embeds, ref["image_embeds"], net_tol(dtype), "ViT-H image_embeds")
+    calls = []
+    cache = EmbeddingCache(enc, penultimate=True)
+    def fn():
+        calls.append(1)
+        return x[:1].to(DEV)
+    a = cache.get("char-7", fn)
+    b = cache.get("char-7", fn)
+    assert len(calls) == 1 and len(cache) == 1 and a is b and a.shape == (1, 257, 1280)
+
+
 def test_ip_adapter_surface():
     """set_ip_adapter name table, state-dict key layout, set_scale, get_image_embeds (reference ip_adapter.py:95-158)."""
     from theatergen_amd import config

@@ -163,3 +163,24 @@ def test_latents(golden_dir):
     assert np.array_equal(comp[0].numpy(), gold["lat.compose_step0"])
     assert np.array_equal(comp[37].numpy(), gold["lat.compose_step37"])
     np.testing.assert_allclose([float(comp.double().sum()), float(comp.double().abs().sum())], gold["lat.compose_checksum"], rtol=0, atol=0)
+
+
+def test_clip_vision_oracle_pinned_against_transformers():
+    """oracle/clip.py == transformers.CLIPVisionModelWithProjection on the stored tiny models (weights, inputs and outputs
+    captured from the installed library by tests/golden/make_clip_golden.py): image_embeds, last and penultimate states."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import clip as oc
+    from tests.golden import make_clip_golden as mk
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_vision.npz"))
+    for name, (hid, inter, layers, heads, img, patch, proj, act) in mk.CASES.items():
+        sd = {k[len(name) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".w.")}
+        o = oc.clip_vision_forward(dict(hidden_size=hid, num_attention_heads=heads, patch_size=patch, hidden_act=act), sd,
+                                   torch.from_numpy(g[name + ".x"]))
+        assert len(o["hidden_states"]) == int(g[name + ".n_hidden_states"]) == layers + 1
+        for key, got in (("image_embeds", o["image_embeds"]), ("last_hidden_state", o["last_hidden_state"]),
+                         ("penultimate", o["hidden_states"][-2])):
+            ref = torch.from_numpy(g[f"{name}.{key}"])
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (name, key)

@@ -48,6 +48,17 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+__device__ __forceinline__ float quick_gelu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+// one switch for the generic epilogues / tg_act
+__device__ __forceinline__ float gelu_erf_f(float x);
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == 1) return silu_f(x);
+  if (act == 2) return gelu_erf_f(x);
+  if (act == 3) return quick_gelu_f(x);
+  return x;
+}
 // exact-erf GELU (F.gelu default, models/attention.py:337).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // far below bf16 / fp16 resolution): 1 rcp + 5 fma + 1 exp instead of libm's branchy erff — the fused GEGLU epilogue
 // runs this on every element of the largest GEMMs.  The negative branch uses erfc directly (no 1 - (1 - tiny)).

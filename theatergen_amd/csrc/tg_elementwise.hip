@@ -25,7 +25,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void act_kernel(const T* x, long n, int act, T* out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float f = to_f32<T>(x[i]);
-    f = act == TG_ACT_SILU ? silu_f(f) : (act == TG_ACT_GELU ? gelu_erf_f(f) : f);
+    f = apply_act(f, act);
     out[i] = from_f32<T>(f);
   }
 }

@@ -86,12 +86,9 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, long m, lon
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += to_f32<T>(t[j]);
   }
-  if (p.act == TG_ACT_SILU) {
+  if (p.act != TG_ACT_NONE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-  } else if (p.act == TG_ACT_GELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
@@ -227,12 +224,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
         for (int e = 0; e < 4; ++e)
           v[e] = acc[i][j][4 * g + e] + to_f32<T>(bias4[j][g][e]) + to_f32<T>(add4[j][g][e]) + to_f32<T>(res4[j][g][e]);
         if constexpr (EPI == 1) {
-          if (p.act == TG_ACT_SILU) {
+          if (p.act != TG_ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-          } else if (p.act == TG_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
           }
         }
 #pragma unroll
@@ -395,12 +389,9 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
         for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
       }
       if constexpr (EPI == 1) {
-        if (p.act == TG_ACT_SILU) {
+        if (p.act != TG_ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        } else if (p.act == TG_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
         }
       }
       if (!unit_scale) {

@@ -33,8 +33,18 @@ class IPAdapter:
         self.image_encoder = None
         self.clip_image_processor = None
         if image_encoder_path is not None:
-            from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection  # third-party, optional
-            self.image_encoder = CLIPVisionModelWithProjection.from_pretrained(image_encoder_path).to(self.device, dtype=self.dtype)
+            # the checkpoint is read with transformers (file format / config), the tower itself then runs on the native
+            # kernels (theatergen_amd/clip.py: same call surface and state-dict names as the library's class)
+            from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection as HFCLIP  # third-party, optional
+            from .clip import CLIPVisionConfig, CLIPVisionModelWithProjection
+            hf = HFCLIP.from_pretrained(image_encoder_path)
+            c = hf.config
+            cfg = CLIPVisionConfig(hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                                   num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                                   image_size=c.image_size, patch_size=c.patch_size, projection_dim=c.projection_dim,
+                                   hidden_act=c.hidden_act, layer_norm_eps=c.layer_norm_eps)
+            self.image_encoder = CLIPVisionModelWithProjection.from_state_dict(cfg, hf.state_dict(), device=self.device, dtype=self.dtype)
+            del hf
             self.clip_image_processor = CLIPImageProcessor()
         self.image_proj_model = self.init_proj()
         if ip_ckpt is not None:

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, AttnDesc, GemmDesc  # noqa: F401
 
 _workspaces = {}
 
