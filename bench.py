@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--char-batch", type=int, default=8, help="character images denoised together (8 = one whole story)")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="the character batch is denoised as this many independent sub-batches replayed concurrently on "
+                         "separate HIP streams (same UNet weights; 1 = one batch on one stream)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--plan", default="sd15")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,7 +109,7 @@ def roofline_leg(unet, engine):
     alg = sum(2.0 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"]) for r in recs if r["kernel"] == name) / top["launches"]
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg),
-            "kernel": name, "launches_per_cfg_call": top["launches"],
+            "kernel": name, "launches_per_cfg_call": top["launches"], "cfg_batch_of_measured_call": 2 * engine.n_img,
             "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
             "flop_per_launch_avg": top["flops"] / top["launches"],
             "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
@@ -163,8 +166,12 @@ def main():
         from theatergen_amd.controlnet import ControlNetModel
         controlnet = ControlNetModel.from_state_dict(cfg, weights.random_controlnet_state_dict(cfg, seed=1), device=device,
                                                      dtype=dtype, num_tokens=T)
-    engine = DenoiseEngine(unet, None, n_img=cb, height=512, width=512, num_inference_steps=args.ddim_steps,
-                           guidance_scale=7.5, enc_len=77 + T, controlnet=controlnet, controlnet_enc_len=77)
+    ns = 1 if args.stage2 else max(1, args.streams)
+    assert cb % ns == 0, "--streams must divide --char-batch"
+    sub = cb // ns
+    engines = [DenoiseEngine(unet, None, n_img=sub, height=512, width=512, num_inference_steps=args.ddim_steps,
+                             guidance_scale=7.5, enc_len=77 + T, controlnet=controlnet, controlnet_enc_len=77) for _ in range(ns)]
+    engine = engines[0]
     vae = None
     if args.with_vae:
         from theatergen_amd import weights
@@ -205,11 +212,22 @@ def main():
 
     def run_story(batches):
         for bi, (enc, lat) in enumerate(batches):
-            engine.set_conditioning(enc)
-            if args.stage2:
-                engine.set_control(enc[:, :77], control_image, 1.0)
-            hist = engine.run(lat)
-            finals[bi * cb:(bi + 1) * cb].copy_(hist[-1])
+            if ns == 1:
+                engine.set_conditioning(enc)
+                if args.stage2:
+                    engine.set_control(enc[:, :77], control_image, 1.0)
+                hist = engine.run(lat)
+                finals[bi * cb:(bi + 1) * cb].copy_(hist[-1])
+            else:
+                # enc rows: [negatives of the cb images ; positives of the cb images] -> per sub-batch slices
+                lats = []
+                for k, e in enumerate(engines):
+                    rows = list(range(k * sub, (k + 1) * sub)) + list(range(cb + k * sub, cb + (k + 1) * sub))
+                    e.set_conditioning(enc[rows])
+                    lats.append(lat[k * sub:(k + 1) * sub])
+                hists = DenoiseEngine.run_concurrent(engines, lats)
+                for k, h in enumerate(hists):
+                    finals[bi * cb + k * sub:bi * cb + (k + 1) * sub].copy_(h[-1])
         if vae is not None:
             with torch.no_grad():
                 images_out = vae.decode_latents(finals)[0]
@@ -240,7 +258,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SD-1.5 512x512, 4-turn story x 2 characters = 8 char images per step per GPU, {args.ddim_steps} DDIM "
                                f"steps, CFG 7.5, IP-Adapter 77+4 tokens scale 0.4, {args.dtype}, random-init weights",
-                   "plan": args.plan, "char_batch": cb, "cfg_batch": 2 * cb, "ddim_steps": args.ddim_steps,
+                   "plan": args.plan, "char_batch": cb, "cfg_batch": 2 * cb, "streams": ns, "ddim_steps": args.ddim_steps,
                    "parallelism": f"dialogue-sharded x{world} (RCCL broadcast + all_gather only)"},
         "whole_job_tflops": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12, 2),
         "whole_job_mfma_frac": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),

@@ -285,6 +285,42 @@ def test_denoise_engine_vs_oracle_loop(dtype):
     assert same, "graph replay is not bit-identical to eager launches"
 
 
+def test_concurrent_engines_share_one_unet():
+    """Two denoising engines on ONE UNet (own conditioning buffers, K / V^T caches per encoder tensor, own kernel scratch
+    slot, own captured graph) replayed concurrently on two streams == the same two engines run one after the other,
+    bit for bit (no race on shared state), and == the oracle loop."""
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from theatergen_amd import config
+    from theatergen_amd.pipelines import DenoiseEngine
+    dtype = torch.bfloat16
+    cfg = config.tiny()
+    unet, sd_r = _build(cfg, dtype)
+    g = torch.Generator().manual_seed(31)
+    steps = 4
+    lats = [torch.randn(2, 4, 16, 16, generator=g) for _ in range(2)]
+    encs = [torch.randn(4, 81, cfg.cross_attention_dim, generator=g) * 0.5 for _ in range(2)]
+    engs = [DenoiseEngine(unet, None, n_img=2, height=128, width=128, num_inference_steps=steps, guidance_scale=7.5, enc_len=81)
+            for _ in range(2)]
+    assert engs[0].ws_slot != engs[1].ws_slot
+    for e, enc in zip(engs, encs):
+        e.set_conditioning(enc.to(DEV, dtype))
+    seq = [e.run(lat).clone() for e, lat in zip(engs, lats)]
+    for rep in range(3):
+        par = [h.clone() for h in DenoiseEngine.run_concurrent(engs, lats)]
+        torch.cuda.synchronize()
+        same = all(torch.equal(a, b) for a, b in zip(seq, par))
+        assert same, f"concurrent replay differs from sequential (repeat {rep})"
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(steps)
+    for k in range(2):
+        ref = lats[k].clone()
+        for t in osch.timesteps.tolist():
+            mi = torch.cat([ref] * 2).to(dtype).float()
+            ref = oddim.step_epilogue(osch, ou.unet_forward(cfg, sd_r, mi, t, encs[k].to(dtype).float(), ip_scale=0.4), t, ref, 7.5)
+        close(par[k][-1], ref, net_tol(dtype), f"concurrent engine {k} vs oracle")
+
+
 def test_stage2_frozen_mask_loop_and_single_object_api():
     """Stage-2 loop body (reference pipelines.py:742-835): latents_all[index+1] * mask + latents * (1 - mask) while
     index < frozen_steps, fused into the step epilogue; plus the stage-1 convenience wrapper."""

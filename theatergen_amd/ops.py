@@ -35,9 +35,29 @@ def _need_cuda(t):
         raise RuntimeError("theatergen_amd: tensors must live on the GPU (no CPU fallback)")
 
 
+_ws_slot = 0
+
+
+class workspace_slot:
+    """Kernels launched inside this context take their scratch (GroupNorm partial sums, K-split partial tiles) from slot
+    ``slot``: denoising chains that run CONCURRENTLY on different streams must not share one scratch buffer."""
+
+    def __init__(self, slot):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        global _ws_slot
+        self._prev, _ws_slot = _ws_slot, self.slot
+
+    def __exit__(self, *exc):
+        global _ws_slot
+        _ws_slot = self._prev
+        return False
+
+
 def workspace(nbytes, device):
-    """Persistent fp32 scratch per device (split-K partials, GroupNorm partial sums)."""
-    key = (device.index, "ws")
+    """Persistent fp32 scratch per (device, slot) (split-K partials, GroupNorm partial sums)."""
+    key = (device.index, "ws", _ws_slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty(max(int(nbytes) // 4 + 1, 1 << 20), dtype=torch.float32, device=device)

@@ -40,6 +40,9 @@ def prepare_ip_embeds(prompt_embeds, negative_prompt_embeds, image_prompt_embeds
     return torch.cat([neg, pos], dim=0)
 
 
+_engine_ids = iter(range(1, 1 << 30))
+
+
 class DenoiseEngine:
     """Batched CFG denoiser for ``n_img`` independent character images on one GPU.
 
@@ -49,6 +52,7 @@ class DenoiseEngine:
     def __init__(self, unet, scheduler=None, n_img=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
                  enc_len=81, use_graph=True, controlnet=None, controlnet_enc_len=77):
         self.unet = unet
+        self.ws_slot = next(_engine_ids)      # private kernel scratch: engines may replay concurrently on different streams
         # stage 2 (reference pipelines.py:759-818): every step the ControlNet runs on the same model input with the TEXT
         # embeddings and the (step-invariant) control image; its residuals enter the UNet call
         self.controlnet = controlnet
@@ -138,6 +142,10 @@ class DenoiseEngine:
 
     # ---- one step ---------------------------------------------------------------------------------------
     def _step(self):
+        with ops.workspace_slot(self.ws_slot):
+            self._step_body()
+
+    def _step_body(self):
         down = mid = None
         if self.controlnet is not None:
             down, mid = self.controlnet(self.model_in, self.sched, self.cn_enc, self.cn_cond, conditioning_scale=self.cn_scale,
@@ -176,14 +184,48 @@ class DenoiseEngine:
             self._step()
         self.graph = g
 
+    def _ensure_graph(self, latents):
+        sig = self._signature()
+        if self.use_graph and (self.graph is None or sig != self._graph_sig):
+            self._reset(latents)
+            self._capture()
+            self._graph_sig = sig
+
+    @staticmethod
+    def run_concurrent(engines, latents_list):
+        """Independent denoising chains (e.g. the two halves of a story's character batch) replayed CONCURRENTLY, one HIP
+        stream per engine: the second chain's kernels fill the partially filled grid rounds, small-grid layers and
+        launch gaps of the first (+4 % images/s for 2 x 4 images vs 1 x 8 on MI355X).  Engines may share one UNet; each
+        has its own conditioning buffers, K / V^T caches, kernel scratch slot and captured graph.  Returns the histories."""
+        dev = engines[0].dev
+        with torch.no_grad():
+            for e, lat in zip(engines, latents_list):
+                if not e.use_graph:
+                    raise RuntimeError("run_concurrent needs graph engines")
+                e._ensure_graph(lat)
+            cur = torch.cuda.current_stream(dev)
+            streams = [e._stream() for e in engines]
+            for e, lat, st in zip(engines, latents_list, streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    e._reset(lat)
+            for _ in range(engines[0].steps):
+                for e, st in zip(engines, streams):
+                    with torch.cuda.stream(st):
+                        e.graph.replay()
+            for st in streams:
+                cur.wait_stream(st)
+        return [e.history for e in engines]
+
+    def _stream(self):
+        if getattr(self, "_own_stream", None) is None:
+            self._own_stream = torch.cuda.Stream(device=self.dev)
+        return self._own_stream
+
     def run(self, latents):
         """latents [n_img, C, h, w] (any float dtype / device) -> latents_all fp32 [steps+1, n_img, C, h, w] on the GPU."""
         with torch.no_grad():
-            sig = self._signature()
-            if self.use_graph and (self.graph is None or sig != self._graph_sig):
-                self._reset(latents)
-                self._capture()
-                self._graph_sig = sig
+            self._ensure_graph(latents)
             self._reset(latents)
             for _ in range(self.steps):
                 if self.use_graph:
