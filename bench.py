@@ -40,9 +40,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--char-batch", type=int, default=8, help="character images denoised together (8 = one whole story)")
     ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="the character batch is denoised as this many independent sub-batches replayed concurrently on "
-                         "separate HIP streams (same UNet weights; 1 = one batch on one stream)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="denoise the character batch as this many independent sub-batches replayed concurrently on separate "
+                         "HIP streams (same UNet weights).  2 is +2 % images/s, but every launch is then a half-batch call "
+                         "overlapping with the other chain, so per-kernel roofline / rocprof figures are no longer those of "
+                         "one kernel owning the chip: the default line keeps 1")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--plan", default="sd15")
     ap.add_argument("--no-cpu-baseline", action="store_true")
