@@ -186,6 +186,8 @@ CONV_CASES = [
     (2, 64, 64, 128, 64, 64, 1, False),
     # LDS-halo kernel on the nearest-x2 upsampled input (output widths 64 / 32 / 16)
     (1, 32, 32, 64, 0, 128, 1, True), (4, 16, 16, 128, 0, 64, 1, True), (16, 8, 8, 64, 0, 192, 1, True),
+    # LDS-halo kernel at width 8: two whole 8x8 images per block (M >= 1024), two-source, ragged N
+    (16, 8, 8, 128, 0, 192, 1, False), (32, 8, 8, 64, 64, 320, 1, False),
 ]
 
 
@@ -219,7 +221,7 @@ def test_conv3x3(dtype, case):
     ("gemm", (16384, 640, 2560)),            # 128x128 tiles, forced 3-way split
     ("conv", (16, 32, 32, 1280, 0, 640)),    # LDS-halo kernel: 640 tiles on 512 slots, 128 tail tiles cut over 64-channel chunks
     ("conv", (16, 16, 16, 1280, 1280, 1280)),  # LDS-halo kernel, two-source, 320 tiles all split
-    ("conv", (16, 8, 8, 640, 640, 1280)),    # 8x8 weight-streaming layer (implicit GEMM, two-source)
+    ("conv", (16, 8, 8, 640, 640, 1280)),    # 8x8 weight-streaming layer (halo kernel, 2 images / block, two-source, all tiles split)
 ])
 def test_gemm_tail_split(kind, shape):
     """K-split of the tail tiles (grid rounds that would leave CUs idle): the heuristic must actually take the split

@@ -638,7 +638,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
 template <typename T, int WI, bool UPS>
 __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, WAVES_N = 2;
-  constexpr int TH = BM / WI, WIN = UPS ? WI / 2 : WI, SW = WIN + 2, SROWS = UPS ? TH / 2 + 2 : TH + 2;
+  // WI = 8 (the 8x8 level): a block's 128 pixels are TWO whole 8x8 images; their two 10x10 padded windows are stacked
+  // in the slab (20 slab rows of width 10), everything else is unchanged
+  constexpr bool MULTI = WI == 8;
+  static_assert(!(MULTI && UPS), "no upsample variant at width 8");
+  constexpr int TH = BM / WI, WIN = UPS ? WI / 2 : WI, SW = WIN + 2, SROWS = MULTI ? 20 : (UPS ? TH / 2 + 2 : TH + 2);
   constexpr int SLAB = SROWS * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
   constexpr int WJ = BN / (8 * NW);
   typedef typename Vec<T>::v8 V8;
@@ -688,9 +692,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   for (int j = 0; j < SJ; ++j) {
     const int sr = (j * NW + wave) * 8 + lrow;
     const int sy = sr / SW, sx = sr - sy * SW;
-    const int iy = iy0 + sy, ix = sx - 1;
+    int iy = iy0 + sy, im = img;
+    if (MULTI) { im = img + sy / 10; iy = sy % 10 - 1; }       // slab rows [10 i, 10 i + 10) = padded window of image img + i
+    const int ix = sx - 1;
     const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WIN && (m0 < p.M);
-    spix[j] = ok ? (img * H + iy) * WIN + ix : -1;
+    spix[j] = ok ? (im * H + iy) * WIN + ix : -1;
   }
   const T* wrow[WJ];
 #pragma unroll
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pm = wave_m * TM * 32 + i * 32 + l31;
-    ppy[i] = pm / WI;
+    ppy[i] = MULTI ? (pm >> 6) * 10 + ((pm & 63) >> 3) : pm / WI;
     ppx[i] = pm % WI;
   }
 
@@ -827,7 +833,7 @@ int launch_reduce(const GemmParams& p, const Plan& pl, hipStream_t st) {
 
 template <typename T, int WI, bool UPS>
 int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
-  constexpr int TH = 128 / WI, SLAB = UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2), NI = (SLAB + 7) / 8;
+  constexpr int TH = 128 / WI, SLAB = WI == 8 ? 200 : (UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2)), NI = (SLAB + 7) / 8;
   const size_t lds = ((size_t)NI * 8 * BK + 2 * 128 * BK) * sizeof(T);
   auto k = conv_halo_kernel<T, WI, UPS>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -839,11 +845,12 @@ int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
   if (d->mode != 1 || d->stride != 1 || d->force_tile != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return false;
+  if (d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->M % 128 != 0) return false;
+  if (d->out_w == 8) return d->out_h == 8 && !d->upsample && d->M >= 1024;   // two whole 8x8 images per block
   if (d->out_w != 16 && d->out_w != 32 && d->out_w != 64) return false;
   const int th = 128 / d->out_w;
-  if (d->out_h % th != 0 || d->M % 128 != 0) return false;
-  if (d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0)) return false;
-  return d->M >= 4096;      // small-M layers are weight-streaming bound: split-K implicit GEMM serves them better
+  if (d->out_h % th != 0) return false;
+  return d->M >= 4096;      // small-M layers are weight-streaming bound: the K-split tail handles them
 }
 
 template <typename T>
@@ -990,6 +997,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     }
     if (d->out_w == 64) return launch_halo<T, 64, false>(p, pl, st);
     if (d->out_w == 32) return launch_halo<T, 32, false>(p, pl, st);
+    if (d->out_w == 8) return launch_halo<T, 8, false>(p, pl, st);
     return launch_halo<T, 16, false>(p, pl, st);
   }
   switch (pl.tile) {
