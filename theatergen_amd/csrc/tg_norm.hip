@@ -55,7 +55,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
       float s[8], q[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-      for (long pix = p_begin + ty; pix < p_end; pix += p.ry) {
+      // 4 pixels per trip: four independent 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
+      long pix = p_begin + ty;
+      for (; pix + 3 * (long)p.ry < p_end; pix += 4 * (long)p.ry) {
+        typename Vec<T>::v8 v0 = gn_load8<T>(p, b, pix, c * 8);
+        typename Vec<T>::v8 v1 = gn_load8<T>(p, b, pix + p.ry, c * 8);
+        typename Vec<T>::v8 v2 = gn_load8<T>(p, b, pix + 2 * (long)p.ry, c * 8);
+        typename Vec<T>::v8 v3 = gn_load8<T>(p, b, pix + 3 * (long)p.ry, c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f0 = to_f32<T>(v0[j]), f1 = to_f32<T>(v1[j]), f2 = to_f32<T>(v2[j]), f3 = to_f32<T>(v3[j]);
+          s[j] += f0; q[j] += f0 * f0;
+          s[j] += f1; q[j] += f1 * f1;
+          s[j] += f2; q[j] += f2 * f2;
+          s[j] += f3; q[j] += f3 * f3;
+        }
+      }
+      for (; pix < p_end; pix += p.ry) {
         typename Vec<T>::v8 v = gn_load8<T>(p, b, pix, c * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -156,8 +172,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
       a[j] = rstd * ga;
       d[j] = be - mean * a[j];
     }
-    for (long pix = p_begin + ty; pix < p_end; pix += p.ry) {
-      V8 v = gn_load8<T>(p, b, pix, c * 8);
+    auto norm8 = [&](const V8& v) {
       V8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -165,7 +180,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
         if (p.silu) f = silu_f(f);
         o[j] = from_f32<T>(f);
       }
-      *reinterpret_cast<V8*>(out + ((long)b * p.hw + pix) * C + c * 8) = o;
+      return o;
+    };
+    // 4 pixels per trip: four independent loads in flight per lane, then four stores
+    long pix = p_begin + ty;
+    for (; pix + 3 * (long)p.ry < p_end; pix += 4 * (long)p.ry) {
+      const V8 v0 = gn_load8<T>(p, b, pix, c * 8);
+      const V8 v1 = gn_load8<T>(p, b, pix + p.ry, c * 8);
+      const V8 v2 = gn_load8<T>(p, b, pix + 2 * (long)p.ry, c * 8);
+      const V8 v3 = gn_load8<T>(p, b, pix + 3 * (long)p.ry, c * 8);
+      T* o0 = out + ((long)b * p.hw + pix) * C + c * 8;
+      *reinterpret_cast<V8*>(o0) = norm8(v0);
+      *reinterpret_cast<V8*>(o0 + (long)p.ry * C) = norm8(v1);
+      *reinterpret_cast<V8*>(o0 + 2 * (long)p.ry * C) = norm8(v2);
+      *reinterpret_cast<V8*>(o0 + 3 * (long)p.ry * C) = norm8(v3);
+    }
+    for (; pix < p_end; pix += p.ry) {
+      const V8 v = gn_load8<T>(p, b, pix, c * 8);
+      *reinterpret_cast<V8*>(out + ((long)b * p.hw + pix) * C + c * 8) = norm8(v);
     }
   }
 }
