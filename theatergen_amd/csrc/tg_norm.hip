@@ -211,39 +211,50 @@ int gn_nblk(int batch, long hw) {
   return (int)nblk;
 }
 
-template <typename T, int MAXC8>
+// LayerNorm: LPR lanes share one token row (64 / LPR rows per wave), each lane owns the 16-byte chunks l, l + LPR, ...
+// (MAXC of them) of its row: at C = 320 a row is 40 chunks, so one-row-per-wave left 24 of 64 lanes idle; with LPR = 8
+// every lane carries 5 chunks.  Two-pass (mean, then centred sum of squares) in registers, reductions by xor-shuffles
+// inside the LPR-lane group.
+template <typename T, int LPR, int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, int C, long ldx, float eps, const T* gamma,
                                                         const T* beta, T* out, long ldo) {
   typedef typename Vec<T>::v8 V8;
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int l = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool row_ok = row < rows;
   const int cpr = C / 8;
-  float v[MAXC8][8];
+  float v[MAXC][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC8; ++i) {
-    const int c = lane + 64 * i;
-    if (c < cpr) {
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = l + LPR * i;
+    if (row_ok && c < cpr) {
       V8 t = *reinterpret_cast<const V8*>(x + row * ldx + c * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { v[i][j] = to_f32<T>(t[j]); s += v[i][j]; }
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC8; ++i) {
-    const int c = lane + 64 * i;
-    if (c < cpr) {
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = l + LPR * i;
+    if (row_ok && c < cpr) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float dlt = v[i][j] - mean; q += dlt * dlt; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
-  for (int i = 0; i < MAXC8; ++i) {
-    const int c = lane + 64 * i;
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  if (!row_ok) return;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = l + LPR * i;
     if (c < cpr) {
       V8 o;
       V8 g8, b8;
@@ -264,16 +275,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, i
 template <typename T>
 int launch_ln(const void* x, long rows, int C, long ldx, float eps, const void* gamma, const void* beta, void* out,
               long ldo, hipStream_t st) {
-  dim3 grid((unsigned)((rows + 3) / 4));
-  const int c8 = (C / 8 + 63) / 64;
-#define LN_CASE(N)                                                                                                  \
-  hipLaunchKernelGGL((layernorm_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, rows, C, ldx, eps, (const T*)gamma, \
-                     (const T*)beta, (T*)out, ldo)
-  if (c8 <= 1) LN_CASE(1);
-  else if (c8 <= 2) LN_CASE(2);
-  else if (c8 <= 3) LN_CASE(3);
-  else if (c8 <= 4) LN_CASE(4);
-  else LN_CASE(8);
+  const int cpr = C / 8;
+#define LN_CASE(LPR, MAXC)                                                                                              \
+  hipLaunchKernelGGL((layernorm_kernel<T, LPR, MAXC>), dim3((unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
+                     dim3(256), 0, st, (const T*)x, rows, C, ldx, eps, (const T*)gamma, (const T*)beta, (T*)out, ldo)
+  if (cpr <= 8) LN_CASE(8, 1);
+  else if (cpr <= 40) LN_CASE(8, 5);          // C <= 320
+  else if (cpr <= 80) LN_CASE(16, 5);         // C <= 640
+  else if (cpr <= 160) LN_CASE(32, 5);        // C <= 1280
+  else if (cpr <= 256) LN_CASE(64, 4);
+  else LN_CASE(64, 8);
 #undef LN_CASE
   TG_LAUNCH_CHECK();
   return TG_OK;
