@@ -138,6 +138,7 @@ typedef struct {
   float scale;
   float w1;
   void* out; int64_t out_ld, out_bs;
+  int32_t causal;   /* 1: key j is visible to query i only if j <= i (segment 0; the CLIP text encoder's mask) */
 } tg_attn_desc;
 
 int tg_attention(const tg_attn_desc* d, void* stream);

@@ -54,3 +54,32 @@ def clip_vision_forward(cfg, sd, pixel_values, p="vision_model"):
     pooled = F.layer_norm(x[:, 0], (D,), sd[f"{p}.post_layernorm.weight"], sd[f"{p}.post_layernorm.bias"], eps)
     emb = F.linear(pooled, sd["visual_projection.weight"])
     return {"image_embeds": emb, "last_hidden_state": x, "hidden_states": hs}
+
+
+def clip_text_forward(cfg, sd, input_ids, p="text_model"):
+    """``transformers.CLIPTextModel`` (the SD text encoder, reference ``models/models.py:53-79`` / ``encode_prompt``): token +
+    position embeddings, the same pre-LN layers with a CAUSAL mask, final_layer_norm; pooled = state at the EOS token
+    (first occurrence of ``eos_token_id``).  cfg: dict(hidden_size, num_attention_heads, hidden_act, eos_token_id).
+    PINNED by ``tests/golden/clip_text.npz`` (captured from the installed library)."""
+    D, H, eps, act = cfg["hidden_size"], cfg["num_attention_heads"], cfg.get("layer_norm_eps", 1e-5), cfg.get("hidden_act", "quick_gelu")
+    B, L = input_ids.shape
+    x = sd[f"{p}.embeddings.token_embedding.weight"][input_ids] + sd[f"{p}.embeddings.position_embedding.weight"][:L][None]
+    mask = torch.full((L, L), float("-inf")).triu(1)
+    i = 0
+    while f"{p}.encoder.layers.{i}.layer_norm1.weight" in sd:
+        q = f"{p}.encoder.layers.{i}"
+        y = F.layer_norm(x, (D,), sd[q + ".layer_norm1.weight"], sd[q + ".layer_norm1.bias"], eps)
+        d = D // H
+        qh = F.linear(y, sd[q + ".self_attn.q_proj.weight"], sd[q + ".self_attn.q_proj.bias"]).reshape(B, L, H, d).transpose(1, 2)
+        kh = F.linear(y, sd[q + ".self_attn.k_proj.weight"], sd[q + ".self_attn.k_proj.bias"]).reshape(B, L, H, d).transpose(1, 2)
+        vh = F.linear(y, sd[q + ".self_attn.v_proj.weight"], sd[q + ".self_attn.v_proj.bias"]).reshape(B, L, H, d).transpose(1, 2)
+        a = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5 + mask, dim=-1) @ vh
+        a = a.transpose(1, 2).reshape(B, L, D)
+        x = x + F.linear(a, sd[q + ".self_attn.out_proj.weight"], sd[q + ".self_attn.out_proj.bias"])
+        y = F.layer_norm(x, (D,), sd[q + ".layer_norm2.weight"], sd[q + ".layer_norm2.bias"], eps)
+        y = _act(F.linear(y, sd[q + ".mlp.fc1.weight"], sd[q + ".mlp.fc1.bias"]), act)
+        x = x + F.linear(y, sd[q + ".mlp.fc2.weight"], sd[q + ".mlp.fc2.bias"])
+        i += 1
+    x = F.layer_norm(x, (D,), sd[f"{p}.final_layer_norm.weight"], sd[f"{p}.final_layer_norm.bias"], eps)
+    eos = (input_ids == cfg["eos_token_id"]).int().argmax(dim=-1)
+    return {"last_hidden_state": x, "pooler_output": x[torch.arange(B), eos]}

@@ -18,9 +18,47 @@ CASES = {
 }
 
 
+TEXT_CASES = {
+    # name: (vocab, hidden, intermediate, layers, heads, max_pos, act, eos)
+    "text_quick_gelu": (96, 64, 128, 3, 4, 24, "quick_gelu", 95),     # OpenAI CLIP ViT-L/14 text tower style (SD-1.5)
+    "text_gelu": (80, 64, 192, 2, 2, 77, "gelu", 79),                  # OpenCLIP style (SD-2.1), full 77-token context
+}
+
+
+def make_text(out):
+    from transformers import CLIPTextConfig, CLIPTextModel
+    for name, (vocab, hid, inter, layers, heads, max_pos, act, eos) in TEXT_CASES.items():
+        torch.manual_seed(4321 + len(name))
+        cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hid, intermediate_size=inter, num_hidden_layers=layers,
+                             num_attention_heads=heads, max_position_embeddings=max_pos, hidden_act=act,
+                             eos_token_id=eos, bos_token_id=0, pad_token_id=1)
+        m = CLIPTextModel(cfg).eval()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+            ids = torch.randint(2, eos, (3, max_pos))
+            ids[:, 0] = 0
+            for b, n in enumerate((max_pos - 1, max_pos // 2, 5)):        # EOS position, padding after it
+                ids[b, n] = eos
+                ids[b, n + 1:] = 1
+            o = m(input_ids=ids)
+        for k, v in m.state_dict().items():
+            # classic (transformers 4.x, the reference's requirement) parameter names carry the "text_model." prefix
+            kk = k if k.startswith("text_model.") else "text_model." + k
+            out[f"{name}.w.{kk}"] = v.numpy().astype(np.float32)
+        out[f"{name}.ids"] = ids.numpy()
+        out[f"{name}.last_hidden_state"] = o.last_hidden_state.numpy()
+        out[f"{name}.pooler_output"] = o.pooler_output.numpy()
+
+
 def main():
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     out = {}
+    tout = {}
+    make_text(tout)
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "clip_text.npz")
+    np.savez_compressed(tpath, **tout)
+    print("wrote", tpath, os.path.getsize(tpath) // 1024, "KiB")
     for name, (hid, inter, layers, heads, img, patch, proj, act) in CASES.items():
         torch.manual_seed(1234 + len(name))
         cfg = CLIPVisionConfig(hidden_size=hid, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,

@@ -578,6 +578,45 @@ def test_clip_vision_vs_transformers_golden(dtype, name):
     close(out.hidden_states[-2], g[name + ".penultimate"], tol, f"clip {name} penultimate")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["text_quick_gelu", "text_gelu"])
+def test_clip_text_vs_transformers_golden(dtype, name):
+    """Native CLIPTextModel (causal attention mask in the flash kernel, EOS pooling, padded prompts) vs outputs captured from
+    the installed transformers library."""
+    from tests.golden import make_clip_golden as mk
+    from theatergen_amd.clip import CLIPTextConfig, CLIPTextModel
+    g = _load("clip_text")
+    vocab, hid, inter, layers, heads, max_pos, act, eos = mk.TEXT_CASES[name]
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=hid, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                         max_position_embeddings=max_pos, hidden_act=act, layer_norm_eps=1e-5, eos_token_id=eos)
+    sd = {k[len(name) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".w.")}
+    enc = CLIPTextModel.from_state_dict(cfg, sd, device=DEV, dtype=dtype)
+    out = enc(torch.from_numpy(g[name + ".ids"]))
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    close(out[0], g[name + ".last_hidden_state"], tol, f"clip {name} last_hidden_state")
+    close(out.pooler_output, g[name + ".pooler_output"], tol, f"clip {name} pooler_output")
+
+
+def test_attention_causal_mask_kernel():
+    """tg_attention causal flag against a masked fp32 softmax: lengths that span several 64-key tiles, ragged, d = 64 / 80."""
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(17)
+    for dtype in DTYPES:
+        for (B, H, d, L) in [(2, 4, 64, 77), (1, 2, 80, 200), (2, 1, 40, 64)]:
+            D = H * d
+            q, k, v = [torch.randn(B, L, D, generator=g).to(dtype) for _ in range(3)]
+            qf, kf, vf = [t.float().reshape(B, L, H, d).transpose(1, 2) for t in (q, k, v)]
+            mask = torch.full((L, L), float("-inf")).triu(1)
+            ref = (torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5 + mask, dim=-1) @ vf).transpose(1, 2).reshape(B, L, D)
+            ldt = (L + 7) // 8 * 8
+            vt = torch.zeros(B, D, ldt, dtype=dtype)
+            vt[:, :, :L] = v.transpose(1, 2)
+            o = torch.empty(B * L, D, dtype=dtype, device=DEV)
+            ops.attention(q.reshape(B * L, D).to(DEV), D, L * D, k.reshape(B * L, D).to(DEV), D, L * D, vt.to(DEV), ldt, D * ldt, L,
+                          B, H, d, L, d ** -0.5, o, D, L * D, causal=True)
+            close(o.reshape(B, L, D), ref, op_tol(dtype), f"causal attention {(B, H, d, L)}")
+
+
 def test_clip_vit_h14_full_vs_oracle_and_embedding_cache():
     """The ViT-H/14 tower IP-Adapter uses (632 M parameters, 257 tokens, 16 heads x 80) against the pinned oracle, and the
     per-character embedding cache."""

@@ -184,3 +184,21 @@ def test_clip_vision_oracle_pinned_against_transformers():
             ref = torch.from_numpy(g[f"{name}.{key}"])
             assert got.shape == ref.shape
             assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (name, key)
+
+
+def test_clip_text_oracle_pinned_against_transformers():
+    """oracle/clip.py::clip_text_forward == transformers.CLIPTextModel (causal mask, EOS pooling) on the stored tiny models."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import clip as oc
+    from tests.golden import make_clip_golden as mk
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text.npz"))
+    for name, (vocab, hid, inter, layers, heads, max_pos, act, eos) in mk.TEXT_CASES.items():
+        sd = {k[len(name) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".w.")}
+        o = oc.clip_text_forward(dict(hidden_size=hid, num_attention_heads=heads, hidden_act=act, eos_token_id=eos), sd,
+                                 torch.from_numpy(g[name + ".ids"]))
+        for key in ("last_hidden_state", "pooler_output"):
+            ref = torch.from_numpy(g[f"{name}.{key}"])
+            assert o[key].shape == ref.shape
+            assert float((o[key] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (name, key)

@@ -35,7 +35,7 @@ class AttnDesc(C.Structure):
         ("q", vp), ("q_ld", i64), ("q_bs", i64),
         ("k0", vp), ("k0_ld", i64), ("k0_bs", i64), ("vt0", vp), ("vt0_ld", i64), ("vt0_bs", i64), ("len0", i32),
         ("k1", vp), ("k1_ld", i64), ("k1_bs", i64), ("vt1", vp), ("vt1_ld", i64), ("vt1_bs", i64), ("len1", i32),
-        ("scale", f32), ("w1", f32), ("out", vp), ("out_ld", i64), ("out_bs", i64),
+        ("scale", f32), ("w1", f32), ("out", vp), ("out_ld", i64), ("out_bs", i64), ("causal", i32),
     ]
 
 

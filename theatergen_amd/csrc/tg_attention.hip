@@ -43,6 +43,7 @@ struct AttnParams {
   float scale_log2;
   float w1;
   void* out; long out_ld, out_bs;
+  int causal;
 };
 
 // Data path: K tile = NP panels of [64 keys][64 d] and V^T tile = [DV d][64 keys], both as 128-byte LDS rows filled by
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   for (int c = 0; c < 8; ++c) vofs[c] = l31 * 64 + 4 * hi + ((c ^ skey) << 3);
   // RAW scores of one 64-key tile for this lane's query (the softmax scale is folded into the exp2 argument by one
   // fma per element); keys >= len are masked to -inf only on a ragged tile, full tiles take no compare/select at all.
-  auto scores = [&](f32x16 (&s)[2], const T* sK, int len, int kv0) {
+  auto scores = [&](f32x16 (&s)[2], const T* sK, int len, int kv0, bool causal) {
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt) {
 #pragma unroll
@@ -166,13 +167,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
         s[kvt] = mfma32(kf, qf[ks], s[kvt]);
       }
     }
-    if (kv0 + KV > len) {
+    if (kv0 + KV > len || causal) {
+      // ragged tile and / or causal mask (key j visible to query i iff j <= i: key 0 is always visible, so a row's running
+      // max is finite from the first tile on and fully masked later tiles contribute exp2(-inf) = 0)
+      const int qmax = causal ? (int)qrow : 0x7fffffff;
 #pragma unroll
       for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + kvt * 32 + mfma32_row(r, lane);
-          if (kv >= len) s[kvt][r] = -INFINITY;
+          if (kv >= len || kv > qmax) s[kvt][r] = -INFINITY;
         }
     }
   };
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     else if (p.len1 > 0) issue(kb1, p.k1_ld, vb1, p.vt1_ld, p.len1, 0, st ^ 1);
     const T* sK = sbase + st * STAGE;
     f32x16 s[2];
-    scores(s, sK, p.len0, kv0);
+    scores(s, sK, p.len0, kv0, p.causal != 0);
     // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
     // v_exp_f32 directly (__builtin_amdgcn_exp2f): arguments are <= 0, results in (0, 1], exp2(-inf) = 0 — none of
     // exp2f()'s denormal-range rescaling (v_ldexp + compares + selects per element) is needed.
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     }
     const T* sK = sbase + st * STAGE;
     f32x16 s[2];
-    scores(s, sK, p.len1, 0);
+    scores(s, sK, p.len1, 0, false);
     const float mc1 = tile_max(s) * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
@@ -430,6 +434,7 @@ extern "C" int tg_attention(const tg_attn_desc* d, void* stream) {
   p.scale_log2 = d->scale * 1.4426950408889634f;
   p.w1 = d->w1;
   p.out = d->out; p.out_ld = d->out_ld; p.out_bs = d->out_bs;
+  p.causal = d->causal;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return dispatch_attn<bf16_t>(d, p, st);
   return dispatch_attn<f16_t>(d, p, st);

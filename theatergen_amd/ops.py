@@ -165,7 +165,7 @@ def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, ups
 
 
 def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch, heads, head_dim, n_q, scale,
-              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0):
+              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0, causal=False):
     _need_cuda(q)
     d = AttnDesc()
     d.dtype = _dt(q)
@@ -179,6 +179,7 @@ def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch,
     d.len1 = int(len1)
     d.scale, d.w1 = float(scale), float(w1)
     d.out, d.out_ld, d.out_bs = _ptr(out), int(out_ld), int(out_bs)
+    d.causal = 1 if causal else 0
     _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
     return out
 
