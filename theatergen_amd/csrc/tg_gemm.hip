@@ -258,6 +258,96 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // unchanged (fp32: acc + bias + bvec + res, activation, scale, one rounding), so results are bit-identical to the
 // direct epilogue.  Columns that go to the transposed output (out_t, lane = token is already coalesced there) and
 // split-K partials keep the direct path.
+// Row loop of the LDS-transposed epilogue (see epilogue_tile_lds): straight-line per 32-row half — all residual /
+// per-batch-vector loads, then the 8 LDS writes, then ALL LDS reads of the half, then the arithmetic and the stores
+// (only the store is predicated on the row bound).  fp32: ((acc + bias) + bvec) + res, activation, * scale, one rounding;
+// x + 0 and x * 1 are exact, so this rounds the same value as the direct epilogue.
+template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES>
+__device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
+                                                  float* scr) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int W = TN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int c = lane % P, r0 = lane / P;
+  const long n = n_wave + c * 8;
+  const bool n_ok = n < p.N;
+  T* outp = reinterpret_cast<T*>(p.out);
+  const T* biasp = reinterpret_cast<const T*>(p.bias);
+  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
+  const T* resp = reinterpret_cast<const T*>(p.res);
+  const long nc = n_ok ? n : 0;                      // clamped column: loads stay in bounds, the store is predicated
+  float bias_f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
+  if (biasp != nullptr) {
+    const V8 b8 = *reinterpret_cast<const V8*>(biasp + nc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
+  }
+  const float scale = p.out_scale;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long m_first = m_wave + 32 * i + r0;
+    V8 add8[NPASS], res8[NPASS];
+    if constexpr (HAS_ADD) {
+#pragma unroll
+      for (int it = 0; it < NPASS; ++it) {
+        long m = m_first + it * RPP;
+        if (m >= p.M) m = p.M - 1;
+        add8[it] = *reinterpret_cast<const V8*>(bvecp + (m / p.rows_per_batch) * p.ldbvec + nc);
+      }
+    }
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int it = 0; it < NPASS; ++it) {
+        long m = m_first + it * RPP;
+        if (m >= p.M) m = p.M - 1;
+        res8[it] = *reinterpret_cast<const V8*>(resp + m * p.ldres + nc);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(scr + l31 * RS + 32 * j + 8 * g + 4 * hi) = o;
+      }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 lo[NPASS], hi4[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      lo[it] = *reinterpret_cast<const f32x4*>(scr + (it * RPP + r0) * RS + c * 8);
+      hi4[it] = *reinterpret_cast<const f32x4*>(scr + (it * RPP + r0) * RS + c * 8 + 4);
+    }
+    __builtin_amdgcn_wave_barrier();
+    T* op = outp + m_first * p.ldc + n;
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[it][e] + bias_f[e]; v[4 + e] = hi4[it][e] + bias_f[4 + e]; }
+      if constexpr (HAS_ADD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(add8[it][e]);
+      }
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
+      }
+      if constexpr (EPI == 1) {
+        if (p.act != TG_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+        }
+      }
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e] * scale);
+      if (m_first + it * RPP < p.M && n_ok) *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
+    }
+  }
+}
+
 template <typename T, int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
                                                   float* scr, int part, long pm0, long pn0) {
@@ -316,94 +406,17 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
       return;
     }
   }
-  constexpr int W = TN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
-  const int c = lane % P, r0 = lane / P;
-  const long n = n_wave + c * 8;
-  const bool n_ok = n < p.N;
   const T* bvecp = reinterpret_cast<const T*>(p.bvec);
   const T* resp = reinterpret_cast<const T*>(p.res);
-  // the epilogue is VALU-issue bound (it ran ~2.5 K instructions per wave and cost more than the K loop at K = 320):
-  // everything wave-uniform is hoisted or branched on, per element only the adds that are really needed remain.
-  // Skipped terms are exact no-ops (x + 0, x * 1), so every variant rounds the same fp32 value.
-  const bool has_add = bvecp != nullptr, has_res = resp != nullptr;
-  const bool unit_scale = p.out_scale == 1.f;
-  float bias_f[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
-  if (biasp != nullptr && n_ok) {
-    const V8 b8 = *reinterpret_cast<const V8*>(biasp + n);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
-  }
-  V8 zero8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) zero8[e] = from_f32<T>(0.f);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    // residual / per-batch-vector loads first: their latency overlaps the LDS bounce
-    V8 add8[NPASS], res8[NPASS];
-    const long m_first = m_wave + 32 * i + r0;
-#pragma unroll
-    for (int it = 0; it < NPASS; ++it) { add8[it] = zero8; res8[it] = zero8; }
-    if (has_add) {
-#pragma unroll
-      for (int it = 0; it < NPASS; ++it) {
-        const long m = m_first + it * RPP;
-        const bool ok = m < p.M && n_ok;
-        const long b = ok ? m / p.rows_per_batch : 0;
-        if (ok) add8[it] = *reinterpret_cast<const V8*>(bvecp + b * p.ldbvec + n);
-      }
-    }
-    if (has_res) {
-      const T* rp = resp + m_first * p.ldres + n;
-#pragma unroll
-      for (int it = 0; it < NPASS; ++it) {
-        const bool ok = m_first + it * RPP < p.M && n_ok;
-        if (ok) res8[it] = *reinterpret_cast<const V8*>(rp + (long)it * RPP * p.ldres);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(scr + l31 * RS + 32 * j + 8 * g + 4 * hi) = o;
-      }
-    __builtin_amdgcn_wave_barrier();
-    T* op = outp + m_first * p.ldc + n;
-#pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      const int r = it * RPP + r0;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
-      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
-      if (!(m_first + it * RPP < p.M && n_ok)) continue;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias_f[e]; v[4 + e] = hi4[e] + bias_f[4 + e]; }
-      if (has_add) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(add8[it][e]);
-      }
-      if (has_res) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
-      }
-      if constexpr (EPI == 1) {
-        if (p.act != TG_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-        }
-      }
-      if (!unit_scale) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-      }
-      V8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e]);
-      *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
-    }
-    __builtin_amdgcn_wave_barrier();
+  // one straight-line instance of the row loop per (per-batch vector?, residual?) combination: with the wave-uniform
+  // branches inside the loop every pass was its own basic block and the compiler exposed one LDS / load latency per
+  // pass (in-kernel s_memtime: ~7200 cycles per 128x128 tile against ~1800 per K-tile)
+  if (bvecp != nullptr) {
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true>(p, acc, m_wave, n_wave, lane, scr);
+    else epilogue_rows_lds<T, TM, TN, EPI, true, false>(p, acc, m_wave, n_wave, lane, scr);
+  } else {
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true>(p, acc, m_wave, n_wave, lane, scr);
+    else epilogue_rows_lds<T, TM, TN, EPI, false, false>(p, acc, m_wave, n_wave, lane, scr);
   }
 }
 
