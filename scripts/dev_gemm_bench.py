@@ -1,5 +1,5 @@
 """dev helper (not part of the product or the tests): time tg_gemm on UNet-representative shapes, per tile config
-and kernel generation (force_tile: 1 + tile id, +16 = v1 register-staged kernel), with a quick correctness check
+(force_tile: 1 + tile id; 0 = the heuristic incl. the LDS-halo conv kernel and the tail split), with a quick correctness check
 against torch on the GPU.  Usage: python scripts/dev_gemm_bench.py [--quick]"""
 import os
 import sys
@@ -81,7 +81,7 @@ def bench_conv(h, cin, cout, variants, c1=0, stride=1, up=False):
 if __name__ == "__main__":
     variants = [("auto(halo)", 0), ("128s2", 1)]
     if "--quick" in sys.argv:
-        variants = [("auto", 0), ("v1_128", 17), ("v2_128", 1), ("v2_256x128", 5)]
+        variants = [("auto", 0), ("128x128", 1), ("64x64", 2), ("128x128 3-stage", 5)]
     bench_conv(64, 320, 320, variants)
     bench_conv(64, 640, 320, variants, c1=320)
     bench_conv(32, 640, 640, variants)

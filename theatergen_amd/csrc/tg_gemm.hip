@@ -421,10 +421,9 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// v2: operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip,
-// no ds_write pass).  v1's staging costs 32 KB of ds_write_b128 per 128x128x64 tile (~415 LDS cycles at ~79 B/clk)
-// next to 256 cycles of fragment reads: with 512 MFMA cycles per tile per SIMD the LDS pipe, not the matrix pipe, was
-// the bound.  LDS image: unpadded 128-byte rows (the DMA destination is lane-linear), XOR-swizzled in 16-byte slots
+// Operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
+// ds_write pass).  (A first, register-staged generation of this kernel spent 32 KB of ds_write_b128 per 128x128x64 tile,
+// ~415 LDS cycles next to 256 cycles of fragment reads and 512 MFMA cycles: the LDS pipe was its bound; it is gone.)  LDS image: unpadded 128-byte rows (the DMA destination is lane-linear), XOR-swizzled in 16-byte slots
 // with key = (row >> 1) & 7; the swizzle is applied on the per-lane SOURCE address and again on the fragment read
 // (cdna guide rule 21), which makes the 16-lane ds_read_b128 groups conflict-free.  Out-of-range rows / conv padding
 // read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
