@@ -163,7 +163,7 @@ void suite(const char* src, long ld, int kt, float* out) {
 
 int main() {
   const long ld = 2560;
-  const int rows = 16 * 256, ktiles = 20;
+  const int rows = 16 * 256 * 2, ktiles = 20;
   char* src;
   float* out;
   (void)hipMalloc(&src, (size_t)rows * ld);
@@ -171,5 +171,6 @@ int main() {
   (void)hipMemset(src, 0, (size_t)rows * ld);
   suite<2, 2>(src, ld, ktiles, out);
   suite<4, 2>(src, ld, ktiles, out);
+  suite<4, 4>(src, ld, ktiles, out);   // 256x256 block tile, 4 waves of 128x128 (256 accumulator registers), 1 block / CU
   return 0;
 }
