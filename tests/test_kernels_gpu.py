@@ -92,7 +92,7 @@ def test_gemm_plain(dtype, shape):
     ref = a.float() @ w.float().t() + bias.float()
     out = ops.linear(a.to(dev), w.to(dev), bias.to(dev))
     check(out, ref, dtype, f"gemm {shape}")
-    for tile in (1, 2, 3, 4, 5):
+    for tile in (1, 2, 3, 4, 5, 6):
         out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), force_tile=tile)
         check(out, ref, dtype, f"gemm {shape} tile {tile}")
     if K >= 256:
@@ -115,7 +115,7 @@ def test_gemm_persistent_stream(shape):
     ad, wd, bd, rd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev)
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float()).cpu()
     outs = []
-    for tile in (0, 1, 2, 5):
+    for tile in (0, 1, 2, 5, 6):
         out = ops.linear(ad, wd, bd, res=rd, force_tile=tile)
         check(out, ref, dtype, f"persistent gemm {shape} tile {tile}")
         outs.append(out)
@@ -172,6 +172,9 @@ def test_gemm_fused_geglu(dtype, shape):
     ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
     wp, bp = pack_geglu(w, b)
     out = ops.gemm(a.to(dev), wp.to(dev), M, N, K, bias=bp.to(dev), geglu=True)
+    big = ops.gemm(a.to(dev), wp.to(dev), M, N, K, bias=bp.to(dev), geglu=True, force_tile=6)     # 256x256 tile, 8 waves of 128x64
+    same = torch.equal(out, big)
+    assert same
     assert out.shape == (M, N // 2)
     check(out, ref, dtype, f"fused geglu {shape}")
 

@@ -55,8 +55,11 @@ struct GemmParams {
 };
 
 struct TileCfg { int bm, bn, bk; };
-const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}};
-constexpr int kNumTiles = 5;  // id 4 = 128x128 with 3 stages (forced only)
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}};
+constexpr int kNumTiles = 6;  // id 4 = 128x128 with 3 stages (forced only);
+// id 5 = 256x256, 8 waves of 128x64, fragments read per k-step (230 VGPRs): +11..22 % over 128x128 on large plain GEMMs
+// (8192x4096x4096 929 vs 839 TF, 16384x5120x2560 1001 vs 818) but no gain at the SD-1.5 UNet's K = 320..1280 with the GEGLU
+// epilogue (scripts/dev_big_tile.py), so it is forced-only for now
 // force_tile: 1 + tile id (0 = heuristic)
 
 // tile: kTiles id; the first `full` tiles are computed whole, each of the `tail` last tiles is cut into `s` K-ranges of
@@ -598,14 +601,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
       // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
       // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
       // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
+      constexpr bool BIGW = TM * TN > 4;          // big wave tiles: fragments are read per k-step (register budget)
       V8 xf[BKT / 16][TM], wf[BKT / 16][TN];
+      if constexpr (!BIGW) {
 #pragma unroll
-      for (int ks = 0; ks < BKT / 16; ++ks) {
-        const int so = ((2 * ks + hi) ^ rkey) * 8;
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+          const int so = ((2 * ks + hi) ^ rkey) * 8;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
+          for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
+          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
@@ -616,11 +622,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < BKT / 16; ++ks)
+      for (int ks = 0; ks < BKT / 16; ++ks) {
+        if constexpr (BIGW) {
+          const int so = ((2 * ks + hi) ^ rkey) * 8;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
+      }
       // keep the MFMA chain ABOVE the wait: an asm "memory" clobber does not order register-only MFMAs, and hipcc
       // otherwise hoists `s_waitcnt vmcnt(0); s_barrier` in front of them, exposing the whole DMA latency per tile
       __builtin_amdgcn_sched_barrier(0);
@@ -918,7 +932,7 @@ Plan make_plan(const tg_gemm_desc* d) {
   // longest-K 8x8 projections; every other layer measured faster unsplit (partials cost more than the idle CUs).
   long S = 512;
   if (!halo && t == 1) S = 768;
-  if (!halo && t == 4) S = 256;
+  if (!halo && (t == 4 || t == 5)) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
   if (d->force_split_k > 0) {
@@ -959,7 +973,7 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
   const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(T);
   dim3 grid((unsigned)(pl.full + pl.tail * pl.s));
   // epilogue kind: 0 = linear only, 1 = generic (activation / GEGLU on any tile), 2 = GEGLU on the default plain tile
-  constexpr bool kMainTile = BM == 128 && BN == 128 && STAGES == 2;
+  constexpr bool kMainTile = (BM == 128 && BN == 128 && STAGES == 2) || (BM == 256 && BN == 256);   // tiles with a GEGLU-only instance
   const int epi = d->geglu ? ((kMainTile && d->mode != 1) ? 2 : 1) : (d->act == TG_ACT_NONE ? 0 : 1);
   if (d->mode == 1) {
     if (epi == 0) launch_glds<T, BM, BN, WM, WN, true, STAGES, BKT, 0>(p, grid, lds, st);
@@ -1017,7 +1031,8 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 1: return launch_cfg2<T, 64, 64, 2, 2, 3>(d, p, pl, st);
     case 2: return launch_cfg2<T, 128, 64, 4, 1, 3>(d, p, pl, st);
     case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
-    default: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
+    case 4: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
+    default: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);   // 8 waves of 128x64, 128 KB, 1 block / CU
   }
 }
 
@@ -1033,7 +1048,7 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
              TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
     const int ft = d->force_tile & 15;
-    TG_CHECK(ft == 0 || ft == 1 || ft == 5, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
+    TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
     TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
   }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
