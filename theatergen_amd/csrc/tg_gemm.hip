@@ -367,44 +367,53 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
     if (EPI == 2 || p.geglu) {
       constexpr int RS = 36;
       const int c = lane & 3, r0 = lane >> 2;       // 4 pieces x 16 rows per pass over the [32][32] result
+      // the 2 x 4 bias quads of this lane's channels do not depend on the row block: loaded once (fp32), straight-line body
+      float baf[4][4], bgf[4][4];
+      bool gok[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long na = n_wave + 4 * hi + 8 * g;
+        gok[g] = na + 32 < p.N;
+        V4 ba, bg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
+        if (biasp != nullptr && gok[g]) {
+          ba = *reinterpret_cast<const V4*>(biasp + na);
+          bg = *reinterpret_cast<const V4*>(biasp + na + 32);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { baf[g][e] = to_f32<T>(ba[e]); bgf[g][e] = to_f32<T>(bg[e]); }
+      }
+      const float scale = p.out_scale;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const long na = n_wave + 4 * hi + 8 * g;
-          f32x4 o = {0.f, 0.f, 0.f, 0.f};
-          if (na + 32 < p.N) {
-            V4 ba, bg;
+          f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
-            if (biasp != nullptr) {
-              ba = *reinterpret_cast<const V4*>(biasp + na);
-              bg = *reinterpret_cast<const V4*>(biasp + na + 32);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float a = acc[i][0][4 * g + e] + to_f32<T>(ba[e]);
-              const float gt = acc[i][1][4 * g + e] + to_f32<T>(bg[e]);
-              o[e] = a * gelu_erf_f(gt) * p.out_scale;
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[i][0][4 * g + e] + baf[g][e];
+            const float gt = acc[i][1][4 * g + e] + bgf[g][e];
+            o[e] = gok[g] ? a * gelu_erf_f(gt) * scale : 0.f;
           }
           *reinterpret_cast<f32x4*>(scr + l31 * RS + 8 * g + 4 * hi) = o;
         }
         __builtin_amdgcn_wave_barrier();
+        f32x4 lo[2], hi4[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int r = it * 16 + r0;
-          const long m = m_wave + 32 * i + r;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8);
-          const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + r * RS + c * 8 + 4);
-          if (m < p.M && n_wave + c * 8 + 32 < p.N) {
-            V8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = from_f32<T>(lo[e]); o[4 + e] = from_f32<T>(hi4[e]); }
-            *reinterpret_cast<V8*>(outp + m * p.ldc + (n_wave >> 1) + c * 8) = o;
-          }
+          lo[it] = *reinterpret_cast<const f32x4*>(scr + (it * 16 + r0) * RS + c * 8);
+          hi4[it] = *reinterpret_cast<const f32x4*>(scr + (it * 16 + r0) * RS + c * 8 + 4);
         }
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const long m = m_wave + 32 * i + it * 16 + r0;
+          V8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = from_f32<T>(lo[it][e]); o[4 + e] = from_f32<T>(hi4[it][e]); }
+          if (m < p.M && n_wave + c * 8 + 32 < p.N) *reinterpret_cast<V8*>(outp + m * p.ldc + (n_wave >> 1) + c * 8) = o;
+        }
       }
       return;
     }
