@@ -684,7 +684,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sS = reinterpret_cast<T*>(smem);                 // [NI*8][64]   halo slab of the current channel chunk
-  T* sW = sS + NI * 8 * BK;                           // [2][BN][64]  weight tiles (double-buffered)
+  // weight-tile ring: 3 stages (2 tiles in flight) wherever slab + 3 x 16 KB still lets two blocks share a CU (every
+  // variant but the 64-wide one): a K-step's period was one DMA round trip of the next W tile, not its 16 MFMAs
+  constexpr int WST = ((size_t)NI * 8 * BK + 3 * BN * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
+  constexpr int WD = WST - 1;                          // W tiles issued ahead of the one being multiplied
+  T* sW = sS + NI * 8 * BK;                           // [WST][BN][64]  weight tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -792,15 +796,23 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   int c_end = part >= 0 ? c_begin + p.kt_per_split : nchunks;
   if (c_end > nchunks) c_end = nchunks;
 
+  const int nkt = (c_end - c_begin) * 9;
+  int icc = c_begin, itap = 0;                         // (chunk, tap) of the next W tile to request
   issue_slab(c_begin);
-  issue_w(c_begin, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s_ = 0; s_ < WD; ++s_) {
+    if (s_ < nkt) {
+      issue_w(icc, itap, s_);
+      if (++itap == 9) { itap = 0; ++icc; }
+    }
+  }
+  if (WD == 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  const int nkt = (c_end - c_begin) * 9;
   int cc = c_begin, tap = 0;
+  int buf = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
     const int ky = tap / 3, kx = tap - ky * 3;
     const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
     V8 xf[BK / 16][TM], wf[BK / 16][TN];
@@ -830,7 +842,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         issue_slab(ncc);
       }
-      issue_w(ncc, ntap, buf ^ 1);
+    }
+    if (kt + WD < nkt) {
+      int nb = buf + WD;
+      if (nb >= WST) nb -= WST;
+      issue_w(icc, itap, nb);
+      if (++itap == 9) { itap = 0; ++icc; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -840,10 +857,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the W tile of step kt+1 (and a slab requested in this step, which is older than this step's W request) must have
+    // landed; the W tile requested in this step may stay in flight
+    if (WD == 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     cc = ncc;
     tap = ntap;
+    buf = buf + 1 == WST ? 0 : buf + 1;
   }
 
   epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
@@ -869,7 +890,8 @@ int launch_reduce(const GemmParams& p, const Plan& pl, hipStream_t st) {
 template <typename T, int WI, bool UPS>
 int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
   constexpr int TH = 128 / WI, SLAB = WI == 8 ? 200 : (UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2)), NI = (SLAB + 7) / 8;
-  const size_t lds = ((size_t)NI * 8 * BK + 2 * 128 * BK) * sizeof(T);
+  const int wst = ((size_t)NI * 8 * BK + 3 * 128 * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
+  const size_t lds = ((size_t)NI * 8 * BK + wst * 128 * BK) * sizeof(T);
   auto k = conv_halo_kernel<T, WI, UPS>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
