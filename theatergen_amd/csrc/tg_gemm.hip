@@ -591,14 +591,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr bool BIGW = TM * TN > 4;            // big wave tiles: fragments are read per k-step (register budget)
+  // EARLY REFILL (2 stages, all fragments of a K-tile read into registers up front): a stage is dead as soon as every wave
+  // has its 16 fragments, i.e. half a K-tile before the next one starts — it is refilled right then with the tile AFTER
+  // next.  Two K-tiles are in flight with two 32 KB stages; the K-tile period was one DMA round trip (~1800 cycles against
+  // 1024 of MFMA work for the two resident blocks) and a third stage does not fit next to a second block.
+  constexpr bool ER = STAGES == 2 && !BIGW;
   if (nkt > 0) {
-    // counted waits: after issuing up to PF tiles ahead, a wave only waits until the NEXT tile's DMA has landed
-    // (vmcnt(NDMA * tiles still allowed in flight)); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
+    // counted waits: a wave only waits until the NEXT tile's DMA has landed (vmcnt(NDMA) = one younger tile may stay in
+    // flight; LDS-DMA completes in issue order); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
+    if constexpr (ER) {
+      issue_tile(kt_begin, 0);
+      if (nkt > 1) issue_tile(kt_begin + 1, 1);
+      if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
-      if (s < nkt) issue_tile(kt_begin + s, s);
-    if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int s = 0; s < PF; ++s)
+        if (s < nkt) issue_tile(kt_begin + s, s);
+      if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     const int l31 = lane & 31;
     const int hi = lane >> 5;
@@ -610,7 +623,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
       // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
       // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
       // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
-      constexpr bool BIGW = TM * TN > 4;          // big wave tiles: fragments are read per k-step (register budget)
       V8 xf[BKT / 16][TM], wf[BKT / 16][TN];
       if constexpr (!BIGW) {
 #pragma unroll
@@ -623,13 +635,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
-      if (it + PF < nkt) {
-        int nb = buf + PF;
-        if (nb >= STAGES) nb -= STAGES;
-        issue_tile(kt_begin + it + PF, nb);
+      if constexpr (!ER) {
+        // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
+        if (it + PF < nkt) {
+          int nb = buf + PF;
+          if (nb >= STAGES) nb -= STAGES;
+          issue_tile(kt_begin + it + PF, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < BKT / 16; ++ks) {
         if constexpr (BIGW) {
@@ -639,6 +653,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
 #pragma unroll
           for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
         }
+        if constexpr (ER) {
+          if (ks == BKT / 32) {
+            // half of the chain is issued: by now every fragment has landed in registers -> the stage is free
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (it + 2 < nkt) issue_tile(kt_begin + it + 2, buf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -647,8 +671,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
       // keep the MFMA chain ABOVE the wait: an asm "memory" clobber does not order register-only MFMAs, and hipcc
       // otherwise hoists `s_waitcnt vmcnt(0); s_barrier` in front of them, exposing the whole DMA latency per tile
       __builtin_amdgcn_sched_barrier(0);
-      // tile it+1 must have landed; tiles it+2 .. it+PF (if issued) may stay in flight
-      if (PF >= 2 && it + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      // tile it+1 must have landed; a younger tile (if issued) may stay in flight
+      if ((ER || PF >= 2) && it + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       buf = buf + 1 == STAGES ? 0 : buf + 1;
