@@ -241,12 +241,17 @@ int tg_masked_compose(float* dst, const float* src, const float* mask, int64_t p
  *    out[0] += fg_w * sum_h (1 - fg) + bg_w * sum_h bg   (scaled by `scale`)
  *    grad (may be NULL) [heads, hw, n_tok] += d out / d A.
  * tg_guidance_ratio: out[0] += scale * mean_h (1 - sum(A*M)/sum(A))^2  (+ grad)
+ * tg_guidance_ref (attention transfer, utils/guidance.py:150-242, inner term :223-233): ref fp32 [heads, hw] (the saved
+ *    reference column ``ref_ca_saved_attns[obj][index][key][0, :, :, 0]``):
+ *    out[0] += scale * mean_h sum_i | A_i M_i / (sum(A M) + eps) - R_i M_i / (sum(R M) + eps) |   (+ grad wrt A)
  */
 int tg_guidance_topk(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* mask,
                      int32_t k_fg, int32_t k_bg, float fg_w, float bg_w, float scale, float* out, float* grad,
                      void* stream);
 int tg_guidance_ratio(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* mask,
                       float scale, float* out, float* grad, void* stream);
+int tg_guidance_ref(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* ref,
+                    const float* mask, float eps, float scale, float* out, float* grad, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

@@ -487,3 +487,30 @@ def test_guidance_reductions():
             assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (nbox, kw, loss.item(), ref.item())
             for k, rg in zip(keys, ref_grads):
                 assert torch.allclose(grads[k].cpu(), rg, rtol=1e-4, atol=1e-7), (nbox, k)
+
+
+def test_guidance_reference_attention_transfer():
+    """compute_ca_lossv3 with ref_ca_saved_attns (reference utils/guidance.py:150-242): value and d loss / d A vs the
+    oracle (itself pinned on the imported reference's ``guid.2.withref.loss``)."""
+    from oracle import guidance_loss as og
+    from tests.golden import gen_common as gc
+    from theatergen_amd import guidance as G
+    dev = _dev()
+    keys = gc.GUIDANCE_KEYS
+    g = torch.Generator().manual_seed(77)
+    maps, _ = gc.guidance_attn_maps(2)
+    refs = gc.guidance_ref_maps(g)
+    for kw in (dict(ref_ca_last_token_only=True), dict(ref_ca_last_token_only=False),
+               dict(ref_ca_word_token_only=True, word_token_indices=[3, 7])):
+        args = dict(ref_ca_saved_attns=refs, index=3, ref_ca_loss_weight=2.0, use_ratio_based_loss=False, **kw)
+        saved = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+        want = og.compute_ca_lossv3(saved, gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2], keys, **args)
+        want_grads = torch.autograd.grad(want, [saved[k] for k in keys])
+        dmaps = {k: v.to(dev) for k, v in maps.items()}
+        loss, grads = G.compute_ca_lossv3(dmaps, gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2], keys, return_grads=True,
+                                          **args)
+        assert abs(loss.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (kw, loss.item(), want.item())
+        for k, rg in zip(keys, want_grads):
+            assert torch.allclose(grads[k].cpu(), rg, rtol=1e-4, atol=1e-6), (kw, k)
+        plain = G.compute_ca_lossv3(dmaps, gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2], keys, **args)
+        assert abs(plain.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))

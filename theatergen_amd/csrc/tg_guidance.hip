@@ -119,7 +119,67 @@ __global__ __launch_bounds__(64 * G_WAVES) void guidance_ratio_kernel(const floa
   }
 }
 
+// attention-transfer term (utils/guidance.py:223-233): per head, the masked current column and the masked reference
+// column are each normalised by (their sum + eps); loss = mean over heads of the L1 distance.  ref: [heads, hw].
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_ref_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                    const float* ref, const float* mask, float eps,
+                                                                    float scale, float* out, float* grad) {
+  extern __shared__ float head_loss[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int h = wave; h < heads; h += G_WAVES) {
+    const float* col = attn + (long)h * hw * n_tok + token;
+    const float* rcol = ref + (long)h * hw;
+    float cs = 0.f, rs = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+      const float m = mask[i];
+      cs += col[(long)i * n_tok] * m;
+      rs += rcol[i] * m;
+    }
+    const float ci = 1.f / (wave_sum(cs) + eps);
+    const float ri = 1.f / (wave_sum(rs) + eps);
+    float l1 = 0.f, sc = 0.f;                          // sc = sum_i sign(d_i) * cm_i  (for the gradient)
+    for (int i = lane; i < hw; i += 64) {
+      const float m = mask[i];
+      const float cm = col[(long)i * n_tok] * m * ci;
+      const float d = cm - rcol[i] * m * ri;
+      l1 += fabsf(d);
+      sc += (d > 0.f ? cm : (d < 0.f ? -cm : 0.f));
+    }
+    l1 = wave_sum(l1);
+    sc = wave_sum(sc);
+    if (lane == 0) head_loss[h] = l1;
+    if (grad) {
+      float* gcol = grad + (long)h * hw * n_tok + token;
+      const float c = scale / (float)heads * ci;
+      for (int i = lane; i < hw; i += 64) {
+        const float m = mask[i];
+        const float d = col[(long)i * n_tok] * m * ci - rcol[i] * m * ri;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        gcol[(long)i * n_tok] += c * m * (sg - sc);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int h = 0; h < heads; ++h) s += head_loss[h];
+    out[0] += scale * s / (float)heads;
+  }
+}
+
 }  // namespace
+
+extern "C" int tg_guidance_ref(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token,
+                               const float* ref, const float* mask, float eps, float scale, float* out, float* grad,
+                               void* stream) {
+  TG_CHECK(attn && ref && mask && out && heads > 0 && hw > 0 && n_tok > 0 && token >= 0 && token < n_tok, TG_ERR_ARG,
+           "tg_guidance_ref: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(guidance_ref_kernel, dim3(1), dim3(64 * G_WAVES), heads * sizeof(float), st, attn, heads, hw, n_tok,
+                     token, ref, mask, eps, scale, out, grad);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
 
 extern "C" int tg_guidance_topk(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token,
                                 const float* mask, int32_t k_fg, int32_t k_bg, float fg_w, float bg_w, float scale,

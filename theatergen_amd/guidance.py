@@ -50,13 +50,53 @@ def add_ca_loss_per_attn_map_to_loss(loss, attn_map, object_number, bboxes, obje
     return loss
 
 
+def add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bboxes, object_positions, guidance_attn_keys,
+                                           ref_ca_saved_attns, ref_ca_last_token_only, ref_ca_word_token_only,
+                                           word_token_indices, index, loss_weight, eps=1e-5, verbose=False, grads=None,
+                                           scale=1.0):
+    """reference guidance.py:150-242 (attention transfer from saved per-box reference maps).  ``loss``: fp32 device
+    scalar tensor [1] accumulated IN PLACE; ``grads``: optional {key: fp32 tensor like saved_attn[key]} accumulated in
+    place; ``scale`` multiplies every added term (compute_ca_lossv3's 1 / (n_obj * n_keys))."""
+    if loss_weight == 0.0:                                    # :156-157
+        return loss
+    for obj_idx in range(object_number):
+        obj_boxes = bboxes[obj_idx]
+        refs = ref_ca_saved_attns[obj_idx]
+        if not isinstance(obj_boxes[0], Iterable):            # :163-166
+            obj_boxes, refs = [obj_boxes], [refs]
+        assert len(obj_boxes) == len(refs), f"{len(obj_boxes)} != {len(refs)}"
+        if ref_ca_word_token_only:                            # :207-217
+            positions = [word_token_indices[obj_idx]]
+        elif ref_ca_last_token_only:
+            positions = [object_positions[obj_idx][-1]]
+        else:
+            positions = object_positions[obj_idx]
+        term = scale * loss_weight / (len(obj_boxes) * len(positions))       # :237
+        for bx, ref in zip(obj_boxes, refs):
+            ref = ref[index]
+            for key in guidance_attn_keys:
+                amap = saved_attn[key]
+                amap3 = (amap.squeeze(dim=0) if amap.dim() == 4 else amap).contiguous()
+                b, i, _ = amap3.shape
+                H = W = int(math.sqrt(i))
+                rmap = ref[key]
+                assert rmap.ndim == 4                         # [1, heads, HW, 1]  (:184-186)
+                rcol = rmap[0, :, :, 0].to(device=amap3.device, dtype=torch.float32).contiguous()
+                _, mask = _box_mask(bx, H, W, amap3.device)
+                g = None
+                if grads is not None:
+                    g = grads[key]
+                    g = g.squeeze(dim=0) if g.dim() == 4 else g
+                for pos in positions:
+                    ops.guidance_ref(amap3, pos, rcol, mask, eps, term, loss, g)
+    return loss
+
+
 def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, ref_ca_saved_attns=None,
                       ref_ca_last_token_only=True, ref_ca_word_token_only=False, word_token_indices=None, index=None,
                       ref_ca_loss_weight=1.0, verbose=False, return_grads=False, **kwargs):
-    """reference guidance.py:244-286 (the reference-attention transfer term :150-242 is not on the HIP path:
-    pass ``ref_ca_saved_attns=None``)."""
-    if ref_ca_saved_attns is not None:
-        raise RuntimeError("theatergen_amd.guidance: ref_ca_saved_attns (attention-transfer loss) is not implemented in HIP")
+    """reference guidance.py:244-286, including the reference-attention transfer term (:150-242, :278-284) when
+    ``ref_ca_saved_attns`` is given."""
     object_number = len(bboxes)
     dev = None
     for k in guidance_attn_keys:
@@ -77,6 +117,11 @@ def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, 
             g = torch.zeros_like(amap3)
             grads[key] = g.reshape(amap.shape)
         add_ca_loss_per_attn_map_to_loss(loss, amap3, object_number, bboxes, object_positions, grad=g, scale=norm, **kwargs)
+    if ref_ca_saved_attns is not None:
+        add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bboxes, object_positions, guidance_attn_keys,
+                                               ref_ca_saved_attns, ref_ca_last_token_only, ref_ca_word_token_only,
+                                               word_token_indices, index, ref_ca_loss_weight,
+                                               grads=grads if return_grads else None, scale=norm)
     return (loss[0], grads) if return_grads else loss[0]
 
 

@@ -334,6 +334,15 @@ def guidance_topk(attn, token, mask, k_fg, k_bg, fg_w, bg_w, scale, out, grad=No
                                            float(fg_w), float(bg_w), float(scale), _ptr(out), _ptr(grad), _stream()))
 
 
+def guidance_ref(attn, token, ref, mask, eps, scale, out, grad=None):
+    """attn fp32 [heads, hw, tokens]; ref fp32 [heads, hw] contiguous"""
+    heads, hw, n_tok = attn.shape
+    if ref.dtype != torch.float32 or ref.numel() != heads * hw or not ref.is_contiguous():
+        raise RuntimeError("guidance_ref: ref must be a contiguous fp32 [heads, hw] column")
+    _lib.check(_lib.lib().tg_guidance_ref(_ptr(attn), heads, hw, n_tok, int(token), _ptr(ref), _ptr(mask), float(eps),
+                                          float(scale), _ptr(out), _ptr(grad), _stream()))
+
+
 def guidance_ratio(attn, token, mask, scale, out, grad=None):
     heads, hw, n_tok = attn.shape
     _lib.check(_lib.lib().tg_guidance_ratio(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), float(scale), _ptr(out),
