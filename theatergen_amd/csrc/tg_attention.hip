@@ -149,11 +149,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   const int skey = (l31 >> 1) & 7;                       // swizzle key of this lane's fragment rows
   // per-lane LDS element offsets of the fragment reads, computed ONCE (they only depend on the lane): inside the loop an
   // access is (stage base + table entry + compile-time constant) instead of re-deriving xor / shift / add per read
-  int kofs[4], vofs[8];
+  // KEY PERMUTATION: MFMA row i of a 32-key score tile is fed K row perm(i) = i with bits 2 and 3 swapped.  The 32x32
+  // accumulator gives lane-half `hi` the rows 8g + 4 hi + j in registers 4g + j; with the permutation registers
+  // 8cc .. 8cc+7 hold the 8 CONSECUTIVE keys 16cc + 8 hi + 0..7, i.e. the P^T fragment of the PV MFMA pairs with ONE
+  // 16-byte V^T slot (a single ds_read_b128 per fragment, no register shuffles) instead of two 8-byte halves of
+  // neighbouring slots.
+  const int prow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int pkey = (prow >> 1) & 7;
+  int kofs[4], vofs[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) kofs[c] = l31 * 64 + (((2 * c + hi) ^ skey) << 3);
+  for (int c = 0; c < 4; ++c) kofs[c] = prow * 64 + (((2 * c + hi) ^ pkey) << 3);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) vofs[c] = l31 * 64 + 4 * hi + ((c ^ skey) << 3);
+  for (int c = 0; c < 4; ++c) vofs[c] = l31 * 64 + (((2 * c + hi) ^ skey) << 3);
   // RAW scores of one 64-key tile for this lane's query (the softmax scale is folded into the exp2 argument by one
   // fma per element); keys >= len are masked to -inf only on a ragged tile, full tiles take no compare/select at all.
   auto scores = [&](f32x16 (&s)[2], const T* sK, int len, int kv0, bool causal) {
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
       for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kv = kv0 + kvt * 32 + mfma32_row(r, lane);
+          const int kv = kv0 + kvt * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);     // key held by register r (permuted rows)
           if (kv >= len || kv > qmax) s[kvt][r] = -INFINITY;
         }
     }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   };
 
   // O^T += V^T * P^T for one tile; P^T comes straight from the score registers: chunk c covers keys
-  // kvt*32 + 16*cc + {4*hi .. +3, 8 + 4*hi .. +3}, i.e. 8 bytes at offset 8*hi of two neighbouring 16-byte slots
+  // kvt*32 + 16*cc + 8*hi + 0..7 = 16-byte slot 4*kvt + 2*cc + hi of the V^T row
   auto pv = [&](const f32x16 (&s)[2], const T* sV) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -199,14 +206,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
       V8 pf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[kvt][8 * cc + j]);
-      const int s0 = 4 * kvt + 2 * cc;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        V4 lo = *reinterpret_cast<const V4*>(sV + vofs[s0] + t * 32 * 64);
-        V4 hi4 = *reinterpret_cast<const V4*>(sV + vofs[s0 + 1] + t * 32 * 64);
-        V8 vf;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
+        const V8 vf = *reinterpret_cast<const V8*>(sV + vofs[c] + t * 32 * 64);
         o[t] = mfma32(vf, pf, o[t]);
       }
     }
