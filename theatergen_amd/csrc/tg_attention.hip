@@ -236,11 +236,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     f32x16 s[2];
     scores(s, sK, p.len0, kv0, p.causal != 0);
     // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
-    // v_exp_f32 directly (__builtin_amdgcn_exp2f): arguments are <= 0, results in (0, 1], exp2(-inf) = 0 — none of
+    // v_exp_f32 directly (__builtin_amdgcn_exp2f): results stay far inside the fp32 range, exp2(-inf) = 0 — none of
     // exp2f()'s denormal-range rescaling (v_ldexp + compares + selects per element) is needed.
-    const float m_new = fmaxf(m_run, tile_max(s));
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-    const float mc = m_new * p.scale_log2;
+    // LAZY RUNNING MAX: softmax is invariant to the reference point, so m_run only moves (and O is only rescaled: 32
+    // accumulator multiplies per tile) when some row's tile max exceeds it by more than LAZY_LOG2 in exp2 units; until
+    // then probabilities are formed against the stale reference and are at most 2^LAZY_LOG2 (bf16 P and the fp32
+    // accumulators have the range).  With a strict "any row has a new max" test the rescale ran on most tiles: over 32
+    // rows a new maximum keeps turning up somewhere.
+    constexpr float LAZY_LOG2 = 8.f;
+    const float tm = tile_max(s);
+    if (__any(tm * p.scale_log2 > m_run * p.scale_log2 + LAZY_LOG2)) {
+      const float m_new = fmaxf(m_run, tm);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+#pragma unroll
+      for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+      if (!ONES) l_run *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt)
@@ -250,16 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
         s[kvt][r] = e;
         if (!ONES) ps += e;
       }
-    if (!ONES) l_run = l_run * alpha + ps;
-    // exact skip of the O rescale: when no lane of the wave raised its running max, alpha == 1 everywhere
-    // (after the first few tiles this is the common case; it saves 32 accumulator reads + muls + writes per tile)
-    if (__any(m_new > m_run)) {
-#pragma unroll
-      for (int t2 = 0; t2 < DT; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
-    }
-    m_run = m_new;
+    if (!ONES) l_run += ps;
     pv(s, sK + K_ELEMS);
   }
   {
