@@ -194,7 +194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvt][r]);
-    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // the other 32-key half of the row lives in lane ^ 32: v_permlane32_swap exchanges the upper 32 lanes of one copy
+    // with the lower 32 of the other (no LDS round trip, unlike the ds_bpermute behind __shfl_xor)
+    // (inline asm: with the builtin hipcc drops the second result and the max with it; s_nop covers the VALU-write ->
+    // permlane-read hazard the assembler does not see)
+    float a = mx, b = mx;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
   };
 
   // O^T += V^T * P^T for one tile; P^T comes straight from the score registers: chunk c covers keys
