@@ -36,3 +36,26 @@ torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / iters * 1e3
 flops = 4.0 * L * L * D * B * H
 print(f"self-attention {B}x{H}x{L}x{L} d={D}: {us:8.1f} us  {flops / us / 1e6:6.0f} TF useful")
+
+# level-0 IP-Adapter cross-attention: 4096 queries x (77 text + 4 image) keys
+Lk, Li = 77, 4
+kc = torch.randn(B * Lk, C, generator=g).to(dev, torch.bfloat16)
+vtc = torch.randn(B, C, 80, generator=g).to(dev, torch.bfloat16)          # V^T rows padded to a 16-byte pitch
+ki = torch.randn(B * Li, C, generator=g).to(dev, torch.bfloat16)
+vti = torch.randn(B, C, 8, generator=g).to(dev, torch.bfloat16)
+
+
+def run_cross():
+    ops.attention(q, C, L * C, kc, C, Lk * C, vtc, 80, C * 80, Lk, B, H, D, L, D ** -0.5, out, C, L * C,
+                  k1=ki, k1_ld=C, k1_bs=Li * C, vt1=vti, vt1_ld=8, vt1_bs=C * 8, len1=Li, w1=1.0)
+
+
+for _ in range(3):
+    run_cross()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(iters):
+    run_cross()
+e1.record()
+torch.cuda.synchronize()
+print(f"cross-attention 4096 x (77 + 4): {e0.elapsed_time(e1) / iters * 1e3:8.1f} us")
