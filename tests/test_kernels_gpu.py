@@ -270,7 +270,10 @@ def test_gemm_tail_split(kind, shape):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 64, 320, 0, True), (2, 256, 1280, 640, True), (1, 16, 64, 0, False), (3, 100, 128, 64, True),
-                                  (2, 4096, 320, 0, True), (2, 64, 2560, 0, True)])
+                                  (2, 4096, 320, 0, True), (2, 64, 2560, 0, True),
+                                  # one-launch small-map path (hw <= 256, channels per group a multiple of 8)
+                                  (2, 64, 1280, 0, True), (2, 256, 1280, 1280, True), (3, 256, 1280, 0, False),
+                                  (2, 100, 256, 0, True), (1, 16, 512, 256, True), (2, 250, 1024, 0, True)])
 def test_groupnorm(dtype, case):
     from theatergen_amd import ops
     dev = _dev()

@@ -202,6 +202,139 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
   }
 }
 
+// SMALL MAPS (hw <= 256: the 16x16 and 8x8 levels) in ONE launch: a block owns one batch item x `gpb` whole groups
+// (nc = gpb * cpg / 8 chunk columns of 16 bytes), keeps its whole slab in registers (thread = (chunk column c, pixel lane
+// py), MAXP pixels each), and does mean -> centred variance -> normalise (+SiLU) -> store without going back to memory.
+// The two-launch path costs >= 11 us on these maps (two launches + the partials round trip) for 3-20 MB of data.
+// Needs cpg % 8 == 0 (a 16-byte chunk never straddles groups).  Deterministic: fixed-order LDS folds.
+template <typename T, int MAXP>
+__global__ __launch_bounds__(256) void gn_small_kernel(GnParams p, int gpb, int nc, int npy) {
+  typedef typename Vec<T>::v8 V8;
+  __shared__ float red[256];
+  __shared__ float col[256];
+  __shared__ float gstat[32];
+  const int C = p.c0 + p.c1;
+  const int cpg = C / p.groups;
+  const int ccg = cpg / 8;                     // chunks per group
+  const int b = blockIdx.y;
+  const int c = threadIdx.x % nc, py = threadIdx.x / nc;
+  const bool active = py < npy;
+  const int ch0 = blockIdx.x * gpb * cpg + c * 8;
+  const int hw = (int)p.hw;
+  V8 v[MAXP];
+  V8 gv, bv;                                     // gamma / beta of this thread's 8 channels: requested with the slab
+  const T* gam = reinterpret_cast<const T*>(p.gamma);
+  const T* bet = reinterpret_cast<const T*>(p.beta);
+  if (active) {
+    if (gam) gv = *reinterpret_cast<const V8*>(gam + ch0);
+    if (bet) bv = *reinterpret_cast<const V8*>(bet + ch0);
+  }
+  float s = 0.f;
+  if (active) {
+    // every load is issued before the first use (out-of-range pixels re-read the last one and are ignored below): with
+    // a branch around each load the compiler serialises load -> wait -> add and the kernel is one latency chain
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int pix = py + i * npy;
+      v[i] = gn_load8<T>(p, b, pix < hw ? pix : hw - 1, ch0);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (py + i * npy < hw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += to_f32<T>(v[i][j]);
+      }
+    }
+    red[py * nc + c] = s;
+  }
+  __syncthreads();
+  const float inv_n = 1.f / ((float)hw * (float)cpg);
+  // fixed-order fold in two short steps (column sums over the pixel lanes, then the ccg columns of a group): one
+  // thread per group walking all npy * ccg entries was a serial chain of dependent LDS reads, ~2.5 us per fold
+  if ((int)threadIdx.x < nc) {
+    float t = 0.f;
+    for (int y = 0; y < npy; ++y) t += red[y * nc + threadIdx.x];
+    col[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < gpb) {
+    float t = 0.f;
+    for (int k = 0; k < ccg; ++k) t += col[threadIdx.x * ccg + k];
+    gstat[threadIdx.x] = t * inv_n;
+  }
+  __syncthreads();
+  const float mean = active ? gstat[c / ccg] : 0.f;
+  float q = 0.f;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int pix = py + i * npy;
+      if (pix < hw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = to_f32<T>(v[i][j]) - mean;
+          q += d * d;
+        }
+      }
+    }
+    red[py * nc + c] = q;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nc) {
+    float t = 0.f;
+    for (int y = 0; y < npy; ++y) t += red[y * nc + threadIdx.x];
+    col[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < gpb) {
+    float t = 0.f;
+    for (int k = 0; k < ccg; ++k) t += col[threadIdx.x * ccg + k];
+    gstat[16 + threadIdx.x] = rsqrtf(t * inv_n + p.eps);
+  }
+  __syncthreads();
+  if (!active) return;
+  const float rstd = gstat[16 + c / ccg];
+  float a[8], d[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float ga = gam ? to_f32<T>(gv[j]) : 1.f;
+    const float be = bet ? to_f32<T>(bv[j]) : 0.f;
+    a[j] = rstd * ga;
+    d[j] = be - mean * a[j];
+  }
+  T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int pix = py + i * npy;
+    if (pix < hw) {
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = to_f32<T>(v[i][j]) * a[j] + d[j];
+        if (p.silu) f = silu_f(f);
+        o[j] = from_f32<T>(f);
+      }
+      *reinterpret_cast<V8*>(out + ((long)b * hw + pix) * C + ch0) = o;
+    }
+  }
+}
+
+// geometry of the one-launch path; false -> use the two-launch path
+bool gn_small_plan(int C, int groups, long hw, int* gpb, int* nc, int* npy, int* maxp) {
+  const int cpg = C / groups;
+  if (hw > 256 || cpg % 8 != 0) return false;
+  int g = 1;
+  while (g < groups && (g * cpg < 64 || groups % g != 0)) ++g;       // >= 128 contiguous bytes per pixel per block
+  if (groups % g != 0 || g > 16) return false;
+  const int n = g * cpg / 8;
+  if (n > 256) return false;
+  const int y = 256 / n;
+  const int mp = (int)((hw + y - 1) / y);
+  if (mp > 24) return false;
+  *gpb = g; *nc = n; *npy = y; *maxp = mp;
+  return true;
+}
+
 int gn_nblk(int batch, long hw) {
   long target = 1024 / (batch > 0 ? batch : 1);
   if (target < 1) target = 1;
@@ -310,13 +443,32 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
   GnParams p{};
   p.x0 = x0; p.x1 = x1; p.c0 = c0; p.c1 = c1; p.batch = batch; p.hw = hw; p.groups = groups; p.eps = eps;
   p.gamma = gamma; p.beta = beta; p.silu = silu; p.out = out;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    int gpb, nc, npy, maxp;
+    const bool vec_ok = reinterpret_cast<uintptr_t>(gamma) % 16 == 0 && reinterpret_cast<uintptr_t>(beta) % 16 == 0;
+    if (vec_ok && gn_small_plan(C, groups, hw, &gpb, &nc, &npy, &maxp)) {
+      dim3 grid(groups / gpb, batch);
+#define TG_GN_SMALL(MP)                                                                                             \
+  do {                                                                                                              \
+    if (dtype == TG_BF16) hipLaunchKernelGGL((gn_small_kernel<bf16_t, MP>), grid, dim3(256), 0, st, p, gpb, nc, npy); \
+    else hipLaunchKernelGGL((gn_small_kernel<f16_t, MP>), grid, dim3(256), 0, st, p, gpb, nc, npy);                   \
+  } while (0)
+      if (maxp <= 3) TG_GN_SMALL(3);
+      else if (maxp <= 6) TG_GN_SMALL(6);
+      else if (maxp <= 12) TG_GN_SMALL(12);
+      else TG_GN_SMALL(24);
+#undef TG_GN_SMALL
+      TG_LAUNCH_CHECK();
+      return TG_OK;
+    }
+  }
   p.nblk = gn_nblk(batch, hw);
   p.partials = reinterpret_cast<float*>(partials);
   p.stats = p.partials + (long)batch * p.nblk * groups * 2;
   const int cpr = C / 8;
   p.cx = cpr < 256 ? cpr : 256;
   p.ry = 256 / p.cx;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(p.nblk, batch);
   const size_t lds = (size_t)p.ry * 2 * C * sizeof(float);
   if (dtype == TG_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, st, p);
