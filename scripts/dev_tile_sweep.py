@@ -17,8 +17,8 @@ def case(M, N, K, geglu=False):
     a = torch.randn(M, K, device=dev).to(dt); ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(dt) for _ in range(NCOPY)]
     b = torch.randn(N, device=dev).to(dt); r = None if geglu else torch.randn(M, N, device=dev).to(dt)
     out = []
-    for ft in (0, 2, 3, 4, 5):
-        if geglu and ft not in (0, 2, 5): continue
+    for ft in (0, 1, 2, 3, 4, 5, 6):
+        if geglu and ft not in (0, 1, 2, 5, 6): continue
         try:
             t = timeit([(lambda w=w: ops.gemm(a, w, M, N, K, bias=b, res=r, geglu=geglu, force_tile=ft)) for w in ws])
             out.append(f"t{ft}:{t:7.1f}")
