@@ -335,8 +335,10 @@ bool gn_small_plan(int C, int groups, long hw, int* gpb, int* nc, int* npy, int*
   return true;
 }
 
+// pixel slabs per batch item: 512 blocks in all (2 per CU).  More slabs mean more partials for every apply block's
+// statistics prologue to fold: 2048 blocks -2 % end to end, 1024 the previous default, 512 +0.6 %, 256 +0.2 %.
 int gn_nblk(int batch, long hw) {
-  long target = 1024 / (batch > 0 ? batch : 1);
+  long target = 512 / (batch > 0 ? batch : 1);
   if (target < 1) target = 1;
   long nblk = hw / 8;  // at least 8 pixels per slab
   if (nblk > target) nblk = target;
