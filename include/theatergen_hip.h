@@ -226,11 +226,14 @@ int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int
 /* ---------------------------------------------------------------------------------------------
  * Latent utilities (utils/latents.py, utils/utils.py) on fp32 latents [.., h, w]:
  * tg_blend_latents : bg (1-M) + (bg sqrt(1-r) + fg sqrt(r)) M                      (latents.py:156-166)
+ *                     storage_dtype -1: fp32 latents; TG_F16 / TG_BF16: the inputs hold half-precision values (the
+ *                     reference draws and blends in unet.dtype, latents.py:261-288) and every half-precision tensor op
+ *                     of the reference expression rounds to that type -> output exactly representable in it
  * tg_shift         : zero-filled integer shift of the last two dims               (utils.py:143-178)
  * tg_masked_compose: dst = dst (1-M) + src M over `planes` planes of h*w           (latents.py:203-214)
  */
 int tg_blend_latents(const float* bg, const float* fg, const float* mask, int32_t planes, int32_t hw, float ratio,
-                     float sigma, float* out, void* stream);
+                     float sigma, int32_t storage_dtype, float* out, void* stream);
 int tg_shift(const float* src, int64_t planes, int32_t h, int32_t w, int32_t dx, int32_t dy, float* dst, void* stream);
 int tg_masked_compose(float* dst, const float* src, const float* mask, int64_t planes, int32_t hw, void* stream);
 

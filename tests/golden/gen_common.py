@@ -70,6 +70,16 @@ def imageproj_params(seed=600):
     return sd, e
 
 
+def mlpproj_params(seed=610, clip_dim=1280, ctx=768):
+    """MLPProjModel (reference ip_adapter/ip_adapter.py:50-64): Linear -> GELU -> Linear -> LayerNorm (IP-Adapter-Full)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {"proj.0.weight": _u((clip_dim, clip_dim), clip_dim, g), "proj.0.bias": _u((clip_dim,), clip_dim, g),
+          "proj.2.weight": _u((ctx, clip_dim), clip_dim, g), "proj.2.bias": _u((ctx,), clip_dim, g),
+          "proj.3.weight": 1 + 0.1 * torch.randn(ctx, generator=g), "proj.3.bias": 0.1 * torch.randn(ctx, generator=g)}
+    e = torch.randn(2, 257, clip_dim, generator=g)
+    return sd, e
+
+
 GUIDANCE_KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
 GUIDANCE_HW = {GUIDANCE_KEYS[0]: 64, GUIDANCE_KEYS[1]: 256, GUIDANCE_KEYS[2]: 256, GUIDANCE_KEYS[3]: 256}
 GUIDANCE_BOXES = {

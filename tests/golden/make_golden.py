@@ -146,6 +146,59 @@ def gen_resampler(ref, out):
         out["imageproj.zero"] = norm(proj(torch.zeros_like(e)).reshape(-1, 4, 768)).numpy()
 
 
+def load_proj_classes():
+    """The REAL ``ImageProjModel`` / ``MLPProjModel`` classes of reference ip_adapter/ip_adapter.py:30-64.  The module itself
+    cannot be imported (it pulls diffusers pipelines at import time), so the two class definitions are cut out of its AST
+    and executed as they stand (build container only; nothing of the source is stored)."""
+    import ast
+    path = f"{REF}/ip_adapter/ip_adapter.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    wanted = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("ImageProjModel", "MLPProjModel")]
+    assert len(wanted) == 2
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), path, "exec"), ns)
+    return ns["ImageProjModel"], ns["MLPProjModel"]
+
+
+def gen_imageproj(ref, out):
+    ImageProjModel, MLPProjModel = load_proj_classes()
+    sd, e = gc.imageproj_params()
+    m = ImageProjModel(cross_attention_dim=768, clip_embeddings_dim=1024, clip_extra_context_tokens=4)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        out["imageproj.out"] = m(e).numpy()
+        out["imageproj.zero"] = m(torch.zeros_like(e)).numpy()
+    sd2, e2 = gc.mlpproj_params()
+    m2 = MLPProjModel(cross_attention_dim=768, clip_embeddings_dim=1280)
+    m2.load_state_dict(sd2)
+    with torch.no_grad():
+        out["mlpproj.out"] = m2(e2).numpy()
+        out["mlpproj.zero"] = m2(torch.zeros_like(e2)).numpy()
+
+
+def gen_latents_half(ref, out):
+    """The latent recipe with the reference's REAL adapter dtype (generate.py:77-81: fp16; bf16 for this build's bench):
+    utils/latents.py draws `torch.randn(..., dtype=unet.dtype)` on the CPU generator and blends half-precision tensors."""
+    L = ref.latents
+    boxes = [[40 / 512, 150 / 512, 230 / 512, 450 / 512], [280 / 512, 150 / 512, 470 / 512, 450 / 512]]
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        class _Cfg: in_channels = 4
+        class _Unet: config = _Cfg(); dtype = dt
+        class _Sched: init_noise_sigma = 1.0
+        class _Pipe: unet = _Unet(); scheduler = _Sched()
+        class _Adapter: pipe = _Pipe()
+        ad = _Adapter()
+        lst, bg, seeds = L.get_input_latents_list(None, bg_seed=0, fg_seed_start=123456789, fg_blending_ratio=0.01,
+                                                  height=512, width=512, adapter=ad, so_boxes=boxes)
+        assert lst[0].dtype == dt and bg.dtype == dt
+        # stored as fp32 (exact: half-precision values), compared bit for bit
+        out[f"{name}.input0"] = lst[0].float().numpy(); out[f"{name}.input1"] = lst[1].float().numpy()
+        out[f"{name}.bg"] = bg.float().numpy()
+        one = L.get_input_latents_lne(1, ad, None, bg_seed=7, fg_seed_start=7 + 123456789, fg_blending_ratio=0.01,
+                                      height=512, width=512, so_boxes=boxes)
+        out[f"{name}.lne_seed7_idx1"] = one.float().numpy()
+
+
 def gen_ff(ref, out):
     att = ref.attention
     g = torch.Generator().manual_seed(700)
@@ -268,7 +321,7 @@ def main():
     ref = load_reference()
     torch.set_num_threads(8)
     jobs = {"attn": gen_attention, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
-            "geometry_latents": gen_geometry_latents}
+            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

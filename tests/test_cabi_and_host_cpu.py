@@ -136,6 +136,44 @@ def test_parameter_tables_and_module_keys():
     assert names[0] == "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor"
     assert names[1] == "down_blocks.0.attentions.0.transformer_blocks.0.attn2.processor"
     assert sum(n.startswith("mid_block") for n in names) == 2 and len(names) == 32
+    # diffusers order = down (0-11), up (12-29), mid (30-31): the reference registers both block lists before mid_block
+    # (models/unet_2d_condition.py:430-431), and IP-Adapter checkpoints index `ip_adapter.{1,3,..,31}` by that order
+    assert all(n.startswith("down_blocks") for n in names[:12])
+    assert names[12].startswith("up_blocks.1.attentions.0") and all(n.startswith("up_blocks") for n in names[12:30])
+    assert names[30] == "mid_block.attentions.0.transformer_blocks.0.attn1.processor"
+    assert names[31] == "mid_block.attentions.0.transformer_blocks.0.attn2.processor"
+
+
+def test_ip_adapter_checkpoint_keys_in_diffusers_order():
+    """A state dict keyed like a released IP-Adapter checkpoint (`{2i+1}.to_k_ip.weight` in the reference's processor
+    order, hidden sizes of the SD-1.5 plan: reference ip_adapter/ip_adapter.py:98-116, 139-140) must load through
+    `ModuleList(unet.attn_processors.values()).load_state_dict` and land on the layer it was made for."""
+    import torch
+    from theatergen_amd import config
+    from theatergen_amd.attention_processor import IPAttnProcessor
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.pipelines import SDPipe
+    from theatergen_amd.unet import UNet2DConditionModel
+    cfg = config.sd15()
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(cfg)
+    # the reference's table, written out independently of the module tree: down 320,320,640,640,1280,1280 ; up-1 1280 x3,
+    # up-2 640 x3, up-3 320 x3 ; mid 1280
+    hidden = [320, 320, 640, 640, 1280, 1280] + [1280] * 3 + [640] * 3 + [320] * 3 + [1280]
+    ad = IPAdapter.__new__(IPAdapter)
+    ad.device, ad.num_tokens, ad.pipe, ad.dtype = "meta", 4, SDPipe.__new__(SDPipe), torch.float32
+    ad.pipe.unet, ad.pipe.controlnet = unet, None
+    ad.set_ip_adapter()
+    procs = list(unet.attn_processors.values())
+    assert len(procs) == 32
+    sd = {}
+    for i, h in enumerate(hidden):
+        sd[f"{2 * i + 1}.to_k_ip.weight"] = torch.empty(h, cfg.cross_attention_dim, device="meta")
+        sd[f"{2 * i + 1}.to_v_ip.weight"] = torch.empty(h, cfg.cross_attention_dim, device="meta")
+    torch.nn.ModuleList(procs).load_state_dict(sd, assign=True)      # raises on any size / key mismatch
+    for i, h in enumerate(hidden):
+        p = procs[2 * i + 1]
+        assert isinstance(p, IPAttnProcessor) and p.hidden_size == h and tuple(p.to_k_ip.weight.shape) == (h, cfg.cross_attention_dim)
 
 
 def test_controlnet_tables_and_oracle_cpu():
@@ -216,3 +254,27 @@ def test_story_workload_and_sharding():
     items = list(range(10))
     parts = [D.shard(items, r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == items and parts[1] == [1, 5, 9]
+
+
+def test_static_slots_identity_is_the_object_not_the_address():
+    """The K / V^T and ControlNet-embedding caches (address + `_version` keys alias when the allocator reuses a
+    freed block) are keyed by the tensor OBJECT through a weak reference: a new tensor at the same address misses, and a
+    slot dies with its tensor."""
+    import gc
+    import torch
+    from theatergen_amd.attention_processor import StaticSlots, tensor_version
+    s = StaticSlots()
+    a = torch.zeros(4, 8)
+    s.put(a, {"v": 1})
+    assert s.get(a)["v"] == 1
+    alias = a.view(4, 8)                         # same storage, same address, same version: a different object -> miss
+    assert alias.data_ptr() == a.data_ptr() and alias._version == a._version and s.get(alias) is None
+    key_id = id(a)
+    del a, alias
+    gc.collect()
+    assert len(s) == 0                           # the slot (and the buffers it holds) is released with the tensor
+    b = torch.zeros(4, 8)                        # whatever id / address b gets, nothing stale can be served
+    assert s.get(b) is None and key_id is not None
+    with torch.inference_mode():
+        t = torch.ones(2)
+    assert tensor_version(t) is None and tensor_version(b) == 0

@@ -31,15 +31,14 @@ def net_tol(dtype):
     return 6e-2 if dtype == torch.bfloat16 else 1.5e-2
 
 
-def close(got, ref, tol, what):
+def close(got, ref, tol, what, l2=None):
+    """both metrics of tests/parity_metrics.py: max|err| / max|ref| <= tol AND relative L2 <= l2 (default tol / 2: an
+    error that is everywhere a sizeable fraction of the peak fails even when no single element stands out)"""
+    from tests import parity_metrics as pm
     got = torch.as_tensor(got).detach().float().cpu()
     ref = torch.as_tensor(ref).detach().float().cpu()
     assert got.shape == ref.shape, f"{what}: {got.shape} vs {ref.shape}"
-    assert torch.isfinite(got).all(), f"{what}: non-finite"
-    err = (got - ref).abs().max().item()
-    lim = tol * max(ref.abs().max().item(), 1e-6)
-    assert err <= lim, f"{what}: max err {err:.4e} > {lim:.4e}"
-    return err / max(ref.abs().max().item(), 1e-6)
+    return pm.check(got, ref, what, tol / 2 if l2 is None else l2, tol)["max_rel"]
 
 
 def _load(name):
@@ -114,8 +113,14 @@ def test_resampler_vs_reference_golden(dtype, ci, name):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_image_proj_vs_reference_golden(dtype):
-    from theatergen_amd.resampler import ImageProjModel
-    gold = _load("resampler")
+    from theatergen_amd.resampler import ImageProjModel, MLPProjModel
+    gold = _load("imageproj")                      # outputs of the reference's real classes (ip_adapter.py:30-64)
+    sd2, e2 = gc.mlpproj_params()
+    m2 = MLPProjModel(cross_attention_dim=768, clip_embeddings_dim=1280)
+    m2.load_state_dict(sd2)
+    m2 = m2.to(DEV, dtype)
+    close(m2(e2.to(DEV)), gold["mlpproj.out"], 2 * op_tol(dtype), "mlp proj")
+    close(m2(torch.zeros_like(e2).to(DEV)), gold["mlpproj.zero"], 2 * op_tol(dtype), "mlp proj zero")
     sd, e = gc.imageproj_params()
     m = ImageProjModel(cross_attention_dim=768, clip_embeddings_dim=1024, clip_extra_context_tokens=4)
     m.load_state_dict(sd)
@@ -708,6 +713,19 @@ def test_latent_utilities_vs_reference_golden():
         assert torch.allclose(lst[i].cpu(), torch.from_numpy(gold[f"lat.input{i}"]), rtol=1e-6, atol=1e-6)
     one = L.get_input_latents_lne(1, ad, None, 7, 7 + 123456789, 0.01, 512, 512, so_boxes=boxes[:2])
     assert torch.allclose(one.cpu(), torch.from_numpy(gold["lat.lne_seed7_idx1"]), rtol=1e-6, atol=1e-6)
+    # the reference's real adapter dtype (fp16, generate.py:77-81; bf16 = this build's bench dtype): drawn AND blended in
+    # that dtype -> bit-exact against the imported reference
+    goldh = _load("latents_half")
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        _Unet.dtype = dt
+        lst, bg, _ = L.get_input_latents_list(None, 0, 123456789, 0.01, 512, 512, ad, so_boxes=boxes[:2])
+        assert lst[0].dtype == dt and bg.dtype == dt
+        assert torch.equal(bg.float().cpu(), torch.from_numpy(goldh[f"{name}.bg"]))
+        for i in range(2):
+            assert torch.equal(lst[i].float().cpu(), torch.from_numpy(goldh[f"{name}.input{i}"])), f"{name} input {i}"
+        one = L.get_input_latents_lne(1, ad, None, 7, 7 + 123456789, 0.01, 512, 512, so_boxes=boxes[:2])
+        assert torch.equal(one.float().cpu(), torch.from_numpy(goldh[f"{name}.lne_seed7_idx1"]))
+    _Unet.dtype = torch.float32
     # geometry on host + shift on device
     masks = [torch.from_numpy(m) for m in gold["geo.masks"]]
     assert np.array_equal(np.array([U.binary_mask_to_box(m) for m in masks]), gold["geo.mask_box"])

@@ -26,14 +26,18 @@ def rel_tol(dtype):
     return 1.0e-2 if dtype == torch.bfloat16 else 2.5e-3
 
 
+def l2_tol(dtype):
+    """relative L2 error of ONE kernel whose output is rounded once to the storage dtype (bf16: 2^-9 per element,
+    uniform -> ~1.1e-3 rms; fp16: 2^-12 -> ~1.4e-4) plus fp32 accumulation-order noise"""
+    return 3.0e-3 if dtype == torch.bfloat16 else 4.0e-4
+
+
 def check(got, ref, dtype, what="", scale=1.0):
+    from tests import parity_metrics as pm
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
-    assert torch.isfinite(got).all(), f"{what}: non-finite output"
-    tol = rel_tol(dtype) * scale * max(ref.abs().max().item(), 1e-6)
-    err = (got - ref).abs().max().item()
-    assert err <= tol, f"{what}: max err {err:.4e} > tol {tol:.4e} (max|ref| {ref.abs().max().item():.3e})"
+    pm.check(got, ref, f"kernel: {what}", l2_tol(dtype) * scale, rel_tol(dtype) * scale, dtype=str(dtype))
 
 
 def rnd(shape, dtype, g, scale=1.0):

@@ -62,10 +62,30 @@ def test_resampler(golden_dir, ci, name):
 
 
 def test_image_proj(golden_dir):
-    gold = _load(golden_dir, "resampler")
+    """imageproj.npz: outputs of the REAL ImageProjModel / MLPProjModel classes (reference ip_adapter/ip_adapter.py:30-64,
+    class source executed by the generator); resampler.npz keeps the earlier 3-line restatement — they must agree"""
+    gold, old = _load(golden_dir, "imageproj"), _load(golden_dir, "resampler")
+    assert np.array_equal(gold["imageproj.out"], old["imageproj.out"]) and np.array_equal(gold["imageproj.zero"], old["imageproj.zero"])
     sd, e = gc.imageproj_params()
     np.testing.assert_allclose(ores.image_proj_model(sd, e, 4, 768).numpy(), gold["imageproj.out"], **TOL)
     np.testing.assert_allclose(ores.image_proj_model(sd, torch.zeros_like(e), 4, 768).numpy(), gold["imageproj.zero"], **TOL)
+    sd2, e2 = gc.mlpproj_params()
+    np.testing.assert_allclose(ores.mlp_proj_model(sd2, e2).numpy(), gold["mlpproj.out"], **TOL)
+    np.testing.assert_allclose(ores.mlp_proj_model(sd2, torch.zeros_like(e2)).numpy(), gold["mlpproj.zero"], **TOL)
+
+
+def test_latents_in_half_precision_adapter_dtype(golden_dir):
+    """the reference draws and blends in unet.dtype (fp16 in generate.py:77-81): another random sequence than an fp32
+    draw, and half-precision rounding inside the blend — bit-exact against the imported reference"""
+    gold = _load(golden_dir, "latents_half")
+    boxes = [[40 / 512, 150 / 512, 230 / 512, 450 / 512], [280 / 512, 150 / 512, 470 / 512, 450 / 512]]
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        lst, bg, _ = ol.get_input_latents_list(0, 123456789, 0.01, 512, 512, boxes, dtype=dt)
+        assert lst[0].dtype == dt
+        assert np.array_equal(bg.float().numpy(), gold[f"{name}.bg"])
+        assert np.array_equal(lst[0].float().numpy(), gold[f"{name}.input0"]) and np.array_equal(lst[1].float().numpy(), gold[f"{name}.input1"])
+        one = ol.get_input_latents_lne(1, 7, 7 + 123456789, 0.01, 512, 512, boxes, dtype=dt)
+        assert np.array_equal(one.float().numpy(), gold[f"{name}.lne_seed7_idx1"])
 
 
 def test_feed_forward_geglu(golden_dir):

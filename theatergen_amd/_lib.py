@@ -61,7 +61,7 @@ SIGNATURES = {
     "tg_conv_out": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "tg_timestep_embedding": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp, i64, vp]),
     "tg_step_epilogue": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp]),
-    "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, vp]),
+    "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, i32, vp, vp]),
     "tg_shift": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "tg_masked_compose": (i32, [vp, vp, vp, i64, i32, vp]),
     "tg_guidance_topk": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, f32, f32, f32, vp, vp, vp]),

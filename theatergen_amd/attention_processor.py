@@ -16,6 +16,8 @@ disappear because the kernel reads Q / K / V^T straight from the projection GEMM
 of the IP path stay independent (segment 1 of the kernel).  ``torch.nn`` modules are used as parameter
 containers only; there is no PyTorch compute and no CPU fallback.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,47 @@ from . import ops
 
 def _round8(n):
     return (n + 7) // 8 * 8
+
+
+def tensor_version(t):
+    """``t._version`` or None where it is unavailable (inference-mode tensors raise): None never compares equal to a
+    recorded version, so such tensors are simply re-projected."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+class StaticSlots:
+    """Step-invariant buffers derived from a conditioning tensor (text / image K and V^T, the ControlNet conditioning
+    embedding) are cached ONLY for tensors their owner registered explicitly (``DenoiseEngine``'s static buffers).
+
+    Identity is the tensor OBJECT, held by weak reference — never its address: a fresh ``torch.cat`` of the next
+    character's embeddings that the caching allocator places at the freed address of the previous one (same shape,
+    ``_version`` 0 again: exactly the reference's usage, ``models/pipelines.py:230-233, 860-950``) is a different object
+    and is projected anew.  A slot lives as long as its tensor: nothing is evicted while a captured hipGraph of the
+    owner may still read the buffers, and the buffers are released when the owner drops the tensor."""
+
+    def __init__(self):
+        self._slots = {}
+
+    def get(self, t):
+        hit = self._slots.get(id(t))
+        return hit[1] if hit is not None and hit[0]() is t else None
+
+    def put(self, t, payload):
+        key, slots = id(t), self._slots
+
+        def _drop(ref, key=key, slots=slots):
+            cur = slots.get(key)
+            if cur is not None and cur[0] is ref:
+                del slots[key]
+
+        slots[key] = (weakref.ref(t, _drop), payload)
+        return payload
+
+    def __len__(self):
+        return len(self._slots)
 
 
 class Attention(nn.Module):
@@ -216,7 +259,7 @@ class IPAttnProcessor(nn.Module):
         self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self._packed = None
-        self._kv = {}
+        self._kv = StaticSlots()
 
     def _ip_weight(self):
         ws = (self.to_k_ip.weight, self.to_v_ip.weight)
@@ -226,41 +269,59 @@ class IPAttnProcessor(nn.Module):
                 self._packed = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._packed[1]
 
-    def project_kv(self, attn, enc):
-        """Text and image K / V^T from ``encoder_hidden_states`` (step-invariant: cached per tensor version)."""
+    def _weights_key(self, attn):
+        return (self.num_tokens, attn.to_k.weight._version, attn.to_v.weight._version, attn.to_k.weight.data_ptr(),
+                self.to_k_ip.weight._version, self.to_v_ip.weight._version, self.to_k_ip.weight.data_ptr())
+
+    def _project_into(self, attn, enc, bufs):
+        """text K | V^T and image K | V^T of ``enc`` [B, L + T, ctx] -> ``bufs`` (two small GEMMs, V written transposed)"""
         B, Ltot, ctx = enc.shape
         T = self.num_tokens
         L = Ltot - T
         inner = attn.inner_dim
-        key = (enc._version, tuple(enc.shape), enc.dtype, T, id(attn),
-               attn.to_k.weight._version, attn.to_v.weight._version, self.to_k_ip.weight._version, self.to_v_ip.weight._version)
-        # one entry PER ENCODER TENSOR (keyed by its address): several denoising engines — each with its own static
-        # conditioning buffer and its own captured graph — can share this UNet, also concurrently on different streams
-        slot = self._kv.get(enc.data_ptr())
-        if slot is not None and slot["key"] == key:
-            return slot["kv"]
-        if L < 1 or T < 1 or T > 64:
-            raise RuntimeError(f"IPAttnProcessor: need 1 <= num_tokens <= 64 and at least one text token (L={L}, T={T})")
+        k, vt, kip, vtip = bufs
         ldt, ldi = _round8(L), _round8(T)
-        # buffers are allocated once per (tensor, shape) and refreshed IN PLACE, so a captured hipGraph of the UNet step
-        # keeps valid K / V^T pointers when new embeddings are copied into the same encoder tensor
-        bkey = (B, L, T, inner, enc.dtype, enc.device)
-        if slot is None or slot["bkey"] != bkey:
-            if slot is None and len(self._kv) >= 16:
-                self._kv.pop(next(iter(self._kv)))
-            slot = {"bkey": bkey, "bufs": (torch.empty((B * L, inner), dtype=enc.dtype, device=enc.device),
-                                           torch.zeros((B, inner, ldt), dtype=enc.dtype, device=enc.device),
-                                           torch.empty((B * T, inner), dtype=enc.dtype, device=enc.device),
-                                           torch.zeros((B, inner, ldi), dtype=enc.dtype, device=enc.device))}
-            self._kv[enc.data_ptr()] = slot
-        k, vt, kip, vtip = slot["bufs"]
         ops.gemm(enc, attn.kv_weight(), B * L, 2 * inner, ctx, rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt,
                  a_rows_per_batch=L, a_batch_stride=Ltot * ctx)
         ops.gemm(enc.reshape(-1)[L * ctx:], self._ip_weight(), B * T, 2 * inner, ctx, rows_per_batch=T, out=kip,
                  n_split=inner, out_t=vtip, ldt=ldi, a_rows_per_batch=T, a_batch_stride=Ltot * ctx)
-        kv = (k, vt, ldt, kip, vtip, ldi, L, T)
-        slot["key"], slot["kv"] = key, kv
-        return kv
+        return (k, vt, ldt, kip, vtip, ldi, L, T)
+
+    def _alloc(self, attn, enc):
+        B, Ltot, _ = enc.shape
+        T = self.num_tokens
+        L = Ltot - T
+        if L < 1 or T < 1 or T > 64:
+            raise RuntimeError(f"IPAttnProcessor: need 1 <= num_tokens <= 64 and at least one text token (L={L}, T={T})")
+        inner = attn.inner_dim
+        kw = dict(dtype=enc.dtype, device=enc.device)
+        # the pad columns of V^T (keys L..ldt) are multiplied by exact-zero probabilities: they must be finite
+        return (torch.empty((B * L, inner), **kw), torch.zeros((B, inner, _round8(L)), **kw),
+                torch.empty((B * T, inner), **kw), torch.zeros((B, inner, _round8(T)), **kw))
+
+    def register_static(self, attn, enc):
+        """Called by the OWNER of a persistent conditioning buffer (``DenoiseEngine.set_conditioning``) after it copied new
+        embeddings into it: (re)project K / V^T into buffers that belong to that tensor.  The buffers are allocated once per
+        (tensor, shape) and refreshed IN PLACE, so a captured hipGraph of the UNet step keeps valid pointers."""
+        slot = self._kv.get(enc)
+        bkey = (tuple(enc.shape), enc.dtype, enc.device, self.num_tokens, attn.inner_dim)
+        if slot is None or slot["bkey"] != bkey or slot["attn"]() is not attn:
+            slot = self._kv.put(enc, {"bkey": bkey, "attn": weakref.ref(attn), "bufs": self._alloc(attn, enc)})
+        slot["kv"] = self._project_into(attn, enc, slot["bufs"])
+        slot["key"] = (tensor_version(enc), self._weights_key(attn))
+        return slot["kv"]
+
+    def project_kv(self, attn, enc):
+        """Text and image K / V^T of ``encoder_hidden_states``.  Step-invariant, but only a REGISTERED tensor (see
+        ``register_static``) is served from its cache — and re-projected in place if it or the weights changed since; any
+        other tensor (the eager drop-in path: a fresh ``torch.cat`` per character) is projected on every call."""
+        slot = self._kv.get(enc)
+        if slot is not None and slot["attn"]() is attn:
+            ver = tensor_version(enc)
+            if ver is not None and slot["key"] == (ver, self._weights_key(attn)):
+                return slot["kv"]
+            return self.register_static(attn, enc)
+        return self._project_into(attn, enc, self._alloc(attn, enc))
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,

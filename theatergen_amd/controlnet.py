@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .attention_processor import Attention, AttnProcessor, CNAttnProcessor
+from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, StaticSlots, tensor_version
 from .config import UNetConfig
 from .unet import (DeviceSchedule, Downsample2D, ResnetBlock2D, TimestepEmbedding, Transformer2DModel,
                    UNet2DConditionModel, _Act, _Block, _Packed)
@@ -155,7 +155,7 @@ class ControlNetModel(nn.Module):
         self._tproj_width = off
         self._p = _Packed()
         self._t_cache = {}
-        self._cond_cache = None
+        self._cond_cache = StaticSlots()
         for p_ in self.parameters():
             p_.requires_grad_(False)
 
@@ -169,19 +169,28 @@ class ControlNetModel(nn.Module):
     _tproj_weight = UNet2DConditionModel._tproj_weight
     time_embed = UNet2DConditionModel.time_embed
 
-    def cond_embedding(self, controlnet_cond):
-        """step-invariant: cached per control-image tensor (data pointer + version) and parameter versions"""
+    def cond_embedding(self, controlnet_cond, static=False):
+        """Control-image embedding (step-invariant).  ``static=True`` is the owner of a persistent control-image buffer
+        (``DenoiseEngine.set_control``) registering / refreshing it: the embedding then lives in a buffer that belongs to
+        that tensor OBJECT (refreshed in place: a captured step graph keeps reading it; engines sharing this ControlNet
+        each have their own).  Any other tensor is embedded on every call — identity is never inferred from an address."""
         emb = self.controlnet_cond_embedding
-        key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape), controlnet_cond.dtype,
-               tuple(p._version for p in emb.parameters()), self.dtype)
-        if self._cond_cache is None or self._cond_cache[0] != key:
-            new = emb.run(controlnet_cond, self.dtype)
-            old = self._cond_cache[1] if self._cond_cache is not None else None
-            if old is not None and old.t.shape == new.t.shape and old.t.dtype == new.t.dtype:
-                old.t.copy_(new.t)        # refresh IN PLACE: a captured step graph keeps reading the same buffer
-                new = old
-            self._cond_cache = (key, new)
-        return self._cond_cache[1]
+        wkey = (tuple(p._version for p in emb.parameters()), self.dtype)
+        slot = self._cond_cache.get(controlnet_cond)
+        if slot is not None and not static:
+            ver = tensor_version(controlnet_cond)
+            if ver is not None and slot["key"] == (ver, wkey):
+                return slot["act"]
+            static = True                                # registered tensor changed in place: refresh its buffer
+        new = emb.run(controlnet_cond, self.dtype)
+        if not static:
+            return new
+        if slot is not None and slot["act"].t.shape == new.t.shape and slot["act"].t.dtype == new.t.dtype:
+            slot["act"].t.copy_(new.t)                    # IN PLACE: graphs captured on this slot stay valid
+        else:
+            slot = self._cond_cache.put(controlnet_cond, {"act": new})
+        slot["key"] = (tensor_version(controlnet_cond), wkey)
+        return slot["act"]
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, guess_mode=False, return_dict=True,

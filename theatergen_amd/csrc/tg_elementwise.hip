@@ -197,13 +197,26 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(StepParams p) {
 
 __global__ void step_advance_kernel(int* step_idx) { *step_idx += 1; }
 
+// ROUND: 0 = fp32 latents (the reference with an fp32 UNet); 1 / 2 = the reference's arithmetic when the latents are
+// fp16 / bf16 tensors (utils/latents.py:156-166 with dtype = unet.dtype, generate.py:77-81): `bg * sqrt(1-r)`,
+// `fg * sqrt(r)` and their sum are half-precision tensor ops (each computed in fp32 and rounded to the storage type),
+// the products with the fp32 mask promote to fp32, `.to(dtype)` rounds once more.  The fp32 output then holds values
+// that are exactly representable in the storage type.
+template <int ROUND>
+__device__ __forceinline__ float round_storage(float x) {
+  if (ROUND == 1) return (float)(f16_t)x;
+  if (ROUND == 2) return (float)(bf16_t)x;
+  return x;
+}
+template <int ROUND>
 __global__ __launch_bounds__(256) void blend_kernel(const float* bg, const float* fg, const float* mask, int planes, int hw,
                                                     float s1, float s2, float sigma, float* out) {
   const long total = (long)planes * hw;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const float m = mask[i % hw];
     const float b = bg[i];
-    out[i] = (b * (1.f - m) + (b * s1 + fg[i] * s2) * m) * sigma;
+    const float inner = round_storage<ROUND>(round_storage<ROUND>(b * s1) + round_storage<ROUND>(fg[i] * s2));
+    out[i] = round_storage<ROUND>(round_storage<ROUND>(b * (1.f - m) + inner * m) * sigma);
   }
 }
 
@@ -605,11 +618,15 @@ extern "C" int tg_step_epilogue(const float* noise_pred, float* latents, int32_t
 }
 
 extern "C" int tg_blend_latents(const float* bg, const float* fg, const float* mask, int32_t planes, int32_t hw,
-                                float ratio, float sigma, float* out, void* stream) {
+                                float ratio, float sigma, int32_t storage_dtype, float* out, void* stream) {
   TG_CHECK(bg && fg && mask && out && planes > 0 && hw > 0, TG_ERR_ARG, "tg_blend_latents: bad args");
+  TG_CHECK(storage_dtype >= -1 && storage_dtype <= 1, TG_ERR_ARG, "tg_blend_latents: storage_dtype must be -1 (fp32), TG_BF16 or TG_F16");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(blend_kernel, dim3(grid_for((long)planes * hw)), dim3(256), 0, st, bg, fg, mask, planes, hw,
-                     (float)sqrt(1.0 - (double)ratio), (float)sqrt((double)ratio), sigma, out);
+  const float s1 = (float)sqrt(1.0 - (double)ratio), s2 = (float)sqrt((double)ratio);
+  const dim3 grid(grid_for((long)planes * hw));
+  if (storage_dtype == TG_F16) hipLaunchKernelGGL(blend_kernel<1>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
+  else if (storage_dtype == TG_BF16) hipLaunchKernelGGL(blend_kernel<2>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
+  else hipLaunchKernelGGL(blend_kernel<0>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

@@ -6,9 +6,11 @@ Mirrors reference ``utils/latents.py``: ``get_unscaled_latents`` :138-149, ``get
 ``.pipe.unet.config.in_channels`` / ``.pipe.unet.dtype`` / ``.pipe.scheduler.init_noise_sigma``).
 
 RNG parity is host-side by construction, exactly like the reference: noise is drawn from the CPU generator seeded
-by ``torch.manual_seed`` (:144-147, :263, :284) and every object gets the SAME ``fg_seed_start`` (:282-283); only
-then it moves to the GPU.  The arithmetic (blend, zero-filled shift, masked paste over all 51 steps) runs in
-``tg_blend_latents`` / ``tg_shift`` / ``tg_masked_compose`` on fp32 device tensors.
+by ``torch.manual_seed`` (:144-147, :263, :284) IN ``unet.dtype`` (an fp16 draw is a different sequence than an fp32
+draw; ``generate.py:77-81`` runs fp16) and every object gets the SAME ``fg_seed_start`` (:282-283); only then it moves
+to the GPU.  The arithmetic (blend, zero-filled shift, masked paste over all 51 steps) runs in ``tg_blend_latents`` /
+``tg_shift`` / ``tg_masked_compose`` on fp32 device tensors; for half-precision latents the blend rounds where the
+reference's half-precision tensor ops round, so the result equals the reference's bit for bit (tests/golden/latents_half.npz).
 ``prepare_mid_image`` (:48-135, pixel-space PIL paste) is outside the hot path.
 """
 import numpy as np
@@ -20,7 +22,7 @@ torch_device = "cuda"
 
 
 def get_unscaled_latents(batch_size, in_channels, height, width, generator, dtype):
-    """CPU draw in ``dtype`` (fp32 in the flow), then to the device (reference :138-149)."""
+    """CPU draw in ``dtype`` (= unet.dtype in the flow), then to the device (reference :138-149)."""
     return torch.randn((batch_size, in_channels, height // 8, width // 8), generator=generator, dtype=dtype).to(torch_device, dtype=dtype)
 
 
@@ -33,10 +35,12 @@ def get_scaled_latents(batch_size, in_channels, height, width, generator, dtype,
 
 
 def blend_latents(latents_bg, latents_fg, fg_mask, fg_blending_ratio=0.01, sigma=1.0):
-    """bg (1-M) + (bg sqrt(1-r) + fg sqrt(r)) M, optionally times init_noise_sigma (reference :156-166, :288)."""
+    """bg (1-M) + (bg sqrt(1-r) + fg sqrt(r)) M, optionally times init_noise_sigma (reference :156-166, :288); result in
+    the dtype of ``latents_bg`` with the reference's rounding points for fp16 / bf16 latents."""
     dtype = latents_bg.dtype
     out = ops.blend_latents(latents_bg.to(torch.float32).contiguous(), latents_fg.to(torch.float32).contiguous(),
-                            fg_mask.to(device=latents_bg.device, dtype=torch.float32).contiguous(), fg_blending_ratio, sigma)
+                            fg_mask.to(device=latents_bg.device, dtype=torch.float32).contiguous(), fg_blending_ratio, sigma,
+                            storage_dtype=dtype if dtype in (torch.float16, torch.bfloat16) else None)
     return out.to(dtype)
 
 
@@ -44,7 +48,7 @@ def get_input_latents_list(model_dict, bg_seed, fg_seed_start, fg_blending_ratio
                            so_prompt_phrase_box_list=None, so_boxes=None, verbose=False):
     """-> (input_latents_list, latents_bg, fg_seed_list), all scaled by init_noise_sigma (reference :257-295)."""
     unet, scheduler = adapter.pipe.unet, adapter.pipe.scheduler
-    dtype = torch.float32 if unet.dtype in (torch.bfloat16, torch.float16) else unet.dtype
+    dtype = unet.dtype                                # the reference draws AND blends in unet.dtype (:261-288)
     sigma = float(scheduler.init_noise_sigma)
     latents_bg = get_unscaled_latents(1, unet.config.in_channels, height, width, torch.manual_seed(bg_seed), dtype)
     if so_boxes is None:
@@ -94,8 +98,10 @@ def compose_latents(adapter, model_dict, latents_all_list, mask_tensor_list, num
     segmentation mask; returns (composed [S,1,C,h,w] fp32 on the GPU, foreground_indices [h,w] long) — reference :168-218."""
     unet, scheduler = adapter.pipe.unet, adapter.pipe.scheduler
     if latents_bg is None:
+        # drawn in unet.dtype like the reference (:170-173); the masked paste below only copies values (masks are 0 / 1), so
+        # the fp32 result holds exactly the reference's half-precision values
         latents_bg = get_scaled_latents(overall_batch_size, unet.config.in_channels, height, width, torch.manual_seed(bg_seed),
-                                        torch.float32, scheduler)
+                                        unet.dtype, scheduler)
     dev = latents_bg.device
     n_rows = (fast_after_steps + 1) if use_fast_schedule else (num_inference_steps + 1)
     composed = torch.zeros((n_rows, *latents_bg.shape), dtype=torch.float32, device=dev)

@@ -307,11 +307,14 @@ def step_epilogue(noise_pred, latents, guidance_scale, coef, step_idx, *, has_cf
                                            mask_per_img, int(frozen_steps), _ptr(history), _ptr(model_in), mi_dt, _stream()))
 
 
-def blend_latents(bg, fg, mask, ratio, sigma=1.0):
+def blend_latents(bg, fg, mask, ratio, sigma=1.0, storage_dtype=None):
+    """fp32 in / out; ``storage_dtype`` torch.float16 / torch.bfloat16: reproduce the half-precision roundings of the
+    reference expression (its latents are ``unet.dtype`` tensors)"""
     out = torch.empty_like(bg)
     hw = bg.shape[-1] * bg.shape[-2]
+    sd = {None: -1, torch.float32: -1, torch.bfloat16: _lib.TG_BF16, torch.float16: _lib.TG_F16}[storage_dtype]
     _lib.check(_lib.lib().tg_blend_latents(_ptr(bg), _ptr(fg), _ptr(mask), bg.numel() // hw, hw, float(ratio), float(sigma),
-                                           _ptr(out), _stream()))
+                                           sd, _ptr(out), _stream()))
     return out
 
 

@@ -114,13 +114,13 @@ class DenoiseEngine:
         if self.graph is not None and float(conditioning_scale) != self.cn_scale:
             self.graph = None          # the scale is a launch constant of the zero-conv epilogues
         self.cn_scale = float(conditioning_scale)
-        self.controlnet.cond_embedding(self.cn_cond)
+        self.controlnet.cond_embedding(self.cn_cond, static=True)
 
     def _refresh_kv(self):
         from .attention_processor import Attention, IPAttnProcessor
         for m in self.unet.modules():
             if isinstance(m, Attention) and isinstance(m.processor, IPAttnProcessor):
-                m.processor.project_kv(m, self.enc)
+                m.processor.register_static(m, self.enc)       # cache keyed by the tensor OBJECT self.enc (never its address)
 
     def set_frozen(self, frozen_latents, frozen_mask, frozen_steps):
         """Stage-2 frozen-mask replace (reference pipelines.py:733-738, 833-834): ``frozen_latents`` fp32

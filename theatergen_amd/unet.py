@@ -283,7 +283,11 @@ class UNet2DConditionModel(nn.Module):
         def tfm(c, heads, layers):
             return Transformer2DModel(heads, c // heads, c, layers, ctx, g, lin)
 
+        # registration order = the reference's (models/unet_2d_condition.py:430-431: both lists exist before mid_block), so
+        # ``attn_processors`` enumerates down (0-11), up (12-29), mid (30-31) for SD-1.5 and the IP-Adapter checkpoints'
+        # ``ip_adapter.{1,3,...,31}.to_k_ip.weight`` keys (ip_adapter.py:139-140) land on the layers they were trained for
         self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
         out_c = boc[0]
         for i, bt in enumerate(cfg.down_block_types):
             in_c, out_c = out_c, boc[i]
@@ -307,7 +311,6 @@ class UNet2DConditionModel(nn.Module):
         mid.resnets.append(ResnetBlock2D(boc[-1], boc[-1], ted, g, eps))
         self.mid_block = mid
 
-        self.up_blocks = nn.ModuleList()
         rboc, rheads, rtl, rlpb = tuple(reversed(boc)), tuple(reversed(heads_t)), tuple(reversed(tl_t)), tuple(reversed(lpb))
         out_c = rboc[0]
         for i, bt in enumerate(cfg.up_block_types):
