@@ -21,6 +21,8 @@ Extra legs on rank 0 at N = 1 (outside the timed region):
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,6 +55,9 @@ def parse():
     ap.add_argument("--with-vae", action="store_true",
                     help="NOT the north-star line: also decode the 8 final latents of every story with the VAE (pipelines.py:468) "
                          "inside the timed region, i.e. end-to-end decoded images/s")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test (CPU, gloo): every rank joins the process group, takes part in the barrier / "
+                         "max-over-ranks / gather plumbing and rank 0 prints a JSON line with the group's world size; no GPU work")
     ap.add_argument("--stage2", action="store_true",
                     help="NOT the north-star line: time the stage-2 step (ControlNet + IP-Adapter UNet, reference "
                          "pipelines.py:759-835) on the same stories instead of the stage-1 per-character step")
@@ -143,15 +148,60 @@ def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps):
             "s_per_cfg_call": round(dt, 3)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves (one process per GPU, the
+    same command line the driver uses) and hand over its exit code.  Fails loudly when fewer than N devices are visible."""
+    if not args.dry_launch:
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {n} GPU(s) are visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_launch(args, D, rank, world):
+    """what the launcher test checks: the group really has `--gpus` members and the collectives of the timed region work"""
+    D.init(backend="gloo")
+    n = torch.distributed.get_world_size() if D.is_dist() else 1
+    if n != args.gpus:
+        raise SystemExit(f"bench.py: process group has {n} rank(s), --gpus {args.gpus}")
+    D.barrier()
+    worst = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    got = D.gather_latents(torch.full((2, 3), float(rank)))
+    ok = worst == float(n) and got.shape[0] == 2 * n and [float(v) for v in got[::2, 0]] == [float(r) for r in range(n)]
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": n, "collectives_ok": bool(ok)}), flush=True)
+    if D.is_dist():
+        torch.distributed.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     args = parse()
     from theatergen_amd import distributed as D
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank, world, local = D.env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_launch:
+        return dry_launch(args, D, rank, world)
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     D.init(device=device)
+    if (torch.distributed.get_world_size() if D.is_dist() else 1) != args.gpus:
+        raise SystemExit(f"bench.py: the process group has {torch.distributed.get_world_size() if D.is_dist() else 1} rank(s), "
+                         f"--gpus {args.gpus}")
+    world = args.gpus                                     # = the process group's size (checked above): what the line reports
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
     from theatergen_amd import story

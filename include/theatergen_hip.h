@@ -104,6 +104,11 @@ typedef struct {
    * (slices encoder_hidden_states[:, :L-T] / [:, L-T:] without a copy, attention_processor.py:467-471) */
   int64_t a_rows_per_batch;
   int64_t a_batch_stride;
+  /* mode 1 only: 0 = symmetric zero padding 1 (every UNet conv); 1 = padding on the bottom / right edge only, the
+   * `F.pad(x, (0, 1, 0, 1))` + stride-2 conv of diffusers' Downsample2D(padding=0) in the VAE ENCODER
+   * (AutoencoderKL.encode, models/pipelines.py:157, 624): input pixel = stride * out + tap, no -1 offset */
+  int32_t pad_mode;
+  int32_t reserved0;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
@@ -235,6 +240,15 @@ int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int
 int tg_blend_latents(const float* bg, const float* fg, const float* mask, int32_t planes, int32_t hw, float ratio,
                      float sigma, int32_t storage_dtype, float* out, void* stream);
 int tg_shift(const float* src, int64_t planes, int32_t h, int32_t w, int32_t dx, int32_t dy, float* dst, void* stream);
+/* DiagonalGaussianDistribution.sample of AutoencoderKL.encode (diffusers 0.21.4; reference models/pipelines.py:157, 624-626):
+ * moments fp32 [B, 2C, hw] = (mean | logvar); out[b, c, i] = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[b, c, i]);
+ * noise == NULL gives the mode (scale * mean).  `scale` = vae.config.scaling_factor (:159, :626). */
+int tg_gaussian_sample(const float* moments, const float* noise, int32_t batch, int32_t channels, int32_t hw, float scale,
+                       float* out, void* stream);
+/* scheduler.add_noise over a table of timesteps (models/pipelines.py:629-631): out[s, i] = ca[s] * x0[i] + cb[s] * noise[i],
+ * x0 / noise fp32 [n], ca / cb fp32 [steps] (sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t)), out fp32 [steps, n] */
+int tg_add_noise(const float* x0, const float* noise, const float* ca, const float* cb, int32_t steps, int64_t n, float* out,
+                 void* stream);
 int tg_masked_compose(float* dst, const float* src, const float* mask, int64_t planes, int32_t hw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

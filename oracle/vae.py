@@ -16,6 +16,13 @@ from the documented 0.21.4 semantics (SD VAE config: ``block_out_channels=(128, 
      conv_norm_out GroupNorm(32) -> SiLU -> conv_out [3x3, 128 -> 3]
   ResnetBlock2D(temb=None): h = conv1(silu(GN(x))); h = conv2(silu(GN(h))); out = shortcut(x) + h   (scale factor 1)
 
+  encode(x): Encoder(double_z=True): conv_in [3x3, 3 -> 128]; DownEncoderBlock2D x 4 (2 x ResnetBlock2D, first one changes
+     channels; all but the last end in Downsample2D(use_conv=True, padding=0): F.pad(h, (0, 1, 0, 1)) then conv3x3 stride 2
+     padding 0); UNetMidBlock2D as above; conv_norm_out GroupNorm(32, eps 1e-6) -> SiLU -> conv_out [3x3, 512 -> 8];
+     moments = quant_conv(h) [1x1, 8 -> 8]; DiagonalGaussianDistribution: mean, logvar = chunk(moments, 2, dim=1),
+     logvar clamped to [-30, 20], sample = mean + exp(0.5 logvar) * randn(generator); the reference multiplies the sample
+     by scaling_factor (models/pipelines.py:157-159, 624-626).
+
 State-dict names are diffusers' (``post_quant_conv.weight``, ``decoder.mid_block.attentions.0.to_q.weight``,
 ``decoder.up_blocks.1.resnets.0.conv_shortcut.weight``, ``decoder.up_blocks.0.upsamplers.0.conv.weight`` ...).
 """
@@ -65,3 +72,32 @@ def decode(cfg, sd, latents, scaling_factor=None):
             x = F.conv2d(x, sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"], sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
     x = F.silu(_gn(sd, "decoder.conv_norm_out", x, groups, 1e-6))
     return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+def encode_moments(cfg, sd, image):
+    """image [B, 3, H, W] in [-1, 1] -> moments [B, 2 * latent_channels, H/8, W/8] (mean | logvar before clamping)"""
+    boc = tuple(cfg["block_out_channels"])
+    groups = cfg.get("norm_num_groups", 32)
+    lpb = cfg.get("layers_per_block", 2)
+    x = F.conv2d(image, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for i in range(len(boc)):
+        for j in range(lpb):
+            x = resnet_block(sd, f"encoder.down_blocks.{i}.resnets.{j}", x, groups)
+        if i != len(boc) - 1:
+            x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+            x = F.conv2d(x, sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"], sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"],
+                         stride=2, padding=0)
+    x = resnet_block(sd, "encoder.mid_block.resnets.0", x, groups)
+    x = mid_attention(sd, "encoder.mid_block.attentions.0", x, groups)
+    x = resnet_block(sd, "encoder.mid_block.resnets.1", x, groups)
+    x = F.silu(_gn(sd, "encoder.conv_norm_out", x, groups, 1e-6))
+    x = F.conv2d(x, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return F.conv2d(x, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def sample_latents(cfg, moments, noise, scaling_factor=None):
+    """DiagonalGaussianDistribution.sample with the given noise, times scaling_factor (reference models/pipelines.py:157-159)"""
+    sf = cfg.get("scaling_factor", 0.18215) if scaling_factor is None else scaling_factor
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return sf * (mean + torch.exp(0.5 * logvar) * noise)

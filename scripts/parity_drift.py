@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""50-step drift curve: SD-1.5 512x512, one character box, 50 DDIM steps, CFG 7.5, latents by the
+reference recipe; the HIP path (bf16 / fp16, hipGraph engine) against the fp32 CPU oracle loop, relative L2 and max error of the
+latents after steps 1 / 5 / 10 / 20 / 50.  ~4-5 minutes of fp32 CPU oracle at 64 threads per dtype.
+
+    python scripts/parity_drift.py [--dtypes bf16,fp16] [--steps 50] > gpurun_out/r2_parity_drift.json   (GPU box)
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtypes", default="bf16")
+    ap.add_argument("--steps", type=int, default=50)
+    args = ap.parse_args()
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from tests import parity_metrics as pm
+    from theatergen_amd import config, latents as L, story, weights as W
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.pipelines import DenoiseEngine, SDPipe
+    from theatergen_amd.unet import UNet2DConditionModel
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    dev = "cuda:0"
+    cfg = config.sd15()
+    sd = W.random_unet_state_dict(cfg, seed=0)
+    marks = [s for s in (1, 5, 10, 20, 30, 40, 50) if s <= args.steps]
+    out = {"workload": f"SD-1.5 512x512, 1 character box, {args.steps} DDIM steps, CFG 7.5, IP 77+4 tokens scale 0.4, seeds bg 0 / fg 123456789",
+           "oracle": "oracle/unet.py + oracle/ddim.py, fp32 CPU, weights rounded to the storage dtype", "curves": {}}
+    for name in args.dtypes.split(","):
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[name]
+        unet = UNet2DConditionModel.from_state_dict(cfg, sd, device=dev, dtype=dtype, num_tokens=4, ip_scale=0.4)
+        sd_r = {k: v.to(dtype).float() for k, v in sd.items()}
+        adapter = IPAdapter(SDPipe(unet), None, None, dev, num_tokens=4)
+        adapter.set_scale(0.4)
+        lat = L.get_input_latents_list(None, 0, 123456789, 0.01, 512, 512, adapter, so_boxes=[story.box_xyxy(0)])[0][0].float().cpu()
+        enc = torch.randn(2, 81, 768, generator=torch.Generator().manual_seed(77)) * 0.5
+        eng = DenoiseEngine(unet, None, n_img=1, height=512, width=512, num_inference_steps=args.steps, guidance_scale=7.5, enc_len=81)
+        eng.set_conditioning(enc.to(dev, dtype))
+        hist = eng.run(lat).cpu()
+        osch = oddim.DDIMSchedule()
+        osch.set_timesteps(args.steps)
+        ref, encr, curve = lat.clone(), enc.to(dtype).float(), {}
+        for i, t in enumerate(osch.timesteps.tolist()):
+            mi = torch.cat([ref] * 2).to(dtype).float()
+            ref = oddim.step_epilogue(osch, ou.unet_forward(cfg, sd_r, mi, t, encr, ip_scale=0.4, num_tokens=4), t, ref, 7.5)
+            if i + 1 in marks:
+                curve[str(i + 1)] = pm.metrics(hist[i + 1], ref)
+                print(name, i + 1, curve[str(i + 1)], file=sys.stderr, flush=True)
+        out["curves"][name] = curve
+        del unet, eng, adapter
+        torch.cuda.empty_cache()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,3 +53,25 @@ def test_broadcast_shard_gather_world2():
         assert mine == [d for d in range(8) if d % 2 == rank]
         assert ids == [0.0, 2.0, 4.0, 6.0, 1.0, 3.0, 5.0, 7.0]       # rank-major gather
         assert t == 2.0                                               # MAX over ranks
+
+
+def test_bench_self_launches_its_ranks_world2():
+    """`python bench.py --gpus 2` with no torchrun environment must START two ranks itself (it used to run one
+    rank and print n_gpus = 1); the launcher is exercised on CPU with the gloo dry run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec == {"dry": True, "n_gpus": 2, "collectives_ok": True}
+    # a torchrun environment that disagrees with --gpus is an error, not a silent 1-GPU run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

@@ -718,13 +718,13 @@ def test_latent_utilities_vs_reference_golden():
     goldh = _load("latents_half")
     for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
         _Unet.dtype = dt
-        lst, bg, _ = L.get_input_latents_list(None, 0, 123456789, 0.01, 512, 512, ad, so_boxes=boxes[:2])
-        assert lst[0].dtype == dt and bg.dtype == dt
-        assert torch.equal(bg.float().cpu(), torch.from_numpy(goldh[f"{name}.bg"]))
+        lst_h, bg_h, _ = L.get_input_latents_list(None, 0, 123456789, 0.01, 512, 512, ad, so_boxes=boxes[:2])
+        assert lst_h[0].dtype == dt and bg_h.dtype == dt
+        assert torch.equal(bg_h.float().cpu(), torch.from_numpy(goldh[f"{name}.bg"])), f"{name} bg draw"
         for i in range(2):
-            assert torch.equal(lst[i].float().cpu(), torch.from_numpy(goldh[f"{name}.input{i}"])), f"{name} input {i}"
-        one = L.get_input_latents_lne(1, ad, None, 7, 7 + 123456789, 0.01, 512, 512, so_boxes=boxes[:2])
-        assert torch.equal(one.float().cpu(), torch.from_numpy(goldh[f"{name}.lne_seed7_idx1"]))
+            assert torch.equal(lst_h[i].float().cpu(), torch.from_numpy(goldh[f"{name}.input{i}"])), f"{name} input {i}"
+        one_h = L.get_input_latents_lne(1, ad, None, 7, 7 + 123456789, 0.01, 512, 512, so_boxes=boxes[:2])
+        assert torch.equal(one_h.float().cpu(), torch.from_numpy(goldh[f"{name}.lne_seed7_idx1"])), f"{name} lne"
     _Unet.dtype = torch.float32
     # geometry on host + shift on device
     masks = [torch.from_numpy(m) for m in gold["geo.masks"]]

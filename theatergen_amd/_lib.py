@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ("act", i32), ("geglu", i32), ("out_scale", f32), ("out", vp), ("ldc", i64), ("n_split", i64),
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
         ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
+        ("pad_mode", i32), ("reserved0", i32),
     ]
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, i32, vp, vp]),
     "tg_shift": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "tg_masked_compose": (i32, [vp, vp, vp, i64, i32, vp]),
+    "tg_gaussian_sample": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
+    "tg_add_noise": (i32, [vp, vp, vp, vp, i32, i64, vp, vp]),
     "tg_guidance_topk": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, f32, f32, f32, vp, vp, vp]),
     "tg_guidance_ratio": (i32, [vp, i32, i32, i32, i32, vp, f32, vp, vp, vp]),
     "tg_guidance_ref": (i32, [vp, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp]),

@@ -220,6 +220,30 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* bg, const float
   }
 }
 
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* moments, const float* noise, int batch, int ch, int hw,
+                                                              float scale, float* out) {
+  const long total = (long)batch * ch * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ((long)ch * hw), r = i - b * (long)ch * hw;
+    const float mean = moments[b * 2 * ch * hw + r];
+    float v = mean;
+    if (noise != nullptr) {
+      const float logvar = fminf(fmaxf(moments[b * 2 * ch * hw + (long)ch * hw + r], -30.f), 20.f);
+      v = mean + expf(0.5f * logvar) * noise[i];
+    }
+    out[i] = scale * v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* x0, const float* noise, const float* ca, const float* cb,
+                                                        int steps, long n, float* out) {
+  const long total = (long)steps * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long s_ = i / n, r = i - s_ * n;
+    out[i] = ca[s_] * x0[r] + cb[s_] * noise[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void shift_kernel(const float* src, long planes, int h, int w, int dx, int dy, float* dst) {
   const long total = planes * h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -627,6 +651,25 @@ extern "C" int tg_blend_latents(const float* bg, const float* fg, const float* m
   if (storage_dtype == TG_F16) hipLaunchKernelGGL(blend_kernel<1>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
   else if (storage_dtype == TG_BF16) hipLaunchKernelGGL(blend_kernel<2>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
   else hipLaunchKernelGGL(blend_kernel<0>, grid, dim3(256), 0, st, bg, fg, mask, planes, hw, s1, s2, sigma, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_gaussian_sample(const float* moments, const float* noise, int32_t batch, int32_t channels, int32_t hw,
+                                  float scale, float* out, void* stream) {
+  TG_CHECK(moments && out && batch > 0 && channels > 0 && hw > 0, TG_ERR_ARG, "tg_gaussian_sample: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0, st, moments, noise,
+                     batch, channels, hw, scale, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+extern "C" int tg_add_noise(const float* x0, const float* noise, const float* ca, const float* cb, int32_t steps, int64_t n,
+                            float* out, void* stream) {
+  TG_CHECK(x0 && noise && ca && cb && out && steps > 0 && n > 0, TG_ERR_ARG, "tg_add_noise: bad args");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for((long)steps * n)), dim3(256), 0, st, x0, noise, ca, cb, steps, (long)n, out);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

@@ -28,6 +28,7 @@ struct GemmParams {
   const void* a1;
   int c0, c1;
   int in_h, in_w, out_h, out_w, stride, upsample;
+  int pad_lo;       // zero rows / columns in front of the image: 1 (symmetric pad 1) or 0 (VAE-encoder downsample: bottom / right only)
   const void* w;
   long M, N, K;
   const void* bias;
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
         int iy, ix;
         bool ok = x_ok[j];
         if (!p.upsample) {
-          iy = x_oy[j] * p.stride + ky - 1;
-          ix = x_ox[j] * p.stride + kx - 1;
+          iy = x_oy[j] * p.stride + ky - p.pad_lo;
+          ix = x_ox[j] * p.stride + kx - p.pad_lo;
           ok = ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
         } else {
           const int uy = x_oy[j] + ky - 1, ux = x_ox[j] + kx - 1;
@@ -925,7 +926,7 @@ int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || d->force_tile != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return false;
+  if (d->mode != 1 || d->stride != 1 || d->pad_mode != 0 || d->force_tile != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return false;
   if (d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->M % 128 != 0) return false;
   if (d->out_w == 8) return d->out_h == 8 && !d->upsample && d->M >= 1024;   // two whole 8x8 images per block
   if (d->out_w != 16 && d->out_w != 32 && d->out_w != 64) return false;
@@ -1049,7 +1050,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   GemmParams p{};
   p.a0 = d->a0; p.a1 = d->a1; p.c0 = d->c0; p.c1 = d->a1 ? d->c1 : 0;
   p.in_h = d->in_h; p.in_w = d->in_w; p.out_h = d->out_h; p.out_w = d->out_w;
-  p.stride = d->stride; p.upsample = d->upsample;
+  p.stride = d->stride; p.upsample = d->upsample; p.pad_lo = d->pad_mode == 1 ? 0 : 1;
   p.w = d->w; p.M = d->M; p.N = d->N; p.K = d->K;
   p.bias = d->bias; p.bvec = d->bvec; p.ldbvec = d->ldbvec;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
@@ -1114,8 +1115,11 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->stride == 1 || d->stride == 2, TG_ERR_ARG, "tg_gemm conv: stride 1|2");
     TG_CHECK(!(d->upsample && d->stride != 1), TG_ERR_ARG, "tg_gemm conv: upsample needs stride 1");
     TG_CHECK(d->M == (int64_t)d->batch * d->out_h * d->out_w, TG_ERR_ARG, "tg_gemm conv: M != batch*out_h*out_w");
-    const int eh = d->upsample ? 2 * d->in_h : (d->in_h + 2 - 3) / d->stride + 1;
-    const int ew = d->upsample ? 2 * d->in_w : (d->in_w + 2 - 3) / d->stride + 1;
+    TG_CHECK(d->pad_mode == 0 || (d->pad_mode == 1 && d->stride == 2 && !d->upsample), TG_ERR_ARG,
+             "tg_gemm conv: pad_mode 1 (bottom / right padding) is the stride-2 encoder downsample only");
+    const int pad2 = d->pad_mode == 1 ? 1 : 2;
+    const int eh = d->upsample ? 2 * d->in_h : (d->in_h + pad2 - 3) / d->stride + 1;
+    const int ew = d->upsample ? 2 * d->in_w : (d->in_w + pad2 - 3) / d->stride + 1;
     TG_CHECK(eh == d->out_h && ew == d->out_w, TG_ERR_ARG, "tg_gemm conv: out %dx%d inconsistent with in %dx%d",
              d->out_h, d->out_w, d->in_h, d->in_w);
   } else {

@@ -67,7 +67,7 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0, geglu=False):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -102,6 +102,7 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.force_split_k = force_split_k
     d.force_tile = force_tile
     d.a_rows_per_batch, d.a_batch_stride = int(a_rows_per_batch), int(a_batch_stride)
+    d.pad_mode = int(pad_mode)
     need = L.tg_gemm_workspace_bytes(C.byref(d))
     if need < 0:
         _lib.check(-1)
@@ -151,17 +152,19 @@ def linear(x, w, bias=None, **kw):
     return gemm(x, w, M, N, K, bias=bias, **kw)
 
 
-def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, **kw):
+def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, pad_mode=0, **kw):
     """3x3 pad-1 convolution as implicit GEMM over token-major x [batch*in_h*in_w, cin] (+ optional concat x1).
-    w_packed: [cout, 9*(cin+c1)] tap-major."""
+    w_packed: [cout, 9*(cin+c1)] tap-major.  ``pad_mode=1``: zero padding on the bottom / right edge only (the VAE
+    encoder's ``Downsample2D(padding=0)``: ``F.pad(x, (0, 1, 0, 1))`` then a stride-2 conv)."""
     if upsample:
         oh, ow = 2 * in_h, 2 * in_w
     else:
-        oh, ow = (in_h + 2 - 3) // stride + 1, (in_w + 2 - 3) // stride + 1
+        pad2 = 1 if pad_mode == 1 else 2
+        oh, ow = (in_h + pad2 - 3) // stride + 1, (in_w + pad2 - 3) // stride + 1
     N = w_packed.shape[0]
     K = 9 * (cin + c1)
     return gemm(x, w_packed, batch * oh * ow, N, K, mode=1, a1=x1, c0=cin, c1=c1,
-                conv=(batch, in_h, in_w, oh, ow, stride, 1 if upsample else 0), bias=bias, **kw)
+                conv=(batch, in_h, in_w, oh, ow, stride, 1 if upsample else 0), bias=bias, pad_mode=pad_mode, **kw)
 
 
 def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch, heads, head_dim, n_q, scale,
@@ -315,6 +318,22 @@ def blend_latents(bg, fg, mask, ratio, sigma=1.0, storage_dtype=None):
     sd = {None: -1, torch.float32: -1, torch.bfloat16: _lib.TG_BF16, torch.float16: _lib.TG_F16}[storage_dtype]
     _lib.check(_lib.lib().tg_blend_latents(_ptr(bg), _ptr(fg), _ptr(mask), bg.numel() // hw, hw, float(ratio), float(sigma),
                                            sd, _ptr(out), _stream()))
+    return out
+
+
+def gaussian_sample(moments, noise, scale=1.0):
+    """moments fp32 [B, 2C, h, w] -> scale * (mean + std * noise) fp32 [B, C, h, w]; ``noise`` None = the mode"""
+    B, C2, h, w = moments.shape
+    out = torch.empty((B, C2 // 2, h, w), dtype=torch.float32, device=moments.device)
+    _lib.check(_lib.lib().tg_gaussian_sample(_ptr(moments), _ptr(noise), B, C2 // 2, h * w, float(scale), _ptr(out), _stream()))
+    return out
+
+
+def add_noise(x0, noise, ca, cb):
+    """out[s] = ca[s] * x0 + cb[s] * noise for a table of `steps` coefficients (fp32)"""
+    steps = ca.numel()
+    out = torch.empty((steps, *x0.shape), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.lib().tg_add_noise(_ptr(x0), _ptr(noise), _ptr(ca), _ptr(cb), steps, x0.numel(), _ptr(out), _stream()))
     return out
 
 

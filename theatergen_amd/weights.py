@@ -296,3 +296,58 @@ def vae_decoder_param_shapes(cfg):
 
 def random_vae_decoder_state_dict(cfg, seed=0, dtype=torch.float32):
     return _fill(vae_decoder_param_shapes(cfg), seed, dtype)
+
+
+def vae_encoder_param_shapes(cfg):
+    """diffusers ``AutoencoderKL`` encoder-side parameter names (``encoder.*`` + ``quant_conv``): the SD VAE encoder has
+    34 163 592 parameters (+ 72 in quant_conv)."""
+    s = OrderedDict()
+    boc = tuple(cfg.block_out_channels)
+    lc = cfg.latent_channels
+    s["encoder.conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3)
+    s["encoder.conv_in.bias"] = (boc[0],)
+
+    def resnet(p, cin, cout):
+        s[p + ".norm1.weight"] = (cin,)
+        s[p + ".norm1.bias"] = (cin,)
+        s[p + ".conv1.weight"] = (cout, cin, 3, 3)
+        s[p + ".conv1.bias"] = (cout,)
+        s[p + ".norm2.weight"] = (cout,)
+        s[p + ".norm2.bias"] = (cout,)
+        s[p + ".conv2.weight"] = (cout, cout, 3, 3)
+        s[p + ".conv2.bias"] = (cout,)
+        if cin != cout:
+            s[p + ".conv_shortcut.weight"] = (cout, cin, 1, 1)
+            s[p + ".conv_shortcut.bias"] = (cout,)
+
+    prev = boc[0]
+    for i, out_c in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else out_c, out_c)
+        if i != len(boc) - 1:
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (out_c,)
+        prev = out_c
+    c = boc[-1]
+    resnet("encoder.mid_block.resnets.0", c, c)
+    a = "encoder.mid_block.attentions.0"
+    s[a + ".group_norm.weight"] = (c,)
+    s[a + ".group_norm.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{a}.{n}.weight"] = (c, c)
+        s[f"{a}.{n}.bias"] = (c,)
+    resnet("encoder.mid_block.resnets.1", c, c)
+    s["encoder.conv_norm_out.weight"] = (c,)
+    s["encoder.conv_norm_out.bias"] = (c,)
+    s["encoder.conv_out.weight"] = (2 * lc, c, 3, 3)
+    s["encoder.conv_out.bias"] = (2 * lc,)
+    s["quant_conv.weight"] = (2 * lc, 2 * lc, 1, 1)
+    s["quant_conv.bias"] = (2 * lc,)
+    return s
+
+
+def random_vae_state_dict(cfg, seed=0, dtype=torch.float32):
+    """encoder + decoder (the full AutoencoderKL state dict)"""
+    shapes = OrderedDict(vae_encoder_param_shapes(cfg))
+    shapes.update(vae_decoder_param_shapes(cfg))
+    return _fill(shapes, seed, dtype)
