@@ -269,6 +269,23 @@ int tg_guidance_ratio(const float* attn, int32_t heads, int32_t hw, int32_t n_to
                       float scale, float* out, float* grad, void* stream);
 int tg_guidance_ref(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token, const float* ref,
                     const float* mask, float eps, float scale, float* out, float* grad, void* stream);
+/* One launch for a whole compute_ca_lossv3 call (utils/guidance.py:244-286: 4 keys x objects x token positions): block i
+ * evaluates items[i] (kind 0 = top-k term :130-144, 1 = ratio term :122-128, 2 = reference-attention term :223-233, fields
+ * as in the three entry points above) into partials[i]; a second kernel then adds the partials to out[0] IN ITEM ORDER, the
+ * same sequence of additions the per-item launches perform (bit-identical loss).  `items_device` lives in device memory;
+ * items of one call must not share a (grad, token) column; max_hw_topk = largest hw among the kind-0 items (0 if none),
+ * max_heads = largest head count: they size the dynamic LDS (TG_ERR_ARG when a map is too large for the select). */
+typedef struct {
+  const float* attn;
+  float* grad;          /* or NULL */
+  const float* mask;
+  const float* ref;     /* kind 2 only */
+  int32_t heads, hw, n_tok, token;
+  int32_t kind, k_fg, k_bg, reserved;
+  float fg_w, bg_w, scale, eps;
+} tg_guidance_item;
+int tg_guidance_batch(const tg_guidance_item* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
+                      float* partials, float* out, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

@@ -224,7 +224,8 @@ def test_vae_decoder_tables_and_oracle_cpu():
     assert sum(math.prod(s) for s in weights.vae_decoder_param_shapes(sd_vae_config()).values()) == 49_490_199
     cfg = tiny_vae_config()
     m = AutoencoderKL(cfg)
-    shapes = weights.vae_decoder_param_shapes(cfg)
+    shapes = dict(weights.vae_decoder_param_shapes(cfg))
+    shapes.update(weights.vae_encoder_param_shapes(cfg))          # the module now carries the encoder half as well
     sd = m.state_dict()
     assert set(sd.keys()) == set(shapes.keys())
     for k, v in sd.items():
@@ -234,6 +235,34 @@ def test_vae_decoder_tables_and_oracle_cpu():
     img = ov.decode(cfg, rnd, lat)
     assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
     assert torch.allclose(ov.decode(cfg, rnd, lat * 2.0, scaling_factor=2 * cfg.scaling_factor), img, atol=1e-5)
+
+
+def test_vae_encoder_tables_and_oracle_cpu():
+    """VAE encode (second half): parameter table == the public SD VAE encoder count, module keys ==
+    diffusers names, the oracle's bottom / right padded downsample halves even sizes, sampling convention."""
+    import math
+    import torch
+    from oracle import vae as ov
+    from theatergen_amd import weights
+    from theatergen_amd.vae import AutoencoderKL, sd_vae_config, tiny_vae_config
+    enc = weights.vae_encoder_param_shapes(sd_vae_config())
+    assert sum(math.prod(s) for k, s in enc.items() if k.startswith("encoder.")) == 34_163_592
+    full = sum(math.prod(s) for s in enc.values()) + sum(math.prod(s) for s in weights.vae_decoder_param_shapes(sd_vae_config()).values())
+    assert full == 83_653_863                                      # the public parameter count of the SD VAE
+    cfg = tiny_vae_config()
+    m = AutoencoderKL(cfg)
+    shapes = dict(weights.vae_encoder_param_shapes(cfg))
+    shapes.update(weights.vae_decoder_param_shapes(cfg))
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    rnd = weights.random_vae_state_dict(cfg, seed=2)
+    img = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    mo = ov.encode_moments(cfg, rnd, img)
+    assert mo.shape == (1, 8, 8, 8) and torch.isfinite(mo).all()
+    z = ov.sample_latents(cfg, mo, torch.zeros(1, 4, 8, 8))
+    assert torch.allclose(z, cfg.scaling_factor * mo[:, :4])
 
 
 def test_story_workload_and_sharding():

@@ -526,6 +526,86 @@ def test_vae_decode_tiny_vs_oracle(dtype):
     close(img2, ref, net_tol(dtype), "vae decode tiny")
 
 
+def _build_vae_full(cfg, dtype, seed=2):
+    from theatergen_amd import weights as W
+    from theatergen_amd.vae import AutoencoderKL
+    sd = W.random_vae_state_dict(cfg, seed=seed)
+    sd_r = {k: v.to(dtype).float() for k, v in sd.items()}
+    return AutoencoderKL.from_state_dict(cfg, sd, device=DEV, dtype=dtype), sd_r
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vae_encode_tiny_vs_oracle(dtype):
+    """AutoencoderKL.encode (reference models/pipelines.py:131-160, 624-626): conv_in, 4 down blocks with the bottom / right
+    padded stride-2 downsample (pad_mode 1), mid block, GroupNorm+SiLU, conv_out to the moments, quant_conv,
+    latent_dist.sample(generator) with the host draw, scaling factor; then scheduler.add_noise over all timesteps (:629-631)."""
+    from oracle import ddim as oddim
+    from oracle import vae as ov
+    from theatergen_amd.scheduler import DDIMScheduler
+    from theatergen_amd.vae import tiny_vae_config
+    cfg = tiny_vae_config()
+    vae, sd_r = _build_vae_full(cfg, dtype)
+    g = torch.Generator().manual_seed(16)
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    ref_m = ov.encode_moments(cfg, sd_r, img.to(dtype).float())
+    dist = vae.encode(img.to(DEV, dtype)).latent_dist
+    assert dist.parameters.shape == (2, 8, 8, 8) and dist.parameters.dtype == torch.float32
+    close(dist.parameters, ref_m, net_tol(dtype), "vae encode tiny: moments")
+    noise = torch.randn((2, 4, 8, 8), generator=torch.manual_seed(33), dtype=dtype)
+    lat = dist.sample(torch.manual_seed(33), scale=cfg.scaling_factor)
+    assert lat.dtype == dtype and lat.shape == (2, 4, 8, 8)
+    close(lat, ov.sample_latents(cfg, ref_m, noise.float()), net_tol(dtype), "vae encode tiny: scaled sample")
+    close(vae.encode_latents(img.to(DEV, dtype), torch.manual_seed(33)), ov.sample_latents(cfg, ref_m, noise.float()), net_tol(dtype),
+          "vae encode_latents tiny")
+    close(dist.mode(), ref_m[:, :4], net_tol(dtype), "vae encode tiny: mode")
+    # decode(encode(x)) runs end to end on one module
+    rec = vae.decode_latents(lat)[0]
+    assert rec.shape == (2, 3, 64, 64) and torch.isfinite(rec).all()
+    # scheduler.add_noise over the whole timestep table (pipelines.py:629-631)
+    sch, osch = DDIMScheduler(), oddim.DDIMSchedule()
+    sch.set_timesteps(50)
+    x0 = torch.randn(1, 4, 8, 8, generator=g)
+    nz = torch.randn(1, 4, 8, 8, generator=g)
+    got = sch.add_noise(x0.to(DEV), nz.to(DEV), sch.timesteps)
+    want = torch.stack([osch.add_noise(x0[0], nz[0], t) for t in sch.timesteps.tolist()])
+    assert got.shape == (50, 4, 8, 8) and torch.allclose(got.cpu(), want, rtol=1e-6, atol=1e-6)
+
+
+def test_vae_encode_sd_full_vs_oracle():
+    """The SD-1.5 VAE encoder (34.2 M parameters): 512x512 image -> 64x64 moments (0.57 TMAC)."""
+    from oracle import vae as ov
+    from theatergen_amd.vae import sd_vae_config
+    dtype = torch.bfloat16
+    cfg = sd_vae_config()
+    vae, sd_r = _build_vae_full(cfg, dtype)
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref_m = ov.encode_moments(cfg, sd_r, img.to(dtype).float())
+    dist = vae.encode(img.to(DEV, dtype)).latent_dist
+    assert dist.parameters.shape == (1, 8, 64, 64)
+    close(dist.parameters, ref_m, net_tol(dtype), "sd vae encode 512x512: moments")
+
+
+def test_conv_bottom_right_padded_stride2():
+    """pad_mode 1 of the implicit-GEMM conv = F.pad(x, (0, 1, 0, 1)) + conv2d(stride 2, padding 0) (diffusers Downsample2D(padding=0))"""
+    import torch.nn.functional as F
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    g = torch.Generator().manual_seed(18)
+    for dtype in DTYPES:
+        for (B, H, W, C, N) in ((2, 16, 16, 64, 64), (1, 10, 14, 128, 192)):
+            x = torch.randn(B, C, H, W, generator=g).to(dtype)
+            w = (torch.randn(N, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(dtype)
+            b = torch.randn(N, generator=g).to(dtype)
+            ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+            xt = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV)
+            out = ops.conv3x3(xt, pack_conv3x3(w).to(DEV), B, H, W, C, stride=2, bias=b.to(DEV), pad_mode=1)
+            oh, ow = ref.shape[-2:]
+            assert out.shape == (B * oh * ow, N)
+            close(out.reshape(B, oh, ow, N).permute(0, 3, 1, 2), ref, op_tol(dtype), f"conv pad_mode 1 {(B, H, W, C, N)}")
+
+
 def test_vae_softmax_rows_and_pointwise_kernels():
     from theatergen_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -521,3 +521,90 @@ def test_guidance_reference_attention_transfer():
             assert torch.allclose(grads[k].cpu(), rg, rtol=1e-4, atol=1e-6), (kw, k)
         plain = G.compute_ca_lossv3(dmaps, gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2], keys, **args)
         assert abs(plain.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+
+
+def test_guidance_at_sd21_map_sizes_and_batched_launch():
+    """BASELINE.json configs[3] (SD-2.1 768x768, 4 boxes): the guidance keys are the mid block (12 x 12 = 144 pixels) and the
+    three up-1 layers (24 x 24 = 576), 20 heads; non-power-of-two maps, 4 boxes incl. a two-box object, top-k and ratio
+    forms, loss and d loss / d A against the oracle.  compute_ca_lossv3 issues ONE batched launch for all its terms: the
+    result must equal the per-term launches bit for bit."""
+    from oracle import guidance_loss as og
+    from tests.golden import gen_common as gc
+    from theatergen_amd import guidance as G
+    from theatergen_amd import ops
+    dev = _dev()
+    keys = gc.GUIDANCE_KEYS
+    hw = {keys[0]: 144, keys[1]: 576, keys[2]: 576, keys[3]: 576}
+    g = torch.Generator().manual_seed(4242)
+    maps = {}
+    for k in keys:
+        a = torch.rand(1, 20, hw[k], 77, generator=g)
+        maps[k] = a / a.sum(-1, keepdim=True)
+    boxes, pos = gc.GUIDANCE_BOXES[4], gc.GUIDANCE_POSITIONS[4]
+    for kw in (dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0), dict(use_ratio_based_loss=True)):
+        saved = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+        ref = og.compute_ca_lossv3(saved, boxes, pos, keys, **kw)
+        ref_grads = torch.autograd.grad(ref, [saved[k] for k in keys])
+        dmaps = {k: v.to(dev) for k, v in maps.items()}
+        loss, grads = G.compute_ca_lossv3(dmaps, boxes, pos, keys, return_grads=True, **kw)
+        assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (kw, loss.item(), ref.item())
+        for k, rg in zip(keys, ref_grads):
+            assert torch.allclose(grads[k].cpu(), rg, rtol=1e-4, atol=1e-7), (kw, k)
+        # the same terms, one launch each (the round-1 path): identical bits
+        seq = torch.zeros(1, dtype=torch.float32, device=dev)
+        seq_grads = {k: torch.zeros_like(dmaps[k][0]) for k in keys}
+        norm = 1.0 / (len(boxes) * len(keys))
+        for k in keys:
+            G.add_ca_loss_per_attn_map_to_loss(seq, dmaps[k][0].contiguous(), len(boxes), boxes, pos, grad=seq_grads[k], scale=norm, **kw)
+        assert seq.item() == loss.item(), (seq.item(), loss.item())
+        for k in keys:
+            assert torch.equal(seq_grads[k], grads[k][0])
+    # a map too large for the LDS-resident select is an argument error, not a launch failure (hw = 9216 = SD-2.1 level 0)
+    big = torch.rand(2, 9216, 8, device=dev)
+    with pytest.raises(RuntimeError, match="too large"):
+        ops.guidance_topk(big, 1, torch.ones(9216, device=dev), 10, 10, 1.0, 1.0, 1.0, torch.zeros(1, device=dev))
+    b = ops.GuidanceBatch(dev)
+    b.add(b.KIND_TOPK, big, 1, torch.ones(9216, device=dev), 1.0, k_fg=10, k_bg=10, fg_w=1.0, bg_w=1.0)
+    with pytest.raises(RuntimeError, match="too large"):
+        b.flush(torch.zeros(1, device=dev))
+
+
+def test_latent_shift_and_compose_at_96x96():
+    """configs[3] geometry: 768 x 768 -> 96 x 96 latents, 4 objects; zero-filled shift and masked paste are data movement:
+    bit-exact against the oracle."""
+    from oracle import box_geometry as geo
+    from oracle import latent_ops as ol
+    from theatergen_amd import latents as L
+    from theatergen_amd import utils as U
+    dev = _dev()
+    g = torch.Generator().manual_seed(96)
+    S = 11
+    lat_all = [torch.randn(S, 1, 4, 96, 96, generator=g) for _ in range(4)]
+    masks = []
+    for i in range(4):
+        m = torch.zeros(96, 96, dtype=torch.bool)
+        y0, x0 = 6 + 17 * i, 9 + 13 * i
+        m[y0:y0 + 22 + 2 * i, x0:x0 + 18 + 3 * i] = True
+        m &= torch.rand(96, 96, generator=g) > 0.1
+        masks.append(m)
+    boxes = [[0.05, 0.1, 0.35, 0.5], [0.5, 0.1, 0.9, 0.45], [0.1, 0.55, 0.45, 0.95], [0.55, 0.6, 0.95, 0.98]]
+    for xo, yo in ((0.13, -0.21), (-0.5, 0.0), (0.07, 0.06)):
+        got = U.shift_tensor(lat_all[0].to(dev), xo, yo, offset_normalized=True).cpu()
+        assert torch.equal(got, geo.shift_tensor(lat_all[0], xo, yo, offset_normalized=True))
+    new_l, new_m, offs = L.align_with_bboxes([x.to(dev) for x in lat_all], masks, boxes)
+    rl, rm, roffs = ol.align_with_bboxes(lat_all, masks, boxes)
+    assert offs == roffs and all(torch.equal(a, b) for a, b in zip(new_m, rm))
+    assert all(torch.equal(a.cpu(), b) for a, b in zip(new_l, rl))
+    bg = torch.randn(1, 4, 96, 96, generator=g)
+
+    class _Cfg:
+        in_channels = 4
+
+    class _Unet:
+        config = _Cfg()
+        dtype = torch.float32
+
+    ad = type("A", (), {"pipe": type("P", (), {"unet": _Unet(), "scheduler": type("Sc", (), {"init_noise_sigma": 1.0})()})()})()
+    comp, fgidx = L.compose_latents(ad, None, new_l, new_m, S - 1, 1, 768, 768, latents_bg=bg.to(dev))
+    rcomp, rfg = ol.compose_latents(rl, rm, bg, S)
+    assert torch.equal(fgidx.cpu(), rfg) and torch.equal(comp.cpu(), rcomp)

@@ -40,6 +40,15 @@ class AttnDesc(C.Structure):
     ]
 
 
+class GuidanceItem(C.Structure):
+    _fields_ = [
+        ("attn", vp), ("grad", vp), ("mask", vp), ("ref", vp),
+        ("heads", i32), ("hw", i32), ("n_tok", i32), ("token", i32),
+        ("kind", i32), ("k_fg", i32), ("k_bg", i32), ("reserved", i32),
+        ("fg_w", f32), ("bg_w", f32), ("scale", f32), ("eps", f32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/theatergen_hip.h
 SIGNATURES = {
     "tg_version": (i32, []),
@@ -70,6 +79,7 @@ SIGNATURES = {
     "tg_guidance_topk": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, f32, f32, f32, vp, vp, vp]),
     "tg_guidance_ratio": (i32, [vp, i32, i32, i32, i32, vp, f32, vp, vp, vp]),
     "tg_guidance_ref": (i32, [vp, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
+    "tg_guidance_batch": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

@@ -34,10 +34,10 @@ __device__ void wave_topk_select(const float* x, int n, int k, int lane, float& 
   sum_gt = wave_sum(s);
 }
 
-__global__ __launch_bounds__(64 * G_WAVES) void guidance_topk_kernel(const float* attn, int heads, int hw, int n_tok, int token,
-                                                                     const float* mask, int k_fg, int k_bg, float fg_w,
-                                                                     float bg_w, float scale, float* out, float* grad) {
-  extern __shared__ float sh[];
+// each *_block function is executed by a whole 256-thread block and returns (in thread 0) the term the reference adds to
+// the loss for ONE (attention map, object, token position); `grad` (optional) is accumulated in place
+__device__ float guidance_topk_block(float* sh, const float* attn, int heads, int hw, int n_tok, int token, const float* mask,
+                                     int k_fg, int k_bg, float fg_w, float bg_w, float scale, float* grad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xf = sh + (size_t)wave * 2 * hw;   // A * M
   float* xb = xf + hw;                      // A * (1 - M)
@@ -82,16 +82,17 @@ __global__ __launch_bounds__(64 * G_WAVES) void guidance_topk_kernel(const float
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+  float term = 0.f;
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
-    out[0] += scale * s;
+    term = scale * s;
   }
+  return term;
 }
 
-__global__ __launch_bounds__(64 * G_WAVES) void guidance_ratio_kernel(const float* attn, int heads, int hw, int n_tok, int token,
-                                                                      const float* mask, float scale, float* out, float* grad) {
-  extern __shared__ float head_loss[];
+__device__ float guidance_ratio_block(float* head_loss, const float* attn, int heads, int hw, int n_tok, int token,
+                                      const float* mask, float scale, float* grad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int h = wave; h < heads; h += G_WAVES) {
     const float* col = attn + (long)h * hw * n_tok + token;
@@ -112,19 +113,19 @@ __global__ __launch_bounds__(64 * G_WAVES) void guidance_ratio_kernel(const floa
     }
   }
   __syncthreads();
+  float term = 0.f;
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
-    out[0] += scale * s / (float)heads;
+    term = scale * s / (float)heads;
   }
+  return term;
 }
 
 // attention-transfer term (utils/guidance.py:223-233): per head, the masked current column and the masked reference
 // column are each normalised by (their sum + eps); loss = mean over heads of the L1 distance.  ref: [heads, hw].
-__global__ __launch_bounds__(64 * G_WAVES) void guidance_ref_kernel(const float* attn, int heads, int hw, int n_tok, int token,
-                                                                    const float* ref, const float* mask, float eps,
-                                                                    float scale, float* out, float* grad) {
-  extern __shared__ float head_loss[];
+__device__ float guidance_ref_block(float* head_loss, const float* attn, int heads, int hw, int n_tok, int token, const float* ref,
+                                    const float* mask, float eps, float scale, float* grad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int h = wave; h < heads; h += G_WAVES) {
     const float* col = attn + (long)h * hw * n_tok + token;
@@ -160,14 +161,74 @@ __global__ __launch_bounds__(64 * G_WAVES) void guidance_ref_kernel(const float*
     }
   }
   __syncthreads();
+  float term = 0.f;
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
-    out[0] += scale * s / (float)heads;
+    term = scale * s / (float)heads;
+  }
+  return term;
+}
+
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_topk_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                     const float* mask, int k_fg, int k_bg, float fg_w,
+                                                                     float bg_w, float scale, float* out, float* grad) {
+  extern __shared__ float sh[];
+  const float t = guidance_topk_block(sh, attn, heads, hw, n_tok, token, mask, k_fg, k_bg, fg_w, bg_w, scale, grad);
+  if (threadIdx.x == 0) out[0] += t;
+}
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_ratio_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                      const float* mask, float scale, float* out, float* grad) {
+  extern __shared__ float sh[];
+  const float t = guidance_ratio_block(sh, attn, heads, hw, n_tok, token, mask, scale, grad);
+  if (threadIdx.x == 0) out[0] += t;
+}
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_ref_kernel(const float* attn, int heads, int hw, int n_tok, int token,
+                                                                    const float* ref, const float* mask, float eps,
+                                                                    float scale, float* out, float* grad) {
+  extern __shared__ float sh[];
+  const float t = guidance_ref_block(sh, attn, heads, hw, n_tok, token, ref, mask, eps, scale, grad);
+  if (threadIdx.x == 0) out[0] += t;
+}
+
+// ONE launch for a whole compute_ca_lossv3 call: block i evaluates items[i] (any mix of the three term kinds, any map
+// size) and writes its term to partials[i]; the last line of the loss — the sum over items — is a second tiny kernel that
+// adds the partials in ITEM ORDER, i.e. exactly the sequence of `loss += term` the per-item launches perform: same bits,
+// ~40 dependent launches fewer for 4 boxes x 4 keys.  Items of one launch never share a (grad, token) column (host rule).
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_batch_kernel(const tg_guidance_item* items, float* partials) {
+  extern __shared__ float sh[];
+  const tg_guidance_item it = items[blockIdx.x];
+  float t;
+  if (it.kind == 0) t = guidance_topk_block(sh, it.attn, it.heads, it.hw, it.n_tok, it.token, it.mask, it.k_fg, it.k_bg, it.fg_w, it.bg_w, it.scale, it.grad);
+  else if (it.kind == 1) t = guidance_ratio_block(sh, it.attn, it.heads, it.hw, it.n_tok, it.token, it.mask, it.scale, it.grad);
+  else t = guidance_ref_block(sh, it.attn, it.heads, it.hw, it.n_tok, it.token, it.ref, it.mask, it.eps, it.scale, it.grad);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ void guidance_fold_kernel(const float* partials, int n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = out[0];
+    for (int i = 0; i < n; ++i) s += partials[i];
+    out[0] = s;
   }
 }
 
 }  // namespace
+
+extern "C" int tg_guidance_batch(const tg_guidance_item* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
+                                 float* partials, float* out, void* stream) {
+  TG_CHECK(items_device && partials && out && n_items > 0 && max_heads > 0 && max_hw_topk >= 0, TG_ERR_ARG, "tg_guidance_batch: bad args");
+  const size_t lds = ((size_t)G_WAVES * 2 * max_hw_topk + max_heads) * sizeof(float);
+  TG_CHECK(lds <= 160 * 1024, TG_ERR_ARG, "tg_guidance_batch: attention map too large for the top-k select (hw = %d needs %zu bytes of LDS, "
+           "160 KB available)", max_hw_topk, lds);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(guidance_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(guidance_batch_kernel, dim3((unsigned)n_items), dim3(64 * G_WAVES), lds, st, items_device, partials);
+  TG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(guidance_fold_kernel, dim3(1), dim3(64), 0, st, partials, n_items, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
 
 extern "C" int tg_guidance_ref(const float* attn, int32_t heads, int32_t hw, int32_t n_tok, int32_t token,
                                const float* ref, const float* mask, float eps, float scale, float* out, float* grad,
@@ -188,7 +249,7 @@ extern "C" int tg_guidance_topk(const float* attn, int32_t heads, int32_t hw, in
            "tg_guidance_topk: bad args");
   TG_CHECK(k_fg >= 1 && k_fg <= hw && k_bg >= 1 && k_bg <= hw, TG_ERR_ARG, "tg_guidance_topk: k out of range");
   const size_t lds = ((size_t)G_WAVES * 2 * hw + heads) * sizeof(float);
-  TG_CHECK(lds <= 160 * 1024, TG_ERR_ARG, "tg_guidance_topk: hw too large (%d)", hw);
+  TG_CHECK(lds <= 160 * 1024, TG_ERR_ARG, "tg_guidance_topk: attention map too large for the top-k select (hw = %d needs %zu bytes of LDS, 160 KB available)", hw, lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(guidance_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -28,9 +28,10 @@ def _box_mask(obj_boxes, H, W, device):
 
 def add_ca_loss_per_attn_map_to_loss(loss, attn_map, object_number, bboxes, object_positions, use_ratio_based_loss=True,
                                      fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0, verbose=False,
-                                     grad=None, scale=1.0):
+                                     grad=None, scale=1.0, batch=None):
     """reference guidance.py:91-148.  ``loss``: fp32 device scalar tensor [1] accumulated IN PLACE;
-    ``attn_map`` fp32 [heads, HW, tokens]; ``grad`` (optional) same shape, accumulated in place."""
+    ``attn_map`` fp32 [heads, HW, tokens]; ``grad`` (optional) same shape, accumulated in place.  With ``batch`` (an
+    ``ops.GuidanceBatch``) the terms are only queued; the caller flushes them in one launch."""
     b, i, j = attn_map.shape
     H = W = int(math.sqrt(i))
     attn_map = attn_map.contiguous()
@@ -43,7 +44,12 @@ def add_ca_loss_per_attn_map_to_loss(loss, attn_map, object_number, bboxes, obje
             k_fg = int((msum * fg_top_p).long().clamp_(min=1))
             k_bg = int(((1 - mask_host).sum() * bg_top_p).long().clamp_(min=1))
         for pos in object_positions[obj_idx]:
-            if use_ratio_based_loss:
+            if batch is not None:
+                if use_ratio_based_loss:
+                    batch.add(batch.KIND_RATIO, attn_map, pos, mask, scale / n_pos, grad)
+                else:
+                    batch.add(batch.KIND_TOPK, attn_map, pos, mask, scale / n_pos, grad, k_fg=k_fg, k_bg=k_bg, fg_w=fg_weight, bg_w=bg_weight)
+            elif use_ratio_based_loss:
                 ops.guidance_ratio(attn_map, pos, mask, scale / n_pos, loss, grad)
             else:
                 ops.guidance_topk(attn_map, pos, mask, k_fg, k_bg, fg_weight, bg_weight, scale / n_pos, loss, grad)
@@ -53,7 +59,7 @@ def add_ca_loss_per_attn_map_to_loss(loss, attn_map, object_number, bboxes, obje
 def add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bboxes, object_positions, guidance_attn_keys,
                                            ref_ca_saved_attns, ref_ca_last_token_only, ref_ca_word_token_only,
                                            word_token_indices, index, loss_weight, eps=1e-5, verbose=False, grads=None,
-                                           scale=1.0):
+                                           scale=1.0, batch=None):
     """reference guidance.py:150-242 (attention transfer from saved per-box reference maps).  ``loss``: fp32 device
     scalar tensor [1] accumulated IN PLACE; ``grads``: optional {key: fp32 tensor like saved_attn[key]} accumulated in
     place; ``scale`` multiplies every added term (compute_ca_lossv3's 1 / (n_obj * n_keys))."""
@@ -88,7 +94,12 @@ def add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bbox
                     g = grads[key]
                     g = g.squeeze(dim=0) if g.dim() == 4 else g
                 for pos in positions:
-                    ops.guidance_ref(amap3, pos, rcol, mask, eps, term, loss, g)
+                    if batch is not None:
+                        if rcol.numel() != amap3.shape[0] * amap3.shape[1]:
+                            raise RuntimeError("guidance: reference map shape does not match the attention map")
+                        batch.add(batch.KIND_REF, amap3, pos, mask, term, g, ref=rcol, eps=eps)
+                    else:
+                        ops.guidance_ref(amap3, pos, rcol, mask, eps, term, loss, g)
     return loss
 
 
@@ -107,6 +118,7 @@ def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, 
     if object_number == 0 or len(guidance_attn_keys) == 0:
         return (loss[0], grads) if return_grads else loss[0]
     norm = 1.0 / (object_number * len(guidance_attn_keys))
+    batch = ops.GuidanceBatch(loss.device)          # every term of this call: one launch + an in-order fold
     for key in guidance_attn_keys:
         amap = saved_attn[key]
         if amap.dtype != torch.float32:
@@ -116,12 +128,14 @@ def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, 
         if return_grads:
             g = torch.zeros_like(amap3)
             grads[key] = g.reshape(amap.shape)
-        add_ca_loss_per_attn_map_to_loss(loss, amap3, object_number, bboxes, object_positions, grad=g, scale=norm, **kwargs)
+        add_ca_loss_per_attn_map_to_loss(loss, amap3.contiguous(), object_number, bboxes, object_positions, grad=g, scale=norm,
+                                         batch=batch, **kwargs)
     if ref_ca_saved_attns is not None:
         add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bboxes, object_positions, guidance_attn_keys,
                                                ref_ca_saved_attns, ref_ca_last_token_only, ref_ca_word_token_only,
                                                word_token_indices, index, ref_ca_loss_weight,
-                                               grads=grads if return_grads else None, scale=norm)
+                                               grads=grads if return_grads else None, scale=norm, batch=batch)
+    batch.flush(loss)
     return (loss[0], grads) if return_grads else loss[0]
 
 

@@ -369,3 +369,51 @@ def guidance_ratio(attn, token, mask, scale, out, grad=None):
     heads, hw, n_tok = attn.shape
     _lib.check(_lib.lib().tg_guidance_ratio(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), float(scale), _ptr(out),
                                             _ptr(grad), _stream()))
+
+
+class GuidanceBatch:
+    """Collects the terms of one ``compute_ca_lossv3`` call (one per attention map x object x token position) and evaluates
+    them with ONE ``tg_guidance_batch`` launch + an in-order fold instead of one dependent launch each.  Terms whose
+    gradient columns would collide (same grad tensor and token in one call) are split over consecutive launches."""
+    KIND_TOPK, KIND_RATIO, KIND_REF = 0, 1, 2
+
+    def __init__(self, device):
+        self.device = device
+        self.items, self.keep = [], []
+
+    def add(self, kind, attn, token, mask, scale, grad=None, ref=None, k_fg=0, k_bg=0, fg_w=0.0, bg_w=0.0, eps=0.0):
+        heads, hw, n_tok = attn.shape
+        if not (0 <= int(token) < n_tok):
+            raise RuntimeError(f"guidance: token position {token} outside the {n_tok} text tokens")
+        if kind == self.KIND_TOPK and not (1 <= k_fg <= hw and 1 <= k_bg <= hw):
+            raise RuntimeError("guidance: top-k size out of range")
+        it = _lib.GuidanceItem()
+        it.attn, it.grad, it.mask, it.ref = _ptr(attn), _ptr(grad), _ptr(mask), _ptr(ref)
+        it.heads, it.hw, it.n_tok, it.token = int(heads), int(hw), int(n_tok), int(token)
+        it.kind, it.k_fg, it.k_bg = int(kind), int(k_fg), int(k_bg)
+        it.fg_w, it.bg_w, it.scale, it.eps = float(fg_w), float(bg_w), float(scale), float(eps)
+        self.items.append(it)
+        self.keep += [attn, grad, mask, ref]
+
+    def flush(self, loss):
+        """loss: fp32 device tensor [1], accumulated in place in item order"""
+        items, self.items = self.items, []
+        while items:
+            seen, now, later = set(), [], []
+            for it in items:
+                col = (it.grad, it.token) if it.grad else None
+                if col is not None and col in seen:
+                    later.append(it)              # keeps item order within each launch; collisions go to the next one
+                else:
+                    if col is not None:
+                        seen.add(col)
+                    now.append(it)
+            arr = (_lib.GuidanceItem * len(now))(*now)
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            partials = torch.empty(len(now), dtype=torch.float32, device=self.device)
+            max_hw = max([it.hw for it in now if it.kind == self.KIND_TOPK] + [0])
+            _lib.check(_lib.lib().tg_guidance_batch(table.data_ptr(), len(now), max_hw, max(it.heads for it in now),
+                                                    partials.data_ptr(), _ptr(loss), _stream()))
+            self.keep += [table, partials]
+            items = later
+        return loss

@@ -92,3 +92,22 @@ class DDIMScheduler:
     def add_noise_coeffs(self, timesteps):
         a = self.alphas_cumprod[timesteps]
         return a ** 0.5, (1 - a) ** 0.5
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """diffusers ``add_noise``: ``sqrt(a_t) x0 + sqrt(1 - a_t) noise`` broadcast over a vector of timesteps, as the
+        stage-2 path calls it with ALL 50 timesteps at once (reference models/pipelines.py:629-631: [1, C, h, w] latents
+        -> [50, C, h, w]).  One ``tg_add_noise`` launch on the device; result in the dtype of ``original_samples``."""
+        ts = torch.as_tensor(timesteps).reshape(-1).to("cpu", torch.long)
+        ca, cb = self.add_noise_coeffs(ts)
+        dev = original_samples.device
+        x0 = original_samples.detach().to(torch.float32).contiguous()
+        nz = noise.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if x0.shape[0] not in (1, ts.numel()) or nz.shape != x0.shape:
+            raise ValueError("add_noise: samples / noise must have batch 1 (broadcast over the timesteps) or one row per timestep")
+        if x0.shape[0] == 1:
+            out = ops.add_noise(x0[0], nz[0], ca.to(dev, torch.float32), cb.to(dev, torch.float32))
+        else:
+            rows = [ops.add_noise(x0[i], nz[i], ca[i:i + 1].to(dev, torch.float32), cb[i:i + 1].to(dev, torch.float32))[0]
+                    for i in range(ts.numel())]
+            out = torch.stack(rows)
+        return out.to(original_samples.dtype)
