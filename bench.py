@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16/fp16, MI355X_MICROARCH.md
 SD15_FLOP_PER_CFG_CALL = 1.607e12  # 401.8 GMAC / sample, batch 2
+PLAN_FLOP_PER_CFG_CALL = {"sd15": 1.607e12, "sd21": 4.30e12, "sdxl": 13.56e12}      # SURVEY.md §8(d), batch-2 CFG unit
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md (6.3 TB/s achievable)
 
 
 def parse():
@@ -48,10 +50,16 @@ def parse():
                          "overlapping with the other chain, so per-kernel roofline / rocprof figures are no longer those of "
                          "one kernel owning the chip: the default line keeps 1")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--plan", default="sd15")
+    ap.add_argument("--plan", default="sd15", choices=["sd15", "sd21", "sdxl"],
+                    help="sd15 = the north-star line (BASELINE.json configs[1]); sd21 = configs[3] (768px editing step with 4-box "
+                         "guidance); sdxl = configs[4] (1024px, IP-Adapter-Plus, use --dtype fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=3)
+    ap.add_argument("--cpu-loop-steps", type=int, default=0,
+                    help="also run BASELINE.json configs[0] as an actual loop on the CPU oracle: SD-1.5 512x512, ONE character box, this "
+                         "many DDIM steps (20 = the config; ~100 s at 64 threads), latents by the reference recipe; recorded as "
+                         "cpu_baseline.config1_loop next to the bounded-sample extrapolation")
     ap.add_argument("--with-vae", action="store_true",
                     help="NOT the north-star line: also decode the 8 final latents of every story with the VAE (pipelines.py:468) "
                          "inside the timed region, i.e. end-to-end decoded images/s")
@@ -106,13 +114,17 @@ def roofline_leg(unet, engine):
     # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     # process); algorithmic bytes (operands once + result once) from the live launch records for comparison
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
-    except (OSError, KeyError, ValueError):
-        pass
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for fn in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True):   # newest round first
+        try:
+            with open(os.path.join(pdir, fn)) as f:
+                pmc = json.load(f)
+            traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+            traffic_src = (f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this bench command, gfx950 x2 "
+                           f"fetch correction; collected at commit {pmc.get('commit', 'n/a')}: rocprofv3 cannot run inside this process)")
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     alg = sum(2.0 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"]) for r in recs if r["kernel"] == name) / top["launches"]
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg),
@@ -125,7 +137,26 @@ def roofline_leg(unet, engine):
                           for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
-def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps):
+def cpu_config1_loop(cfg, sd32, steps):
+    """BASELINE.json configs[0] on the oracle: fp32, 1 box, `steps` DDIM steps with CFG 7.5, reference op order"""
+    from oracle import ddim as oddim
+    from oracle import latent_ops as ol
+    from oracle import unet as ou
+    from theatergen_amd import story
+    lat = ol.get_input_latents_list(0, 123456789, 0.01, 512, 512, [story.box_xyxy(0)])[0][0]
+    enc = torch.randn(2, 81, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(77)) * 0.5
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(steps)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in osch.timesteps.tolist():
+            lat = oddim.step_epilogue(osch, ou.unet_forward(cfg, sd32, torch.cat([lat] * 2), t, enc, ip_scale=0.4, num_tokens=4), t, lat, 7.5)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(lat).all()
+    return {"ddim_steps": steps, "s_per_image": round(dt, 2), "s_per_step": round(dt / steps, 3), "images_per_s": round(1.0 / dt, 6)}
+
+
+def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps, loop_steps=0):
     """The oracle (CPU fp32 restatement of the reference op order) on the host cores: `n_calls` CFG UNet calls."""
     from oracle import unet as ou
     cores = min(os.cpu_count() or 1, 64)
@@ -141,11 +172,15 @@ def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps):
         for i in range(n_calls):
             ou.unet_forward(cfg, sd32, x, 981 - 20 * i, enc, ip_scale=0.4, num_tokens=4)
         dt = (time.perf_counter() - t0) / n_calls
+    loop = cpu_config1_loop(cfg, sd32, loop_steps) if loop_steps > 0 else None
     torch.set_num_threads(prev)
-    return {"value": round(1.0 / (dt * ddim_steps), 6), "unit": "char_images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_calls} CFG UNet calls (batch 2, SD-1.5 512x512, fp32, reference op order incl. unfused "
-                      f"baddbmm/softmax/bmm attention) = {dt:.2f} s/call; x{ddim_steps} calls per char image",
-            "s_per_cfg_call": round(dt, 3)}
+    out = {"value": round(1.0 / (dt * ddim_steps), 6), "unit": "char_images/s", "cores": cores, "kind": "port",
+           "sample": f"{n_calls} CFG UNet calls (batch 2, SD-1.5 512x512, fp32, reference op order incl. unfused "
+                     f"baddbmm/softmax/bmm attention) = {dt:.2f} s/call; x{ddim_steps} calls per char image",
+           "s_per_cfg_call": round(dt, 3)}
+    if loop is not None:
+        out["config1_loop"] = loop
+    return out
 
 
 def self_launch(args):
@@ -183,11 +218,205 @@ def dry_launch(args, D, rank, world):
         raise SystemExit(1)
 
 
+def _ev_ms(fn, iters=1):
+    """HIP-event time of fn() on the current stream (ms per call)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_sd21_editing(args):
+    """BASELINE.json configs[3]: SD-2.1 plan 768x768 (latent 96x96, v-prediction, ctx 1024, 20 heads x 64 on the guidance
+    layers), ONE edited image with 4 character boxes: per DDIM step the CFG UNet call with the attention-map side channel on
+    the 4 guidance keys (cond half), compute_ca_lossv3 over the 4 boxes with its analytic d loss / d A (HIP reductions), and
+    the fused CFG + DDIM + frozen-mask replace epilogue fed by the 4-object composed latents.  Eager launches (the capture
+    side channel fills a host dict and the guidance table is built on the host per call).  NOT the north-star line."""
+    from theatergen_amd import guidance as G
+    from theatergen_amd import latents as L
+    from theatergen_amd import ops, story
+    from theatergen_amd.scheduler import DDIMScheduler
+    device = torch.device("cuda", 0)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    T = 4
+    cfg, sd, unet, adapter = build_model("sd21", dtype, device, num_tokens=T)
+    del sd
+    steps = args.ddim_steps
+    sch = DDIMScheduler(prediction_type="v_prediction")
+    sch.set_timesteps(steps)
+    hw = cfg.sample_size
+    boxes = [story.box_xyxy(i) for i in range(4)]
+    positions = [[2, 3], [7], [10, 11, 12], [15]]
+    keys = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+    g = torch.Generator().manual_seed(40)
+    enc = (torch.randn(2, 77 + T, cfg.cross_attention_dim, generator=g) * 0.5).to(device, dtype)
+    # per-object stage-1 histories (synthetic) -> align + compose at 96x96 (utils/latents.py:168-240), timed separately
+    lat_all = [torch.randn(steps + 1, 1, 4, hw, hw, generator=g).to(device) for _ in range(4)]
+    masks = []
+    for i, b in enumerate(boxes):
+        m = torch.zeros(hw, hw, dtype=torch.bool)
+        x0, y0, x1, y1 = [int(round(v * hw)) for v in b]
+        m[y0 + 2:y1 - 2, x0 + 2:x1 - 2] = True
+        masks.append(m)
+    bg = torch.randn(1, 4, hw, hw, generator=g).to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    new_l, new_m, _ = L.align_with_bboxes(lat_all, masks, boxes)
+    composed, fg_idx = L.compose_latents(adapter, None, new_l, new_m, steps, 1, 8 * hw, 8 * hw, latents_bg=bg)
+    torch.cuda.synchronize()
+    compose_ms = (time.perf_counter() - t0) * 1e3
+    frozen_mask = (fg_idx != 0).to(torch.float32).reshape(1, hw, hw).contiguous()
+    coef = sch.coef_table().to(device)
+    step_idx = torch.zeros(1, dtype=torch.int32, device=device)
+    t_table = sch.timesteps.to(device=device, dtype=torch.float32)
+    from theatergen_amd.unet import DeviceSchedule
+    dsch = DeviceSchedule(t_table, step_idx)
+    latents = composed[0].clone()
+    model_in = torch.cat([latents] * 2).to(dtype)
+    parts = {"unet": 0.0, "guidance": 0.0, "epilogue": 0.0}
+    map_bytes = 0
+
+    def one_step(timed):
+        nonlocal map_bytes
+        saved = {}
+        kw = {"save_attn_to_dict": saved, "save_keys": keys, "return_cond_ca_only": True}
+        out = {}
+
+        def f_unet():
+            out["np"] = unet(model_in, dsch, enc, cross_attention_kwargs=kw, return_dict=False, out_dtype=torch.float32)[0]
+
+        def f_guid():
+            out["loss"], out["grads"] = G.compute_ca_lossv3(saved, boxes, positions, keys, return_grads=True,
+                                                            use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+
+        def f_epi():
+            ops.step_epilogue(out["np"], latents, 7.5, coef, step_idx, advance=True, prediction_type=1, frozen=composed,
+                              frozen_mask=frozen_mask, frozen_steps=steps, history=None, model_in=model_in)
+        if timed:
+            parts["unet"] += _ev_ms(f_unet)
+            parts["guidance"] += _ev_ms(f_guid)
+            parts["epilogue"] += _ev_ms(f_epi)
+            map_bytes = sum(2 * v.numel() * 4 for v in saved.values())       # maps read once, gradients written once
+        else:
+            f_unet(); f_guid(); f_epi()
+        return out
+
+    with torch.no_grad():
+        for _ in range(args.warmup * 2 + 2):
+            one_step(False)
+        step_idx.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_timed = args.steps * steps
+        for i in range(n_timed):
+            if i % steps == 0:
+                step_idx.zero_()
+                latents.copy_(composed[0])
+                model_in.copy_(torch.cat([latents] * 2))
+            res = one_step(False)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        step_idx.zero_()
+        for _ in range(5):
+            one_step(True)
+    assert torch.isfinite(res["np"]).all() and torch.isfinite(res["loss"])
+    ms_step = elapsed / n_timed * 1e3
+    unet_ms = parts["unet"] / 5
+    ach = PLAN_FLOP_PER_CFG_CALL["sd21"] / (unet_ms * 1e-3) / 1e12
+    gb = map_bytes / (parts["guidance"] / 5 * 1e-3) / 1e9
+    result = {
+        "metric": "SD-2.1 768px editing step with 4-box attention-mask guidance: seconds per DDIM step", "value": round(ms_step * 1e-3, 5),
+        "unit": "s/step", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step * steps, 2),
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[3]: SD-2.1 plan 768x768, 1 image x 4 character boxes, {steps} DDIM steps (v-prediction), "
+                               "CFG 7.5, IP 77+4 tokens; per step: CFG-batch-2 UNet with attention capture on 4 keys (12x12 / 24x24 x 20 heads "
+                               "x 77 tokens), compute_ca_lossv3 + d loss / d A over 4 boxes, CFG + DDIM + frozen-mask replace; eager launches",
+                   "plan": "sd21", "ddim_steps": steps, "boxes": 4},
+        "images_per_s": round(1.0 / (ms_step * 1e-3 * steps), 4),
+        "per_step_ms": {k: round(v / 5, 3) for k, v in parts.items()}, "compose_align_ms_once": round(compose_ms, 2),
+        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                     "traffic": None, "kernel": "whole CFG-batch-2 UNet call incl. attention capture (4.30 TFLOP algorithmic, SURVEY 8(d))",
+                     "avg_launch_us": round(unet_ms * 1e3, 1)},
+        "guidance": {"bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 5),
+                     "bytes_per_step": map_bytes, "ms": round(parts["guidance"] / 5, 3),
+                     "note": "4 maps x 20 heads x (144 | 576) x 77 fp32 read + gradients written; latency-bound (1.5 MB per step)"},
+    }
+    print(json.dumps(result), flush=True)
+
+
+def bench_sdxl(args):
+    """BASELINE.json configs[4]: SDXL-base plan 1024x1024 (latent 128x128, text_time conditioning), IP-Adapter-Plus = 16 image
+    tokens from the Perceiver Resampler, fp16, 30 DDIM steps, one image per step (CFG batch 2) on the hipGraph engine;
+    the Resampler (cond + zero-image uncond, once per character) is timed separately.  NOT the north-star line."""
+    from theatergen_amd.pipelines import DenoiseEngine
+    from theatergen_amd.resampler import Resampler
+    from theatergen_amd import weights as W
+    device = torch.device("cuda", 0)
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    T = 16
+    cfg, sd, unet, adapter = build_model("sdxl", dtype, device, num_tokens=T)
+    del sd
+    steps = 30 if args.ddim_steps == 50 else args.ddim_steps
+    g = torch.Generator().manual_seed(50)
+    kw = dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=T, embedding_dim=1280, output_dim=cfg.cross_attention_dim, ff_mult=4)
+    rs = Resampler(**kw)
+    rs.load_state_dict(W.random_resampler_state_dict(seed=401, **kw))
+    rs = rs.to(device, dtype)
+    clip_hidden = torch.randn(2, 257, 1280, generator=g).to(device, dtype)      # cond image + zero image (CLIP penultimate states)
+    with torch.no_grad():
+        for _ in range(3):
+            tok = rs(clip_hidden)
+        res_ms = _ev_ms(lambda: rs(clip_hidden), iters=20)
+    text = (torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.5).to(device, dtype)
+    enc = torch.cat([text, torch.stack([tok[1], tok[0]])], dim=1).contiguous()    # negatives first: uncond tokens on row 0
+    added = {"text_embeds": torch.randn(2, 1280, generator=g).to(device, dtype),
+             "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]] * 2, device=device)}
+    eng = DenoiseEngine(unet, None, n_img=1, height=1024, width=1024, num_inference_steps=steps, guidance_scale=7.5, enc_len=77 + T)
+    eng.set_conditioning(enc, added)
+    lat = torch.randn(1, 4, 128, 128, generator=g)
+    for _ in range(args.warmup):
+        eng.run(lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hist = eng.run(lat)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(hist[-1]).all()
+    s_step = elapsed / (args.steps * steps)
+    ach = PLAN_FLOP_PER_CFG_CALL["sdxl"] / s_step / 1e12
+    result = {
+        "metric": "SDXL 1024px IP-Adapter-Plus: seconds per DDIM step (CFG batch 2)", "value": round(s_step, 5), "unit": "s/step",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if dtype == torch.float16 else "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[4]: SDXL-base plan 1024x1024 (latent 128x128, 2.6 B parameters, text_time conditioning), "
+                               f"IP-Adapter-Plus 77+16 tokens scale 0.4, {steps} DDIM steps, CFG 7.5, one image per step, hipGraph engine",
+                   "plan": "sdxl", "ddim_steps": steps},
+        "images_per_s": round(1.0 / (s_step * steps), 4),
+        "resampler_us_per_character": round(res_ms * 1e3, 1),
+        "resampler_note": "SDXL-Plus Resampler (depth 4, 20 heads x 64, 16 queries, 257 CLIP tokens), batch 2 = cond + zero-image uncond "
+                          "(ip_adapter.py:347-359): 2 x 5.13 GMAC",
+        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                     "traffic": None, "kernel": "whole CFG-batch-2 UNet step (13.56 TFLOP algorithmic, SURVEY 8(d)) incl. the step epilogue",
+                     "avg_launch_us": round(s_step * 1e6, 1)},
+    }
+    print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse()
     from theatergen_amd import distributed as D
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    if args.plan in ("sd21", "sdxl"):
+        if args.gpus != 1:
+            raise SystemExit("bench.py: --plan sd21 / sdxl are single-GPU lines")
+        torch.cuda.set_device(0)
+        return bench_sd21_editing(args) if args.plan == "sd21" else bench_sdxl(args)
     rank, world, local = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -327,7 +556,7 @@ def main():
         if not args.no_roofline:
             result["roofline"] = roofline_leg(unet, engine)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps)
+            result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps, args.cpu_loop_steps)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if D.is_dist():

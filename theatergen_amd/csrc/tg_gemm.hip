@@ -53,6 +53,8 @@ struct GemmParams {
   int tiles_n;
   long a_rpb, a_bs;
   int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
+  int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
+                    // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
 };
 
 struct TileCfg { int bm, bn, bk; };
@@ -107,6 +109,30 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, long m, lon
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(v[j]);
     *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + n4) = o;
+  }
+}
+
+// EXPERIMENT (TG_GEMM_FLAGS bit 0): the two blocks that share a CU start together and have identical work, so they sit in
+// their K loops together (each with half the matrix pipe) and in their epilogues together (matrix pipe idle).  Delay ONE of
+// the two first-round blocks of every CU by about half a tile period so that one block's epilogue overlaps the other's K
+// loop; later rounds inherit the offset (a finished block is replaced at once).  CU identity from the hardware id registers,
+// arrival parity from a never-reset global counter (consecutive arrivals on one CU differ in parity).  Speed only.
+__device__ unsigned int tg_cu_arrivals[2048];
+__device__ __forceinline__ void stagger_first_round(int flags, char* smem_base) {
+  if (!(flags & 1) || gridDim.x < 512 || blockIdx.x >= 512) return;
+  int* dec = reinterpret_cast<int*>(smem_base);
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+    const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+    *dec = (int)(atomicAdd(&tg_cu_arrivals[key], 1u) & 1u);
+  }
+  __syncthreads();
+  const int late = *dec;
+  __syncthreads();
+  if (late) {
+    const int units = (flags >> 8) & 0xff;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);         // ~2048 cycles ~ 1 us each
   }
 }
 
@@ -462,6 +488,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sX = reinterpret_cast<T*>(smem);                 // [2][BM][64]
   T* sW = sX + STAGES * BM * BKT;                     // [STAGES][BN][BKT]
+  stagger_first_round(p.flags, smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -645,6 +672,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (p.flags & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < BKT / 16; ++ks) {
         if constexpr (BIGW) {
@@ -669,6 +697,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
       }
+      if (p.flags & 2) __builtin_amdgcn_s_setprio(0);
       // keep the MFMA chain ABOVE the wait: an asm "memory" clobber does not order register-only MFMAs, and hipcc
       // otherwise hoists `s_waitcnt vmcnt(0); s_barrier` in front of them, exposing the whole DMA latency per tile
       __builtin_amdgcn_sched_barrier(0);
@@ -709,6 +738,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sS = reinterpret_cast<T*>(smem);                 // [NI*8][64]   halo slab of the current channel chunk
+  stagger_first_round(p.flags, smem);
   // weight-tile ring: 3 stages (2 tiles in flight) wherever slab + 3 x 16 KB still lets two blocks share a CU (every
   // variant but the 64-wide one): a K-step's period was one DMA round trip of the next W tile, not its 16 MFMAs
   constexpr int WST = ((size_t)NI * 8 * BK + 3 * BN * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
@@ -1060,6 +1090,10 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.full_tiles = pl.full; p.tail_s = pl.s; p.kt_per_split = pl.kps; p.tiles_n = (int)pl.tiles_n;
   p.tile_bm = kTiles[pl.tile].bm; p.tile_bn = kTiles[pl.tile].bn;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
+  {
+    static const int env_flags = [] { const char* e = getenv("TG_GEMM_FLAGS"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+    p.flags = env_flags;
+  }
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
