@@ -114,7 +114,7 @@ typedef struct {
 int tg_gemm(const tg_gemm_desc* d, void* stream);
 int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
 /* the tile (tokens x channels), the K-split of the tail tiles (1 = none) and the kernel (0 = GEMM, 1 = implicit-GEMM
- * conv, 2 = LDS-halo conv) the heuristic picks for a descriptor (bench / profiling attribution) */
+ * conv, 2 = LDS-halo conv, 3 = big-tile persistent GEMM) the heuristic picks for a descriptor (bench / profiling attribution) */
 int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind);
 
 /* ---------------------------------------------------------------------------------------------

@@ -3,10 +3,10 @@
      ImageProjModel, latent utilities), and
  (b) the CPU oracle (oracle/) on the same seeded inputs for the UNet and the denoising loop.
 
-Stated tolerances (max-abs error relative to max|ref|, storage dtype of activations):
-   single op / processor:   bf16 1.5e-2   fp16 4e-3
-   whole UNet forward:      bf16 6e-2     fp16 1.5e-2   (~60 layers of bf16 activations, fp32 accumulation)
-   5-step denoising loop:   bf16 6e-2     fp16 1.5e-2   on the final latents
+Stated tolerances, two metrics each (tests/parity_metrics.py): max|err| / max|ref| <= tol AND relative L2 <= tol / 2:
+   single op / processor:            bf16 1.5e-2   fp16 4e-3
+   full-size UNet forward:           bf16 2.4e-2   fp16 4e-3     (measured: rel-L2 7.5e-3..8.5e-3 / ~1e-3)
+   tiny-plan UNet, loops, VAE:       bf16 6e-2     fp16 1.5e-2   (8 channels per GroupNorm group: noisier; measured rel-L2 <= 2.2e-2)
 fp32 latent utilities: 1e-5 / bit-exact where only data movement is involved.
 """
 import os
@@ -28,7 +28,14 @@ def op_tol(dtype):
 
 
 def net_tol(dtype):
+    """tiny plans / VAE (few channels per GroupNorm group: larger relative noise): max 6e-2 / 1.5e-2, rel-L2 half of it"""
     return 6e-2 if dtype == torch.bfloat16 else 1.5e-2
+
+
+def full_tol(dtype):
+    """full-size UNets (measured round 2: bf16 rel-L2 7.5e-3..8.5e-3, max 7.8e-3..1.0e-2; fp16 rel-L2 9.4e-4..9.9e-4):
+    max <= 2.4e-2 / 4e-3, rel-L2 <= 1.2e-2 / 2e-3"""
+    return 2.4e-2 if dtype == torch.bfloat16 else 4e-3
 
 
 def close(got, ref, tol, what, l2=None):
@@ -214,7 +221,7 @@ def test_unet_sd15_full_vs_oracle(dtype):
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     ref = ou.unet_forward(cfg, sd_r, x.to(dtype).float(), 981, enc.to(dtype).float(), ip_scale=0.4, num_tokens=4)
     out = unet(x.to(DEV, dtype), 981, enc.to(DEV, dtype), out_dtype=torch.float32).sample
-    close(out, ref, net_tol(dtype), "sd15 unet")
+    close(out, ref, full_tol(dtype), "sd15 unet")
 
 
 @pytest.mark.parametrize("plan", ["sd21", "sdxl"])
@@ -243,7 +250,7 @@ def test_unet_other_baseline_plans_full_vs_oracle(plan):
     torch.cuda.empty_cache()
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     ref = ou.unet_forward(cfg, sd_r, x.to(dtype).float(), 621, enc.to(dtype).float(), ip_scale=0.4, num_tokens=T, added_cond_kwargs=addr)
-    close(out, ref, net_tol(dtype), f"{plan} unet full")
+    close(out, ref, full_tol(dtype), f"{plan} unet full")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

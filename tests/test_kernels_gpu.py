@@ -608,3 +608,62 @@ def test_latent_shift_and_compose_at_96x96():
     comp, fgidx = L.compose_latents(ad, None, new_l, new_m, S - 1, 1, 768, 768, latents_bg=bg.to(dev))
     rcomp, rfg = ol.compose_latents(rl, rm, bg, S)
     assert torch.equal(fgidx.cpu(), rfg) and torch.equal(comp.cpu(), rcomp)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(66000, 320, 320), (9000, 1000, 192), (4096, 1280, 1280), (300, 640, 64), (16384, 640, 2560)])
+def test_gemm_big_tiles(dtype, shape):
+    """The big-tile kernels (tg_gemm_bt.hip: force_tile 9 = 128 x 320, 10 = 256 x 256; 8 waves, persistent, one barrier per
+    K-tile, asm LDS-DMA / fragment reads with counted waits): ragged M and N, K of one tile up to 40 tiles, several output
+    tiles per workgroup (the cross-tile prefetch), bias + per-batch vector + residual in the chunked LDS epilogue.  They
+    accumulate in the same order as the 128 x 128 kernel, so the results must also be BIT-identical to it."""
+    from theatergen_amd import ops
+    dev = _dev()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    rows = 100 if M % 100 == 0 else M
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias, res, bvec = rnd((N,), dtype, g), rnd((M, N), dtype, g), rnd((M // rows, N), dtype, g)
+    ad, wd, bd, rd, vd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev), bvec.to(dev)
+    ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
+    base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
+    for tile in (9, 10):
+        out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
+        check(out, ref, dtype, f"big tile {tile} {shape}")
+        same = torch.equal(out, base)
+        assert same, f"big tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
+        again = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
+        same = torch.equal(out, again)
+        assert same
+    # activation epilogue + scale
+    out = ops.linear(ad, wd, bd, act=ops.ACT_SILU, out_scale=0.5, force_tile=9)
+    check(out, F.silu(ad.float() @ wd.float().t() + bd.float()).cpu() * 0.5, dtype, f"big tile silu {shape}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_big_tiles_qkv_split_and_geglu(dtype):
+    """Big tiles with the attention operand layout (Q | K token-major + V^T per batch item, n_split on a wave-tile boundary)
+    and the fused GEGLU epilogue (256 x 256 tile)."""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_geglu
+    dev = _dev()
+    g = torch.Generator().manual_seed(99)
+    B, rows, C = 3, 1024, 320
+    M, N, K = B * rows, 3 * C, C
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    ref = a.float() @ w.float().t()
+    for tile in (1, 9):
+        out = torch.zeros((M, 2 * C), dtype=dtype, device=dev)
+        out_t = torch.zeros((B, C, rows), dtype=dtype, device=dev)
+        ops.gemm(a.to(dev), w.to(dev), M, N, K, rows_per_batch=rows, out=out, n_split=2 * C, out_t=out_t, ldt=rows, force_tile=tile)
+        check(out, ref[:, :2 * C], dtype, f"qkv main tile {tile}")
+        check(out_t, ref[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, f"qkv V^T tile {tile}")
+    M2, N2, K2 = 4096, 2560, 320
+    a2, w2, b2 = rnd((M2, K2), dtype, g), rnd((N2, K2), dtype, g, 1 / math.sqrt(K2)), rnd((N2,), dtype, g)
+    y = a2.float() @ w2.float().t() + b2.float()
+    wp, bp = pack_geglu(w2, b2)
+    small = ops.gemm(a2.to(dev), wp.to(dev), M2, N2, K2, bias=bp.to(dev), geglu=True, force_tile=1)
+    big = ops.gemm(a2.to(dev), wp.to(dev), M2, N2, K2, bias=bp.to(dev), geglu=True, force_tile=10)
+    check(big, y[:, :N2 // 2] * F.gelu(y[:, N2 // 2:]), dtype, "geglu big tile")
+    same = torch.equal(small, big)
+    assert same

@@ -17,45 +17,9 @@
 // contiguous 128-B segment of a shifted input pixel (or zeros at the border).  Stride-2 (Downsample2D),
 // nearest-x2 upsampled input (Upsample2D) and a two-source channel concat (skip connection) are folded
 // into the gather.
-#include "tg_common.h"
+#include "tg_gemm_common.h"
 
 namespace {
-
-constexpr int BK = 64;
-
-struct GemmParams {
-  const void* a0;
-  const void* a1;
-  int c0, c1;
-  int in_h, in_w, out_h, out_w, stride, upsample;
-  int pad_lo;       // zero rows / columns in front of the image: 1 (symmetric pad 1) or 0 (VAE-encoder downsample: bottom / right only)
-  const void* w;
-  long M, N, K;
-  const void* bias;
-  const void* bvec;
-  long ldbvec;
-  long rows_per_batch;
-  const void* res;
-  long ldres;
-  int act;
-  int geglu;
-  float out_scale;
-  void* out;
-  long ldc;
-  long n_split;
-  void* out_t;
-  long ldt;
-  float* ws;
-  int full_tiles;   // tiles [0, full_tiles) are computed whole; each later tile is cut into tail_s K-ranges
-  int tail_s;
-  int tile_bm, tile_bn;
-  int kt_per_split;
-  int tiles_n;
-  long a_rpb, a_bs;
-  int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
-  int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
-                    // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
-};
 
 struct TileCfg { int bm, bn, bk; };
 const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}};
@@ -70,394 +34,6 @@ constexpr int kNumTiles = 6;  // id 4 = 128x128 with 3 stages (forced only);
 struct Plan { int tile; bool halo; int full, tail, s, kps; long tiles_m, tiles_n; };
 
 
-template <typename T>
-__device__ __forceinline__ void epilogue_store4(const GemmParams& p, long m, long n4, float v0, float v1, float v2, float v3) {
-  if (m >= p.M || n4 >= p.N) return;
-  typedef typename Vec<T>::v4 V4;
-  float v[4] = {v0, v1, v2, v3};
-  long b = 0;
-  if (p.bvec || (p.n_split > 0)) b = m / p.rows_per_batch;
-  if (p.bias) {
-    V4 t = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.bias) + n4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += to_f32<T>(t[j]);
-  }
-  if (p.bvec) {
-    V4 t = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.bvec) + b * p.ldbvec + n4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += to_f32<T>(t[j]);
-  }
-  if (p.res) {
-    V4 t = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.res) + m * p.ldres + n4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += to_f32<T>(t[j]);
-  }
-  if (p.act != TG_ACT_NONE) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
-  if (p.n_split > 0 && n4 >= p.n_split) {
-    T* o = reinterpret_cast<T*>(p.out_t);
-    long tok = m - b * p.rows_per_batch;
-    long nt = p.N - p.n_split;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[(b * nt + (n4 + j - p.n_split)) * p.ldt + tok] = from_f32<T>(v[j]);
-  } else {
-    V4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(v[j]);
-    *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + n4) = o;
-  }
-}
-
-// EXPERIMENT (TG_GEMM_FLAGS bit 0): the two blocks that share a CU start together and have identical work, so they sit in
-// their K loops together (each with half the matrix pipe) and in their epilogues together (matrix pipe idle).  Delay ONE of
-// the two first-round blocks of every CU by about half a tile period so that one block's epilogue overlaps the other's K
-// loop; later rounds inherit the offset (a finished block is replaced at once).  CU identity from the hardware id registers,
-// arrival parity from a never-reset global counter (consecutive arrivals on one CU differ in parity).  Speed only.
-__device__ unsigned int tg_cu_arrivals[2048];
-__device__ __forceinline__ void stagger_first_round(int flags, char* smem_base) {
-  if (!(flags & 1) || gridDim.x < 512 || blockIdx.x >= 512) return;
-  int* dec = reinterpret_cast<int*>(smem_base);
-  if (threadIdx.x == 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
-    const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
-    *dec = (int)(atomicAdd(&tg_cu_arrivals[key], 1u) & 1u);
-  }
-  __syncthreads();
-  const int late = *dec;
-  __syncthreads();
-  if (late) {
-    const int units = (flags >> 8) & 0xff;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);         // ~2048 cycles ~ 1 us each
-  }
-}
-
-// XCD-aware tile order (speed only, never correctness): the dispatcher places block b on XCD b % 8, each XCD has a
-// private 4 MiB L2.  With the natural order the tiles that share an activation row-slab (same tile_m, different
-// tile_n) land on different XCDs and every L2 fetches the slab again from the fabric (measured: 44 % L2 miss rate,
-// ~3.9 TB/s of miss traffic on the 64x64 320->320 conv).  Remap so that XCD x owns a CONTIGUOUS chunk of logical
-// tiles (bijective for any grid size): neighbours in (tile_m, tile_n) order run on the same L2 at the same time.
-__device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
-  const int q = nblocks >> 3, r = nblocks & 7;
-  const int xcd = bid & 7;
-  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + (bid >> 3);
-}
-
-// Whole-wave-tile epilogue.  All bias / per-batch vector / residual loads of one 32-token row block are issued
-// back to back BEFORE any of them is consumed (one latency exposure per row block instead of one per 4 outputs),
-// then activation / scale / 8-byte stores.  lane&31 = token row, 4 consecutive registers = 4 consecutive channels.
-// EPI: 0 = linear epilogue only (bias / per-batch vector / residual / scale: every conv and most projections),
-// 1 = generic (activations, GEGLU), 2 = GEGLU only.  The activation code (erf polynomials, exp) is ~80 % of the
-// kernel's instructions; leaving it out of the kernels that never run it is worth ~6 % at K = 320 (code size).
-template <typename T, int TM, int TN, int EPI>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int part,
-                                              long pm0, long pn0) {
-  typedef typename Vec<T>::v4 V4;
-  if (part >= 0) {
-    // K-split tail tile: fp32 partial in tile-local layout ws[part][tile_bm][tile_bn]; the reduce kernel sums the
-    // tail_s partials of the tile in a fixed order and applies the epilogue
-    float* wsp = p.ws + (long)part * p.tile_bm * p.tile_bn;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long lr = m_base + 32 * i - pm0;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const long lc = n_base + 32 * j + 8 * g - pn0;
-          f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(wsp + lr * p.tile_bn + lc) = o;
-        }
-    }
-    return;
-  }
-  if constexpr (TN == 2 && EPI != 0) {
-    if (EPI == 2 || p.geglu) {
-      // fused GEGLU (models/attention.py:337-338): W rows are packed [a(32) ; gate(32)] per 64-column group, so this
-      // wave holds a[c] in tile j = 0 and gate[c] in tile j = 1 for the same 32 channels, in the same lane/register:
-      // out[m, c] = (a + bias_a) * gelu(gate + bias_g), written to a [M, N/2] tensor — the [M, N] pre-activation
-      // never exists in HBM.
-      const T* biasp = reinterpret_cast<const T*>(p.bias);
-      const long hi4 = n_base & 31;                 // 4 * (lane >> 5)
-      const long nA = n_base - hi4;                 // first packed column of the a-block (multiple of 64)
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const long m = m_base + 32 * i;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const long na = nA + hi4 + 8 * g;         // packed column of a; gate sits 32 further
-          if (na + 32 >= p.N) continue;
-          V4 ba, bg;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
-          if (biasp != nullptr) {
-            ba = *reinterpret_cast<const V4*>(biasp + na);
-            bg = *reinterpret_cast<const V4*>(biasp + na + 32);
-          }
-          V4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = acc[i][0][4 * g + e] + to_f32<T>(ba[e]);
-            const float gt = acc[i][1][4 * g + e] + to_f32<T>(bg[e]);
-            o[e] = from_f32<T>(a * gelu_erf_f(gt) * p.out_scale);
-          }
-          *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + (nA >> 1) + hi4 + 8 * g) = o;
-        }
-      }
-      return;
-    }
-  }
-  const T* biasp = reinterpret_cast<const T*>(p.bias);
-  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
-  const T* resp = reinterpret_cast<const T*>(p.res);
-  V4 zero4;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) zero4[e] = from_f32<T>(0.f);
-  V4 bias4[TN][4];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const long n4 = n_base + 32 * j + 8 * g;
-      bias4[j][g] = (biasp != nullptr && n4 < p.N) ? *reinterpret_cast<const V4*>(biasp + n4) : zero4;
-    }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long m = m_base + 32 * i;
-    const bool m_ok = m < p.M;
-    long b = 0;
-    if (bvecp != nullptr || p.n_split > 0) b = (m_ok ? m : 0) / p.rows_per_batch;
-    V4 add4[TN][4], res4[TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long n4 = n_base + 32 * j + 8 * g;
-        const bool ok = m_ok && n4 < p.N;
-        add4[j][g] = (bvecp != nullptr && ok) ? *reinterpret_cast<const V4*>(bvecp + b * p.ldbvec + n4) : zero4;
-        res4[j][g] = (resp != nullptr && ok) ? *reinterpret_cast<const V4*>(resp + m * p.ldres + n4) : zero4;
-      }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long n4 = n_base + 32 * j + 8 * g;
-        if (!(m_ok && n4 < p.N)) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = acc[i][j][4 * g + e] + to_f32<T>(bias4[j][g][e]) + to_f32<T>(add4[j][g][e]) + to_f32<T>(res4[j][g][e]);
-        if constexpr (EPI == 1) {
-          if (p.act != TG_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        if (p.n_split > 0 && n4 >= p.n_split) {
-          T* o = reinterpret_cast<T*>(p.out_t);
-          const long tok = m - b * p.rows_per_batch;
-          const long nt = p.N - p.n_split;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[(b * nt + (n4 + e - p.n_split)) * p.ldt + tok] = from_f32<T>(v[e]);
-        } else {
-          V4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-          *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + m * p.ldc + n4) = o;
-        }
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// LDS-transposed epilogue.  In the MFMA accumulator layout a lane owns ONE token row and 4 consecutive channels per
-// register quad, so the direct epilogue above issues 8-byte stores to 32 different 128-byte lines per instruction
-// (and the same pattern for residual loads): 16 K line accesses per CU per tile round, ~8.7 us of fixed cost per
-// 128x128 tile (K sweep in profiles/r1_gemm_findings.md) — more than the K loop itself when K <= 640.  Here each wave
-// bounces its fp32 accumulators through a private LDS scratch (the operand stages are dead after the K loop's last
-// barrier) and comes back with lane = (row, 8-channel piece): bias / per-batch vector / residual are 16-byte loads,
-// the store is 16 bytes per lane, 8 full 128-byte lines per wave-instruction.  Arithmetic and its order are
-// unchanged (fp32: acc + bias + bvec + res, activation, scale, one rounding), so results are bit-identical to the
-// direct epilogue.  Columns that go to the transposed output (out_t, lane = token is already coalesced there) and
-// split-K partials keep the direct path.
-// Row loop of the LDS-transposed epilogue (see epilogue_tile_lds): straight-line per 32-row half — all residual /
-// per-batch-vector loads, then the 8 LDS writes, then ALL LDS reads of the half, then the arithmetic and the stores
-// (only the store is predicated on the row bound).  fp32: ((acc + bias) + bvec) + res, activation, * scale, one rounding;
-// x + 0 and x * 1 are exact, so this rounds the same value as the direct epilogue.
-template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES>
-__device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr) {
-  typedef typename Vec<T>::v8 V8;
-  constexpr int W = TN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int c = lane % P, r0 = lane / P;
-  const long n = n_wave + c * 8;
-  const bool n_ok = n < p.N;
-  T* outp = reinterpret_cast<T*>(p.out);
-  const T* biasp = reinterpret_cast<const T*>(p.bias);
-  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
-  const T* resp = reinterpret_cast<const T*>(p.res);
-  const long nc = n_ok ? n : 0;                      // clamped column: loads stay in bounds, the store is predicated
-  float bias_f[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
-  if (biasp != nullptr) {
-    const V8 b8 = *reinterpret_cast<const V8*>(biasp + nc);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
-  }
-  const float scale = p.out_scale;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long m_first = m_wave + 32 * i + r0;
-    V8 add8[NPASS], res8[NPASS];
-    if constexpr (HAS_ADD) {
-#pragma unroll
-      for (int it = 0; it < NPASS; ++it) {
-        long m = m_first + it * RPP;
-        if (m >= p.M) m = p.M - 1;
-        add8[it] = *reinterpret_cast<const V8*>(bvecp + (m / p.rows_per_batch) * p.ldbvec + nc);
-      }
-    }
-    if constexpr (HAS_RES) {
-#pragma unroll
-      for (int it = 0; it < NPASS; ++it) {
-        long m = m_first + it * RPP;
-        if (m >= p.M) m = p.M - 1;
-        res8[it] = *reinterpret_cast<const V8*>(resp + m * p.ldres + nc);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(scr + l31 * RS + 32 * j + 8 * g + 4 * hi) = o;
-      }
-    __builtin_amdgcn_wave_barrier();
-    f32x4 lo[NPASS], hi4[NPASS];
-#pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      lo[it] = *reinterpret_cast<const f32x4*>(scr + (it * RPP + r0) * RS + c * 8);
-      hi4[it] = *reinterpret_cast<const f32x4*>(scr + (it * RPP + r0) * RS + c * 8 + 4);
-    }
-    __builtin_amdgcn_wave_barrier();
-    T* op = outp + m_first * p.ldc + n;
-#pragma unroll
-    for (int it = 0; it < NPASS; ++it) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[it][e] + bias_f[e]; v[4 + e] = hi4[it][e] + bias_f[4 + e]; }
-      if constexpr (HAS_ADD) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(add8[it][e]);
-      }
-      if constexpr (HAS_RES) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(res8[it][e]);
-      }
-      if constexpr (EPI == 1) {
-        if (p.act != TG_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-        }
-      }
-      V8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e] * scale);
-      if (m_first + it * RPP < p.M && n_ok) *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
-    }
-  }
-}
-
-template <typename T, int TM, int TN, int EPI>
-__device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr, int part, long pm0, long pn0) {
-  typedef typename Vec<T>::v4 V4;
-  typedef typename Vec<T>::v8 V8;
-  const int l31 = lane & 31, hi = lane >> 5;
-  if (part >= 0 || !p.epi_lds || (p.n_split > 0 && n_wave >= p.n_split)) {
-    epilogue_tile<T, TM, TN, EPI>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0);
-    return;
-  }
-  T* outp = reinterpret_cast<T*>(p.out);
-  const T* biasp = reinterpret_cast<const T*>(p.bias);
-  if constexpr (TN == 2 && EPI != 0) {
-    if (EPI == 2 || p.geglu) {
-      constexpr int RS = 36;
-      const int c = lane & 3, r0 = lane >> 2;       // 4 pieces x 16 rows per pass over the [32][32] result
-      // the 2 x 4 bias quads of this lane's channels do not depend on the row block: loaded once (fp32), straight-line body
-      float baf[4][4], bgf[4][4];
-      bool gok[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long na = n_wave + 4 * hi + 8 * g;
-        gok[g] = na + 32 < p.N;
-        V4 ba, bg;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ba[e] = from_f32<T>(0.f); bg[e] = from_f32<T>(0.f); }
-        if (biasp != nullptr && gok[g]) {
-          ba = *reinterpret_cast<const V4*>(biasp + na);
-          bg = *reinterpret_cast<const V4*>(biasp + na + 32);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { baf[g][e] = to_f32<T>(ba[e]); bgf[g][e] = to_f32<T>(bg[e]); }
-      }
-      const float scale = p.out_scale;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = acc[i][0][4 * g + e] + baf[g][e];
-            const float gt = acc[i][1][4 * g + e] + bgf[g][e];
-            o[e] = gok[g] ? a * gelu_erf_f(gt) * scale : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(scr + l31 * RS + 8 * g + 4 * hi) = o;
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 lo[2], hi4[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          lo[it] = *reinterpret_cast<const f32x4*>(scr + (it * 16 + r0) * RS + c * 8);
-          hi4[it] = *reinterpret_cast<const f32x4*>(scr + (it * 16 + r0) * RS + c * 8 + 4);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const long m = m_wave + 32 * i + it * 16 + r0;
-          V8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = from_f32<T>(lo[it][e]); o[4 + e] = from_f32<T>(hi4[it][e]); }
-          if (m < p.M && n_wave + c * 8 + 32 < p.N) *reinterpret_cast<V8*>(outp + m * p.ldc + (n_wave >> 1) + c * 8) = o;
-        }
-      }
-      return;
-    }
-  }
-  const T* bvecp = reinterpret_cast<const T*>(p.bvec);
-  const T* resp = reinterpret_cast<const T*>(p.res);
-  // one straight-line instance of the row loop per (per-batch vector?, residual?) combination: with the wave-uniform
-  // branches inside the loop every pass was its own basic block and the compiler exposed one LDS / load latency per
-  // pass (in-kernel s_memtime: ~7200 cycles per 128x128 tile against ~1800 per K-tile)
-  if (bvecp != nullptr) {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true>(p, acc, m_wave, n_wave, lane, scr);
-    else epilogue_rows_lds<T, TM, TN, EPI, true, false>(p, acc, m_wave, n_wave, lane, scr);
-  } else {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true>(p, acc, m_wave, n_wave, lane, scr);
-    else epilogue_rows_lds<T, TM, TN, EPI, false, false>(p, acc, m_wave, n_wave, lane, scr);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // Operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
@@ -466,7 +42,6 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
 // with key = (row >> 1) & 7; the swizzle is applied on the per-lane SOURCE address and again on the fragment read
 // (cdna guide rule 21), which makes the 16-lane ds_read_b128 groups conflict-free.  Out-of-range rows / conv padding
 // read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
-__device__ __attribute__((aligned(256))) unsigned char tg_zero_page[256];
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_kernel(GemmParams p) {
@@ -1074,6 +649,42 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
   return launch_reduce<T>(p, pl, st);
 }
 
+}  // namespace
+// big-tile kernels (tg_gemm_bt.hip): bt_tile 0 = 256 x 320, 1 = 128 x 320, 2 = 256 x 256
+int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
+namespace {
+
+// Big tiles (tg_gemm_bt.hip): force_tile 9 = 128 x 320, 10 = 256 x 256; plain GEMM with one A source, K a multiple of 64,
+// no K split.  What the heuristic (force_tile 0) takes, and why so little (profiles/r2_gemm_findings.md, all on MI355X):
+//   * isolated launches (scripts/dev_bt_bench.py, rotating operands; us, 128x128 -> big tile): fused GEGLU 65536x2560x320
+//     230 -> 188, 16384x5120x640 193 -> 156; projections 16384x640x640 29.1 -> 25.6, 16384x640x2560 92 -> 80, 65536x320x320
+//     31 -> 29; big GEMMs 8192x4096x4096 723 -> 1016 TF.  In the eager UNet step (scripts/dev_insitu_gemm.py) the same launches
+//     save 0.36 ms of 15.1 ms.
+//   * in the hipGraph-replayed bench the picture turns: with the 128 x 320 projections ON the whole bench is 2.1 % SLOWER
+//     (7.516 vs 7.674 images/s, three interleaved rounds), with only the GEGLU launches on the 256 x 256 tile it is 0.3 %
+//     faster (7.698).  rocprofv3 + rocm-smi of the two runs: the projection launches take the same time as before (32.4 us
+//     average against 128x128's mix), but the shader clock settles at ~2150 MHz instead of ~2225 MHz (at LOWER package power,
+//     1170 vs 1240 W) and every other kernel of the step slows down with it (attention 288 -> 303 us, halo convs +2..4 %).
+//   So only the GEGLU tile is selected; 128 x 320 stays available as force_tile 9 (parity-tested, bit-identical results).
+inline int bt_tile_of(const tg_gemm_desc* d) {
+  const int ft = d->force_tile;
+  const bool can = d->mode == 0 && d->force_split_k <= 1 && d->a1 == nullptr && d->K % BK == 0;
+  if (ft >= 9 && ft <= 10) return can ? ft - 8 : -1;
+  if (ft != 0 || !can) return -1;
+  int devf = 0;
+  { const char* e = getenv("TG_GEMM_FLAGS"); devf = e ? (int)strtol(e, nullptr, 0) : 0; }   // dev A/B switches
+  if (devf & 8) return -1;
+  if (d->geglu) {
+    const long tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    return (d->M >= 16384 && tiles >= 1024) ? 2 : -1;
+  }
+  if ((devf & 64) && d->N % 320 == 0 && d->N <= 640 && (d->n_split <= 0 || d->n_split % 160 == 0)) {   // off by default (see above)
+    const long tiles = ((d->M + 127) / 128) * (d->N / 320);
+    if (tiles >= 256 && !(d->N == 320 && d->K >= 1280)) return 1;
+  }
+  return -1;
+}
+
 template <typename T>
 int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   Plan pl = make_plan(d);
@@ -1091,8 +702,8 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.tile_bm = kTiles[pl.tile].bm; p.tile_bn = kTiles[pl.tile].bn;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
   {
-    static const int env_flags = [] { const char* e = getenv("TG_GEMM_FLAGS"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
-    p.flags = env_flags;
+    const char* e = getenv("TG_GEMM_FLAGS");          // dev experiments; read per launch so one process can A/B
+    p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
   }
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1104,6 +715,11 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     const int64_t need = plan_workspace_bytes(pl);
     TG_CHECK(need == 0 || (d->workspace != nullptr && d->workspace_bytes >= need), TG_ERR_ARG,
              "tg_gemm: the K-split tail needs %lld workspace bytes, got %lld", (long long)need, (long long)d->workspace_bytes);
+  }
+  if (const int bt = bt_tile_of(d); bt >= 0) {
+    TG_CHECK(!d->geglu || bt == 2, TG_ERR_ARG, "tg_gemm: the GEGLU epilogue needs the 256 x 256 big tile (force_tile 10)");
+    TG_CHECK(d->n_split <= 0 || d->n_split % (bt == 2 ? 128 : 160) == 0, TG_ERR_ARG, "tg_gemm: big tiles need n_split on a wave-tile boundary");
+    return tg_gemm_bt_launch(d, &p, bt, st);
   }
   if (pl.halo) {
     if (d->upsample) {
@@ -1138,7 +754,7 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
              TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
     const int ft = d->force_tile & 15;
-    TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
+    TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6 || ft == 10, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
     TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
   }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
@@ -1174,6 +790,13 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
+  if (const int bt = bt_tile_of(d); bt >= 0) {
+    if (tile_m) *tile_m = bt == 1 ? 128 : 256;
+    if (tile_n) *tile_n = bt == 1 ? 320 : 256;
+    if (splits) *splits = 1;
+    if (kernel_kind) *kernel_kind = 3;
+    return TG_OK;
+  }
   Plan pl = make_plan(d);
   if (tile_m) *tile_m = kTiles[pl.tile].bm;
   if (tile_n) *tile_n = kTiles[pl.tile].bn;
@@ -1184,6 +807,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
+  if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
 }
 

@@ -120,7 +120,12 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     e0.record()
     _lib.check(L.tg_gemm(C.byref(d), _stream()))
     e1.record()
-    kname = "conv_halo_kernel<128x128>" if kk.value == 2 else f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
+    if kk.value == 2:
+        kname = "conv_halo_kernel<128x128>"
+    elif kk.value == 3:
+        kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
+    else:
+        kname = f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
     _gemm_profile.append(dict(kernel=kname, splits=sp.value,
                               M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1)))
     return out
