@@ -229,6 +229,29 @@ int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int
                      int32_t frozen_steps, float* history, void* model_in, int32_t model_in_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input-gradient kernels of `latent_backward_guidance` (models/pipelines.py:62-128: autograd.grad(loss, [latents]) through the
+ * UNet).  Weights are frozen, so only d loss / d input exists; the contractions of the backward pass are tg_gemm on transposed /
+ * tap-flipped weights, these are the remaining Jacobians (fp32 arithmetic, storage dtype in / out, deterministic):
+ * tg_groupnorm_bwd  : GroupNorm(+SiLU) wrt its token-major input x [batch*hw, C]       (ResnetBlock2D / Transformer2DModel norms)
+ * tg_layernorm_bwd  : LayerNorm wrt its input [rows, C]                                 (models/attention.py:186-236)
+ * tg_geglu_bwd      : h = [a | gate] [rows, 2*inner], dg [rows, inner] -> dh            (models/attention.py:337-338)
+ * tg_softmax_bwd_rows: dS = scale * P * (dP + extra - sum_j P_j (dP_j + extra_j)) per row; P fp32 (tg_attn_probs, probs_fp32 = 1) or
+ *                     in the storage dtype (tg_softmax_rows of a scores GEMM: self-attention with more than 256 keys), dP storage dtype,
+ *                     extra (may be NULL) fp32 = d loss / d P from tg_guidance_*; dS (and optionally P) written in the storage
+ *                     dtype with pitch ld_out >= length, pad columns zeroed            (ip_adapter/attention_processor.py:187-219)
+ * tg_sumpool2x2     : sum over the 2 x 2 block of an upsampled token-major map [batch, 2h, 2w, C] -> [batch, h, w, C] (Upsample2D)
+ */
+int tg_groupnorm_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int64_t hw, int32_t channels, int32_t groups, float eps,
+                     const void* gamma, const void* beta, int32_t silu, void* dx, void* stream);
+int tg_layernorm_bwd(int32_t dtype, const void* x, const void* dy, int64_t rows, int32_t channels, float eps, const void* gamma, void* dx,
+                     void* stream);
+int tg_geglu_bwd(int32_t dtype, const void* h, const void* dg, int64_t rows, int64_t inner, void* dh, void* stream);
+int tg_softmax_bwd_rows(int32_t dtype, const void* probs, int32_t probs_fp32, int64_t ld_probs, const void* dprobs, int64_t ld_dprobs,
+                        const float* extra, int64_t ld_extra, int64_t rows, int32_t length, float scale, void* dscores, void* probs_out,
+                        int64_t ld_out, void* stream);
+int tg_sumpool2x2(int32_t dtype, const void* du, int32_t batch, int32_t h, int32_t w, int32_t channels, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Latent utilities (utils/latents.py, utils/utils.py) on fp32 latents [.., h, w]:
  * tg_blend_latents : bg (1-M) + (bg sqrt(1-r) + fg sqrt(r)) M                      (latents.py:156-166)
  *                     storage_dtype -1: fp32 latents; TG_F16 / TG_BF16: the inputs hold half-precision values (the

@@ -1,0 +1,235 @@
+"""GPU: the input-gradient path of ``latent_backward_guidance`` (reference models/pipelines.py:62-128) against
+``torch.autograd`` on the CPU oracle: each Jacobian kernel of csrc/tg_backward.hip vs autograd of the plain fp32 op, the attention
+block's input gradient (self, and IP-Adapter cross-attention with the loss gradient entering at the text probabilities), and
+d loss / d latents through the tiny UNet plus one guided latent update.
+
+Tolerances (relative L2 / max-abs of the peak; half-precision storage of every activation AND every back-propagated gradient):
+single Jacobian bf16 8e-3 / 2.5e-2, fp16 1e-3 / 4e-3; attention block bf16 2e-2 / 5e-2, fp16 3e-3 / 1e-2; whole-UNet gradient with the
+smooth (ratio) loss bf16 5e-2 / 1e-1, fp16 8e-3 / 2e-2 (measured on MI355X: 2.3e-2 / 2.1e-2 and 3.0e-3 / 2.8e-3; cosine 0.99975 /
+0.999995); with the top-k loss the gradient is compared by direction (measured cosine 0.903 bf16, 0.9992 fp16: top-k membership
+flips between half-precision and fp32 maps change it discretely); latents after one guided update bf16 4e-3, fp16 8e-4 (1.3e-3 / 2.0e-4)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import parity_metrics as pm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def jt(dtype):
+    return (8e-3, 2.5e-2) if dtype == torch.bfloat16 else (1e-3, 4e-3)
+
+
+def rnd(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_norm_and_activation_jacobians(dtype):
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(1)
+    l2, mx = jt(dtype)
+    # GroupNorm (+SiLU): token-major [B*hw, C]; 10 channels per group (SD level 0), 40 per group, and a tiny map
+    for (B, hw, C, groups, silu) in ((2, 64, 320, 32, True), (1, 256, 64, 32, False), (2, 16, 1280, 32, True), (1, 4, 64, 32, True)):
+        x, dy = rnd((B * hw, C), dtype, g), rnd((B * hw, C), dtype, g)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype), (0.2 * torch.randn(C, generator=g)).to(dtype)
+        xr = x.float().reshape(B, hw, C).permute(0, 2, 1).clone().requires_grad_(True)
+        y = F.group_norm(xr, groups, gamma.float(), beta.float(), 1e-5)
+        if silu:
+            y = F.silu(y)
+        ref = torch.autograd.grad(y, xr, dy.float().reshape(B, hw, C).permute(0, 2, 1))[0].permute(0, 2, 1).reshape(B * hw, C)
+        got = ops.groupnorm_bwd(x.to(DEV), dy.to(DEV), B, hw, groups, 1e-5, gamma.to(DEV), beta.to(DEV), silu=silu)
+        pm.check(got, ref, f"groupnorm_bwd {(B, hw, C, groups, silu)} {dtype}", l2, mx)
+    for (rows, C) in ((300, 320), (64, 1280), (5, 64)):
+        x, dy = rnd((rows, C), dtype, g), rnd((rows, C), dtype, g)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype), (0.2 * torch.randn(C, generator=g)).to(dtype)
+        xr = x.float().clone().requires_grad_(True)
+        ref = torch.autograd.grad(F.layer_norm(xr, (C,), gamma.float(), beta.float(), 1e-5), xr, dy.float())[0]
+        pm.check(ops.layernorm_bwd(x.to(DEV), dy.to(DEV), gamma.to(DEV), 1e-5), ref, f"layernorm_bwd {(rows, C)} {dtype}", l2, mx)
+    h, dg = rnd((130, 2 * 256), dtype, g), rnd((130, 256), dtype, g)
+    hr = h.float().clone().requires_grad_(True)
+    a, gt = hr.chunk(2, dim=-1)
+    ref = torch.autograd.grad(a * F.gelu(gt), hr, dg.float())[0]
+    pm.check(ops.geglu_bwd(h.to(DEV), dg.to(DEV)), ref, f"geglu_bwd {dtype}", l2, mx)
+    # softmax backward with the loss-gradient term and padded output pitch
+    rows, L, ld = 70, 77, 80
+    s = torch.randn(rows, L, generator=g)
+    P = torch.softmax(s * 0.5, -1)
+    dP = torch.zeros(rows, ld)
+    dP[:, :L] = torch.randn(rows, L, generator=g)
+    dP = dP.to(dtype)
+    extra = torch.randn(rows, L, generator=g) * 0.3
+    sr = s.clone().requires_grad_(True)
+    ref = torch.autograd.grad(torch.softmax(sr * 0.5, -1), sr, dP[:, :L].float() + extra)[0]
+    dS, Pst = ops.softmax_bwd_rows(P.to(DEV), dP.to(DEV), L, 0.5, ld, extra=extra.to(DEV), want_probs=True)
+    pm.check(dS[:, :L], ref, f"softmax_bwd_rows {dtype}", l2, mx)
+    assert float(dS[:, L:].abs().max()) == 0.0 and float(Pst[:, L:].abs().max()) == 0.0
+    pm.check(Pst[:, :L], P, f"softmax_bwd_rows probs copy {dtype}", l2, mx)
+    dS2 = ops.softmax_bwd_rows(P.to(DEV, dtype), dP.to(DEV), L, 0.5, ld, extra=extra.to(DEV))          # probabilities in the storage dtype
+    pm.check(dS2[:, :L], ref, f"softmax_bwd_rows storage-dtype probs {dtype}", 2 * l2, 2 * mx)
+    du = rnd((2 * 8 * 6, 64), dtype, g)
+    ref = F.avg_pool2d(du.float().reshape(2, 8, 6, 64).permute(0, 3, 1, 2), 2) * 4
+    pm.check(ops.sumpool2x2(du.to(DEV), 2, 4, 3).reshape(2, 4, 3, 64).permute(0, 3, 1, 2), ref, f"sumpool2x2 {dtype}", l2, mx)
+
+
+def _build(cfg, dtype, seed=0):
+    from theatergen_amd import weights as W
+    from theatergen_amd.unet import UNet2DConditionModel
+    sd = W.random_unet_state_dict(cfg, seed=seed)
+    sd_r = {k: v.to(dtype).float() for k, v in sd.items()}
+    return UNet2DConditionModel.from_state_dict(cfg, sd, device=DEV, dtype=dtype, num_tokens=4, ip_scale=0.4), sd_r
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_block_input_gradient(dtype):
+    """d/dh of to_out(attention(h)) for a self-attention layer and for the IP-Adapter cross-attention layer with a loss gradient on
+    the text probabilities, vs autograd of the pinned oracle processors."""
+    from oracle import attention as oa
+    from tests.golden import gen_common as gc
+    from theatergen_amd.attention_processor import Attention, AttnProcessor, IPAttnProcessor
+    from theatergen_amd.backward import attention_input_grad
+    g = torch.Generator().manual_seed(3)
+    C, heads, ctx, N, T, B = 128, 4, 64, 48, 4, 2
+    l2, mx = (2e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 1e-2)
+    w = gc.attn_weights(C, ctx, seed=11)
+    ws = gc.attn_weights(C, C, seed=12, with_ip=False)
+    wr = {k: v.to(dtype).float() for k, v in w.items()}
+    wsr = {k: v.to(dtype).float() for k, v in ws.items()}
+    h = rnd((B, N, C), dtype, g)
+    enc = rnd((B, 77 + T, ctx), dtype, g, 0.5)
+    dout = rnd((B * N, C), dtype, g)
+    # self
+    sattn = Attention(query_dim=C, heads=heads, dim_head=C // heads)
+    sattn.load_state_dict(ws)
+    sattn = sattn.to(DEV, dtype)
+    hr = h.float().clone().requires_grad_(True)
+    ref = torch.autograd.grad(oa.attn_processor(wsr, heads, hr), hr, dout.float().reshape(B, N, C))[0].reshape(B * N, C)
+    got = attention_input_grad(sattn, AttnProcessor(), h.to(DEV).reshape(B * N, C), B, N, None, dout.to(DEV), None)
+    pm.check(got, ref, f"self-attention input grad {dtype}", l2, mx)
+    # IP cross-attention + d loss / d P_text
+    attn = Attention(query_dim=C, cross_attention_dim=ctx, heads=heads, dim_head=C // heads)
+    attn.load_state_dict({k: v for k, v in w.items() if "_ip" not in k})
+    attn = attn.to(DEV, dtype)
+    proc = IPAttnProcessor(hidden_size=C, cross_attention_dim=ctx, scale=0.4, num_tokens=T)
+    proc.load_state_dict({"to_k_ip.weight": w["to_k_ip.weight"], "to_v_ip.weight": w["to_v_ip.weight"]})
+    proc = proc.to(DEV, dtype)
+    extra = torch.randn(B, heads, N, 77, generator=g) * 0.2
+    hr = h.float().clone().requires_grad_(True)
+    out, probs = oa.ip_attn_processor(wr, heads, hr, enc.float(), 0.4, T, return_probs=True)
+    ref = torch.autograd.grad([out, probs], hr, [dout.float().reshape(B, N, C), extra])[0].reshape(B * N, C)
+    got = attention_input_grad(attn, proc, h.to(DEV).reshape(B * N, C), B, N, enc.to(DEV), dout.to(DEV), extra.to(DEV))
+    pm.check(got, ref, f"ip cross-attention input grad {dtype}", l2, mx)
+    # loss gradient only (the last guidance key: nothing downstream)
+    ref2 = torch.autograd.grad(oa.ip_attn_processor(wr, heads, hr, enc.float(), 0.4, T, return_probs=True)[1], hr, extra)[0].reshape(B * N, C)
+    got2 = attention_input_grad(attn, proc, h.to(DEV).reshape(B * N, C), B, N, enc.to(DEV), None, extra.to(DEV))
+    pm.check(got2, ref2, f"ip cross-attention input grad, loss term only {dtype}", l2, mx)
+
+
+GUIDE_TOPK = dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+GUIDE_RATIO = dict(use_ratio_based_loss=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unet_latent_gradient_and_guided_update(dtype):
+    """d (loss_scale * compute_ca_lossv3) / d latents through the tiny SD plan (down path, mid block, up block 1: every layer kind
+    incl. strided downsample, skip concat, nearest upsample) vs torch.autograd on the oracle, then one iteration of
+    latent_backward_guidance (latents -= sqrt(1 - alpha_bar_t) * grad, models/pipelines.py:108-115).
+    The ratio form of the loss (guidance.py:122-128) is smooth and tests the reverse pass itself; the top-k form (:130-144) selects
+    map elements, and a selection that flips between the half-precision maps and the oracle's fp32 maps changes the gradient
+    discretely — it is compared by direction (cosine), and exactly where the selections agree (fp16)."""
+    from oracle import ddim as oddim
+    from oracle import guidance_loss as og
+    from oracle import unet as ou
+    from tests.golden import gen_common as gc
+    from theatergen_amd import config
+    from theatergen_amd import guidance as G
+    from theatergen_amd.backward import UNetInputGrad, latent_backward_guidance
+    from theatergen_amd.scheduler import DDIMScheduler
+    cfg = config.tiny()
+    unet, sd_r = _build(cfg, dtype)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 4, 32, 32, generator=g)
+    enc = torch.randn(1, 81, cfg.cross_attention_dim, generator=g) * 0.5
+    keys = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+    boxes, pos = gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2]
+    t, loss_scale = 741, 30.0
+    grads_ref = {}
+    for name, kw in (("ratio", GUIDE_RATIO), ("topk", GUIDE_TOPK)):
+        x = lat.to(dtype).float().clone().requires_grad_(True)
+        saved = {}
+        ou.unet_forward(cfg, sd_r, x, t, enc.to(dtype).float(), ip_scale=0.4, cross_attention_kwargs={"save_attn_to_dict": saved, "save_keys": keys})
+        loss_ref = og.compute_ca_lossv3(saved, boxes, pos, keys, **kw) * loss_scale
+        grad_ref = torch.autograd.grad(loss_ref, x)[0]
+        grads_ref[name] = (loss_ref, grad_ref)
+
+        def loss_fn(sv, kw=kw):
+            return G.compute_ca_lossv3(sv, boxes, pos, keys, return_grads=True, loss_scale=loss_scale, **kw)
+        loss, grad = UNetInputGrad(unet).loss_and_grad(lat.to(DEV, dtype), t, enc.to(DEV, dtype), loss_fn, keys)
+        assert grad.shape == lat.shape and grad.dtype == torch.float32
+        assert abs(loss.item() - loss_ref.item()) <= 2e-2 * abs(loss_ref.item()), (name, loss.item(), loss_ref.item())
+        m = pm.metrics(grad, grad_ref)
+        cos = float(F.cosine_similarity(grad.cpu().flatten().double(), grad_ref.flatten().double(), dim=0))
+        pm.record(f"d loss / d latents, tiny UNet, {name} loss {dtype}", m, cosine=cos)
+        if name == "ratio":
+            l2, mx = (5e-2, 1e-1) if dtype == torch.bfloat16 else (8e-3, 2e-2)
+            assert m["finite"] and m["rel_l2"] <= l2 and m["max_rel"] <= mx, (name, m)
+        else:
+            assert m["finite"] and cos >= (0.85 if dtype == torch.bfloat16 else 0.99), (name, m, cos)
+        # determinism of the whole reverse pass
+        loss2, grad2 = UNetInputGrad(unet).loss_and_grad(lat.to(DEV, dtype), t, enc.to(DEV, dtype), loss_fn, keys)
+        assert torch.equal(grad, grad2) and loss.item() == loss2.item()
+    # one guided update through the reference-shaped entry point (smooth loss)
+    loss_ref, grad_ref = grads_ref["ratio"]
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    new_lat, new_loss = latent_backward_guidance(None, sch, unet, enc.to(DEV, dtype), 0, boxes, pos, t, lat.to(DEV, dtype), 1e6,
+                                                 loss_scale=loss_scale, loss_threshold=0.0, max_iter=1, guidance_attn_keys=keys, **GUIDE_RATIO)
+    osch = oddim.DDIMSchedule()
+    step = float((1 - osch.alphas_cumprod[t]) ** 0.5)
+    want = lat.to(dtype).float() - step * grad_ref
+    pm.check(new_lat, want, f"latents after one guidance iteration {dtype}", 4e-3 if dtype == torch.bfloat16 else 8e-4,
+             2e-2 if dtype == torch.bfloat16 else 4e-3)
+    assert abs(float(new_loss) - loss_ref.item()) <= 2e-2 * abs(loss_ref.item())
+    # index >= max_index_step: untouched (reference :66)
+    same, _ = latent_backward_guidance(None, sch, unet, enc.to(DEV, dtype), 10, boxes, pos, t, lat.to(DEV, dtype), 1e6, guidance_attn_keys=keys)
+    assert torch.equal(same.cpu(), lat.to(dtype))
+
+
+def test_latent_gradient_sd15_full_size_vs_oracle_autograd():
+    """The same reverse pass at BASELINE size: full SD-1.5 plan, 512 x 512 (latent 64 x 64: self-attention rows of 4096 keys go through
+    the scores-GEMM / row-softmax path), batch 1, bf16, smooth loss, against torch.autograd on the fp32 oracle."""
+    import os
+    from oracle import guidance_loss as og
+    from oracle import unet as ou
+    from tests.golden import gen_common as gc
+    from theatergen_amd import config
+    from theatergen_amd import guidance as G
+    from theatergen_amd.backward import UNetInputGrad
+    dtype = torch.bfloat16
+    cfg = config.sd15()
+    unet, sd_r = _build(cfg, dtype)
+    g = torch.Generator().manual_seed(19)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    enc = torch.randn(1, 81, 768, generator=g) * 0.5
+    keys = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+    boxes, pos = gc.GUIDANCE_BOXES[2], gc.GUIDANCE_POSITIONS[2]
+
+    def loss_fn(sv):
+        return G.compute_ca_lossv3(sv, boxes, pos, keys, return_grads=True, loss_scale=30.0, **GUIDE_RATIO)
+    loss, grad = UNetInputGrad(unet).loss_and_grad(lat.to(DEV, dtype), 741, enc.to(DEV, dtype), loss_fn, keys)
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    x = lat.to(dtype).float().clone().requires_grad_(True)
+    saved = {}
+    ou.unet_forward(cfg, sd_r, x, 741, enc.to(dtype).float(), ip_scale=0.4, cross_attention_kwargs={"save_attn_to_dict": saved, "save_keys": keys})
+    loss_ref = og.compute_ca_lossv3(saved, boxes, pos, keys, **GUIDE_RATIO) * 30.0
+    grad_ref = torch.autograd.grad(loss_ref, x)[0]
+    assert abs(loss.item() - loss_ref.item()) <= 2e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    m = pm.metrics(grad, grad_ref)
+    cos = float(F.cosine_similarity(grad.cpu().flatten().double(), grad_ref.flatten().double(), dim=0))
+    pm.record("d loss / d latents, full SD-1.5 512^2, ratio loss bf16", m, cosine=cos)
+    assert m["finite"] and cos >= 0.99 and m["rel_l2"] <= 1e-1, (m, cos)

@@ -80,6 +80,11 @@ SIGNATURES = {
     "tg_guidance_ratio": (i32, [vp, i32, i32, i32, i32, vp, f32, vp, vp, vp]),
     "tg_guidance_ref": (i32, [vp, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
     "tg_guidance_batch": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "tg_groupnorm_bwd": (i32, [i32, vp, vp, i32, i64, i32, i32, f32, vp, vp, i32, vp, vp]),
+    "tg_layernorm_bwd": (i32, [i32, vp, vp, i64, i32, f32, vp, vp, vp]),
+    "tg_geglu_bwd": (i32, [i32, vp, vp, i64, i64, vp, vp]),
+    "tg_softmax_bwd_rows": (i32, [i32, vp, i32, i64, vp, i64, vp, i64, i64, i32, f32, vp, vp, i64, vp]),
+    "tg_sumpool2x2": (i32, [i32, vp, i32, i32, i32, i32, vp, vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

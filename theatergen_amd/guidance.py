@@ -105,9 +105,10 @@ def add_ref_ca_loss_per_attn_map_to_lossv2(loss, saved_attn, object_number, bbox
 
 def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, ref_ca_saved_attns=None,
                       ref_ca_last_token_only=True, ref_ca_word_token_only=False, word_token_indices=None, index=None,
-                      ref_ca_loss_weight=1.0, verbose=False, return_grads=False, **kwargs):
+                      ref_ca_loss_weight=1.0, verbose=False, return_grads=False, loss_scale=1.0, **kwargs):
     """reference guidance.py:244-286, including the reference-attention transfer term (:150-242, :278-284) when
-    ``ref_ca_saved_attns`` is given."""
+    ``ref_ca_saved_attns`` is given.  ``loss_scale`` (extension): every term — value and gradient — is multiplied by it on the
+    device (``latent_backward_guidance`` differentiates ``loss * loss_scale``, models/pipelines.py:94)."""
     object_number = len(bboxes)
     dev = None
     for k in guidance_attn_keys:
@@ -117,7 +118,7 @@ def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, 
     grads = {}
     if object_number == 0 or len(guidance_attn_keys) == 0:
         return (loss[0], grads) if return_grads else loss[0]
-    norm = 1.0 / (object_number * len(guidance_attn_keys))
+    norm = float(loss_scale) / (object_number * len(guidance_attn_keys))
     batch = ops.GuidanceBatch(loss.device)          # every term of this call: one launch + an in-order fold
     for key in guidance_attn_keys:
         amap = saved_attn[key]

@@ -376,6 +376,53 @@ def guidance_ratio(attn, token, mask, scale, out, grad=None):
                                             _ptr(grad), _stream()))
 
 
+# ---- input-gradient kernels (latent_backward_guidance) ------------------------------------------------------------------
+def groupnorm_bwd(x, dy, batch, hw, groups, eps, gamma, beta, silu=False):
+    _need_cuda(x)
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().tg_groupnorm_bwd(_dt(x), _ptr(x), _ptr(dy), int(batch), int(hw), x.shape[-1], int(groups), float(eps), _ptr(gamma),
+                                           _ptr(beta), 1 if silu else 0, _ptr(dx), _stream()))
+    return dx
+
+
+def layernorm_bwd(x, dy, gamma, eps=1e-5):
+    _need_cuda(x)
+    rows, Cc = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().tg_layernorm_bwd(_dt(x), _ptr(x), _ptr(dy), rows, Cc, float(eps), _ptr(gamma), _ptr(dx), _stream()))
+    return dx
+
+
+def geglu_bwd(h, dg):
+    rows, two_inner = h.shape
+    dh = torch.empty_like(h)
+    _lib.check(_lib.lib().tg_geglu_bwd(_dt(h), _ptr(h), _ptr(dg), rows, two_inner // 2, _ptr(dh), _stream()))
+    return dh
+
+
+def softmax_bwd_rows(probs, dprobs, length, scale, ld_out, extra=None, want_probs=False):
+    """probs fp32 or storage dtype [rows, >= length] (row pitch probs.stride(0)), dprobs storage dtype [rows, >= length];
+    -> dS [rows, ld_out] (and P in the storage dtype, same shape, when ``want_probs``)"""
+    rows = probs.shape[0]
+    if probs.dtype != torch.float32 and probs.dtype != dprobs.dtype:
+        raise RuntimeError("softmax_bwd_rows: probs must be fp32 or the storage dtype")
+    ds = torch.empty((rows, ld_out), dtype=dprobs.dtype, device=dprobs.device)
+    pout = torch.empty_like(ds) if want_probs else None
+    _lib.check(_lib.lib().tg_softmax_bwd_rows(_dt(dprobs), _ptr(probs), 1 if probs.dtype == torch.float32 else 0, probs.stride(0),
+                                              _ptr(dprobs), dprobs.stride(0), _ptr(extra),
+                                              extra.stride(0) if extra is not None else 0, rows, int(length), float(scale), _ptr(ds),
+                                              _ptr(pout), int(ld_out), _stream()))
+    return (ds, pout) if want_probs else ds
+
+
+def sumpool2x2(du, batch, h, w):
+    """du token-major [batch * 2h * 2w, C] -> [batch * h * w, C]"""
+    Cc = du.shape[-1]
+    out = torch.empty((batch * h * w, Cc), dtype=du.dtype, device=du.device)
+    _lib.check(_lib.lib().tg_sumpool2x2(_dt(du), _ptr(du), int(batch), int(h), int(w), Cc, _ptr(out), _stream()))
+    return out
+
+
 class GuidanceBatch:
     """Collects the terms of one ``compute_ca_lossv3`` call (one per attention map x object x token position) and evaluates
     them with ONE ``tg_guidance_batch`` launch + an in-order fold instead of one dependent launch each.  Terms whose

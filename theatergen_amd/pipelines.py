@@ -17,6 +17,9 @@ from .scheduler import DDIMScheduler
 from .unet import DeviceSchedule
 
 
+DEFAULT_GUIDANCE_ATTN_KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]     # reference pipelines.py:21
+
+
 class SDPipe:
     """Minimal pipeline object: what ``IPAdapter`` and the latent utilities read from ``adapter.pipe``
     (``.unet``, ``.scheduler``, ``.controlnet``; reference ``ip_adapter.py:74``, ``utils/latents.py:261``)."""
@@ -253,3 +256,9 @@ def denoise_single_object(adapter, prompt_embeds, negative_prompt_embeds, input_
     engine.set_conditioning(enc)
     latents_all = engine.run(input_latents)
     return latents_all[-1], latents_all
+
+
+def latent_backward_guidance(*args, **kwargs):
+    """reference ``models/pipelines.py:62-128`` (same signature); implemented in ``theatergen_amd.backward``"""
+    from .backward import latent_backward_guidance as impl
+    return impl(*args, **kwargs)
