@@ -232,4 +232,5 @@ def test_latent_gradient_sd15_full_size_vs_oracle_autograd():
     m = pm.metrics(grad, grad_ref)
     cos = float(F.cosine_similarity(grad.cpu().flatten().double(), grad_ref.flatten().double(), dim=0))
     pm.record("d loss / d latents, full SD-1.5 512^2, ratio loss bf16", m, cosine=cos)
-    assert m["finite"] and cos >= 0.99 and m["rel_l2"] <= 1e-1, (m, cos)
+    # measured on MI355X: rel-L2 2.0e-2, max 2.0e-2 of the peak, cosine 0.9998
+    assert m["finite"] and cos >= 0.995 and m["rel_l2"] <= 5e-2 and m["max_rel"] <= 1e-1, (m, cos)
