@@ -27,6 +27,12 @@ __device__ __attribute__((aligned(256))) unsigned char attn_zero_page[256];
 #define TG_R8(x) x, x, x, x, x, x, x, x
 __device__ __attribute__((aligned(256))) const unsigned short attn_ones_bf16[64] = {TG_R8(TG_R8(0x3F80))};
 __device__ __attribute__((aligned(256))) const unsigned short attn_ones_f16[64] = {TG_R8(TG_R8(0x3C00))};
+// FOLD variants: K's first padding column (d = head dim) is fed 1.0 so that the QK^T MFMA adds the query's running-max bias
+__device__ __attribute__((aligned(256))) const unsigned short attn_one0_bf16[8] = {0x3F80, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(256))) const unsigned short attn_one0_f16[8] = {0x3C00, 0, 0, 0, 0, 0, 0, 0};
+template <typename T> __device__ __forceinline__ const T* one0_page();
+template <> __device__ __forceinline__ const bf16_t* one0_page<bf16_t>() { return reinterpret_cast<const bf16_t*>(attn_one0_bf16); }
+template <> __device__ __forceinline__ const f16_t* one0_page<f16_t>() { return reinterpret_cast<const f16_t*>(attn_one0_f16); }
 template <typename T> __device__ __forceinline__ const T* ones_page();
 template <> __device__ __forceinline__ const bf16_t* ones_page<bf16_t>() { return reinterpret_cast<const bf16_t*>(attn_ones_bf16); }
 template <> __device__ __forceinline__ const f16_t* ones_page<f16_t>() { return reinterpret_cast<const f16_t*>(attn_ones_f16); }
@@ -54,7 +60,13 @@ struct AttnParams {
 // accumulates the softmax denominator l = sum_k p[k] in accumulator row DV-1 (rescaled with O for free) and the 32
 // per-tile v_add_f32 of the row sum disappear — the loop is VALU-bound (32 v_exp_f32 at quarter rate + ~100 other
 // VALU ops against 14 MFMAs per wave-tile at head dim 40), so every removed VALU instruction counts.
-template <typename T, int DPAD, int DV, bool ONES>
+// FOLD (head dim = DPAD - 8, i.e. 40 -> 48: the SD-1.5 level-0 layers that dominate attention time): the loop is VALU-bound and a
+// quarter of its VALU instructions were the `fma(s, scale, -max)` in front of every exp2.  Q is pre-multiplied by scale * log2(e)
+// once per block, and the spare K column of the padded QK^T contraction carries 1.0 while the query's spare element carries
+// -(running reference) — so the MFMA itself delivers exp2's argument and the 32 fmas per tile disappear.  The reference is a
+// storage-dtype value (softmax is invariant to it); it moves lazily as before, and a move shifts the current tile's scores by the
+// exact difference of the two representable values.
+template <typename T, int DPAD, int DV, bool ONES, bool FOLD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 3 : (DV <= 96 ? 2 : 1)))) void attention_kernel(AttnParams p) {
   typedef typename Vec<T>::v8 V8;
   typedef typename Vec<T>::v4 V4;
@@ -95,9 +107,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(0.f);
       if (q_ok && d < HD) v = *reinterpret_cast<const V8*>(qp + d);
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(to_f32<T>(v[j]) * p.scale_log2);
+      }
       qf[ks] = v;
     }
   }
+  float qbias = 0.f;                       // FOLD: value of the query's spare element qf[NKS - 1][0] (lanes hi = 1) = -reference, log2 units
 
   f32x16 o[DT];
 #pragma unroll
@@ -123,7 +140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
       const int r = prow & 63, panel = prow >> 6;
       const int d0 = panel * 64 + ((slot ^ ((r >> 1) & 7)) << 3);
       const bool ok = d0 < HD && kv0 + r < len;
-      dma(ok ? kb + (long)(kv0 + r) * k_ld + d0 : zero, sK + q * 512);
+      const T* src = ok ? kb + (long)(kv0 + r) * k_ld + d0 : zero;
+      if (FOLD && d0 == HD) src = one0_page<T>();
+      dma(src, sK + q * 512);
     }
 #pragma unroll
     for (int j = 0; j < VJ; ++j) {
@@ -251,26 +270,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     // rows a new maximum keeps turning up somewhere.
     constexpr float LAZY_LOG2 = 8.f;
     const float tm = tile_max(s);
-    if (__any(tm * p.scale_log2 > m_run * p.scale_log2 + LAZY_LOG2)) {
-      const float m_new = fmaxf(m_run, tm);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-#pragma unroll
-      for (int t2 = 0; t2 < DT; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
-      if (!ONES) l_run *= alpha;
-      m_run = m_new;
-    }
-    const float mc = m_run * p.scale_log2;
     float ps = 0.f;
+    if constexpr (FOLD) {
+      // s already holds exp2's argument relative to the current reference (-qbias)
+      if (t == 0 || __any(tm > LAZY_LOG2)) {
+        const float sh = t == 0 ? tm : fmaxf(tm, 0.f);
+        const float nb = to_f32<T>(from_f32<T>(qbias - sh));            // the new bias must be a storage-dtype value
+        const float delta = nb - qbias;                                 // exact: both are representable
+        const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(delta);   // first tile: O and l are still zero
 #pragma unroll
-    for (int kvt = 0; kvt < 2; ++kvt)
+        for (int t2 = 0; t2 < DT; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc));
-        s[kvt][r] = e;
-        if (!ONES) ps += e;
+          for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+        if (!ONES) l_run *= alpha;
+#pragma unroll
+        for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kvt][r] += delta;
+        qbias = nb;
+        if (hi) qf[NKS - 1][0] = from_f32<T>(nb);
       }
+#pragma unroll
+      for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kvt][r]);
+          s[kvt][r] = e;
+          if (!ONES) ps += e;
+        }
+    } else {
+      if (__any(tm * p.scale_log2 > m_run * p.scale_log2 + LAZY_LOG2)) {
+        const float m_new = fmaxf(m_run, tm);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+        if (!ONES) l_run *= alpha;
+        m_run = m_new;
+      }
+      const float mc = m_run * p.scale_log2;
+#pragma unroll
+      for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc));
+          s[kvt][r] = e;
+          if (!ONES) ps += e;
+        }
+    }
     if (!ONES) l_run += ps;
     pv(s, sK + K_ELEMS);
   }
@@ -301,14 +349,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     }
     const T* sK = sbase + st * STAGE;
     f32x16 s[2];
+    if constexpr (FOLD) {
+      if (hi) qf[NKS - 1][0] = from_f32<T>(0.f);            // segment 1 has its own softmax: no carried reference
+    }
     scores(s, sK, p.len1, 0, false);
-    const float mc1 = tile_max(s) * p.scale_log2;
+    const float sc1 = FOLD ? 1.0f : p.scale_log2;           // FOLD: the scores are already in log2 units
+    const float mc1 = tile_max(s) * sc1;
     float ps = 0.f;
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc1));
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], sc1, -mc1));
         s[kvt][r] = e;
         ps += e;
       }
@@ -339,14 +391,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   }
 }
 
-template <typename T, int DPAD, int DV, bool ONES>
+template <typename T, int DPAD, int DV, bool ONES, bool FOLD = false>
 int launch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
   constexpr int NP = (DPAD + 63) / 64;
   const size_t lds = (size_t)2 * (NP * 64 * 64 + DV * 64) * sizeof(T);
   AttnParams pp = p;
   pp.n_qblk = (d->n_q + 127) / 128;
   dim3 grid((unsigned)(pp.n_qblk * d->heads * d->batch));
-  auto k = attention_kernel<T, DPAD, DV, ONES>;
+  auto k = attention_kernel<T, DPAD, DV, ONES, FOLD>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, pp);
@@ -360,6 +412,7 @@ int dispatch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
   const int hd = d->head_dim;
   if (hd <= 16) return launch_attn<T, 16, 32, true>(d, p, st);
   if (hd <= 32) return launch_attn<T, 32, 32, false>(d, p, st);
+  if (hd == 40 && !getenv("TG_ATTN_NOFOLD")) return launch_attn<T, 48, 64, true, true>(d, p, st);    // bias folded into QK^T (dev switch for A/B)
   if (hd <= 48) return launch_attn<T, 48, 64, true>(d, p, st);
   if (hd <= 64) return launch_attn<T, 64, 64, false>(d, p, st);
   if (hd <= 80) return launch_attn<T, 80, 96, true>(d, p, st);
