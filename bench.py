@@ -323,6 +323,24 @@ def bench_sd21_editing(args):
         for _ in range(5):
             one_step(True)
     assert torch.isfinite(res["np"]).all() and torch.isfinite(res["loss"])
+    # one iteration of latent_backward_guidance (models/pipelines.py:62-128): forward to the last guidance key + the explicit input-gradient pass
+    from theatergen_amd.backward import UNetInputGrad
+    eng_g = UNetInputGrad(unet)
+
+    def loss_fn(sv):
+        return G.compute_ca_lossv3(sv, boxes, positions, keys, return_grads=True, loss_scale=30.0, use_ratio_based_loss=False, fg_top_p=0.2,
+                                   bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    lat1 = composed[0].to(dtype)
+    enc1 = enc[1:2].contiguous()
+    with torch.no_grad():
+        gl, gg = eng_g.loss_and_grad(lat1, 741, enc1, loss_fn, keys)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            gl, gg = eng_g.loss_and_grad(lat1, 741, enc1, loss_fn, keys)
+        torch.cuda.synchronize()
+        guide_ms = (time.perf_counter() - t1) / 3 * 1e3
+    assert torch.isfinite(gg).all() and float(gg.abs().max()) > 0
     ms_step = elapsed / n_timed * 1e3
     unet_ms = parts["unet"] / 5
     ach = PLAN_FLOP_PER_CFG_CALL["sd21"] / (unet_ms * 1e-3) / 1e12
@@ -337,6 +355,10 @@ def bench_sd21_editing(args):
                    "plan": "sd21", "ddim_steps": steps, "boxes": 4},
         "images_per_s": round(1.0 / (ms_step * 1e-3 * steps), 4),
         "per_step_ms": {k: round(v / 5, 3) for k, v in parts.items()}, "compose_align_ms_once": round(compose_ms, 2),
+        "latent_backward_guidance_iteration_ms": round(guide_ms, 1),
+        "latent_backward_guidance_note": "one iteration = cond-only UNet forward to the last guidance key + compute_ca_lossv3 + d loss / d latents "
+                                         "(explicit reverse pass, materialised attention probabilities per head: 9216-key self-attention rows at level 0); "
+                                         "host wall time, eager; the reference runs up to 5 per step for the first 10 steps (dead code in its shipped flow)",
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": None, "kernel": "whole CFG-batch-2 UNet call incl. attention capture (4.30 TFLOP algorithmic, SURVEY 8(d))",
                      "avg_launch_us": round(unet_ms * 1e3, 1)},

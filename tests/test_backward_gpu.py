@@ -134,8 +134,9 @@ GUIDE_TOPK = dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_wei
 GUIDE_RATIO = dict(use_ratio_based_loss=True)
 
 
+@pytest.mark.parametrize("variant", ["conv", "linear"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_unet_latent_gradient_and_guided_update(dtype):
+def test_unet_latent_gradient_and_guided_update(dtype, variant):
     """d (loss_scale * compute_ca_lossv3) / d latents through the tiny SD plan (down path, mid block, up block 1: every layer kind
     incl. strided downsample, skip concat, nearest upsample) vs torch.autograd on the oracle, then one iteration of
     latent_backward_guidance (latents -= sqrt(1 - alpha_bar_t) * grad, models/pipelines.py:108-115).
@@ -150,7 +151,7 @@ def test_unet_latent_gradient_and_guided_update(dtype):
     from theatergen_amd import guidance as G
     from theatergen_amd.backward import UNetInputGrad, latent_backward_guidance
     from theatergen_amd.scheduler import DDIMScheduler
-    cfg = config.tiny()
+    cfg = config.tiny() if variant == "conv" else config.tiny(linear=True)       # SD-1.5-like / SD-2.1-like (linear projections, heads per level)
     unet, sd_r = _build(cfg, dtype)
     g = torch.Generator().manual_seed(9)
     lat = torch.randn(1, 4, 32, 32, generator=g)
@@ -174,7 +175,7 @@ def test_unet_latent_gradient_and_guided_update(dtype):
         assert abs(loss.item() - loss_ref.item()) <= 2e-2 * abs(loss_ref.item()), (name, loss.item(), loss_ref.item())
         m = pm.metrics(grad, grad_ref)
         cos = float(F.cosine_similarity(grad.cpu().flatten().double(), grad_ref.flatten().double(), dim=0))
-        pm.record(f"d loss / d latents, tiny UNet, {name} loss {dtype}", m, cosine=cos)
+        pm.record(f"d loss / d latents, tiny UNet ({variant}), {name} loss {dtype}", m, cosine=cos)
         if name == "ratio":
             l2, mx = (5e-2, 1e-1) if dtype == torch.bfloat16 else (8e-3, 2e-2)
             assert m["finite"] and m["rel_l2"] <= l2 and m["max_rel"] <= mx, (name, m)
