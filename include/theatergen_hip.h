@@ -108,7 +108,15 @@ typedef struct {
    * `F.pad(x, (0, 1, 0, 1))` + stride-2 conv of diffusers' Downsample2D(padding=0) in the VAE ENCODER
    * (AutoencoderKL.encode, models/pipelines.py:157, 624): input pixel = stride * out + tap, no -1 offset */
   int32_t pad_mode;
-  int32_t reserved0;
+  /* mode 1, stride 1, N % 320 == 0 only (the slab kernel, tg_gemm_plan kernel_kind 4): GroupNorm (+ SiLU) of the INPUT applied
+   * while the window is staged: A'[b, p, c] = act(A[b, p, c] * a[b, c] + d[b, c]) with a = rstd * gamma, d = beta - mean * a from
+   * tg_groupnorm_coef ([batch][2][c0 + c1] fp32: a then d per batch item); zero padding stays zero.  Same fp32 expression and
+   * storage-dtype rounding as tg_groupnorm, so conv(A', W) is bit-identical to tg_groupnorm followed by the plain conv; the
+   * normalised tensor never exists in HBM (ResnetBlock2D: conv1(nonlinearity(norm1(x))), conv2(nonlinearity(norm2(h))),
+   * models/unet_2d_blocks.py:184-195 via diffusers ResnetBlock2D.forward).  NULL = plain conv.  TG_ERR_UNSUPPORTED when the
+   * problem is not one the slab kernel takes (ask tg_gemm_plan first). */
+  int32_t a_silu;        /* 1: act = SiLU, 0: identity */
+  const void* a_coef;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
@@ -171,6 +179,11 @@ int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int3
                  void* partials, void* stream);
 int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, const void* gamma,
                  const void* beta, void* out, int64_t ldo, void* stream);
+/* GroupNorm statistics only: coef[b][0][c] = rstd(b, group(c)) * gamma[c], coef[b][1][c] = beta[c] - mean(b, group(c)) * coef[b][0][c]
+ * (fp32 [batch][2][c0 + c1]; the same reductions, in the same order, as tg_groupnorm) for tg_gemm_desc.a_coef: the apply pass
+ * (normalise + SiLU, one HBM write + read of the activation per conv) moves into the consumer conv's window staging. */
+int tg_groupnorm_coef(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch, int64_t hw,
+                      int32_t groups, float eps, const void* gamma, const void* beta, float* coef, void* partials, void* stream);
 
 /* out[m, j] = x[m, j] * gelu(x[m, inner + j])  (GEGLU.forward, models/attention.py:337-338) */
 int tg_geglu(int32_t dtype, const void* x, int64_t rows, int64_t inner, void* out, void* stream);

@@ -667,3 +667,107 @@ def test_gemm_big_tiles_qkv_split_and_geglu(dtype):
     check(big, y[:, :N2 // 2] * F.gelu(y[:, N2 // 2:]), dtype, "geglu big tile")
     same = torch.equal(small, big)
     assert same
+
+
+# ---- slab conv kernel (tg_conv_slab.hip): BM x 320 tiles, window staged once per 320 channels, GroupNorm + SiLU prologue ----
+SLAB_CASES = [
+    # B, h, w, cin, c1, cout, force_tile (11 = slab kernel regardless of the tile count)
+    (2, 64, 64, 320, 0, 320, 11),       # SD-1.5 level 0; 64 tiles: fewer tiles than workgroup slots
+    (2, 64, 64, 640, 320, 320, 11),     # up block 3: two sources (hidden + skip), 15 channel chunks
+    (1, 128, 64, 64, 0, 320, 11),       # ONE channel chunk (no staging under the loop), tall map
+    (3, 32, 32, 320, 0, 640, 11),       # two N tiles share a window
+    (3, 32, 32, 1280, 640, 640, 11),    # SD-1.5 up block 2, 30 chunks
+    (2, 64, 32, 128, 0, 320, 11),       # two chunks: the look-ahead request never fires
+    (34, 32, 32, 320, 0, 320, 11),      # 272 tiles on 256 persistent workgroups: second, partial round
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", SLAB_CASES)
+def test_conv_slab_kernel(dtype, case):
+    """slab kernel vs fp32 F.conv2d, bias + per-image vector + residual + scale epilogue; and bit-identical to the LDS-halo
+    kernel (same K order: channel chunk, tap, k) where that one takes the problem unsplit."""
+    import os
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    B, h, w, cin, c1, cout, ft = case
+    g = torch.Generator().manual_seed(sum(case))
+    ctot = cin + c1
+    x = rnd((B, ctot, h, w), dtype, g)
+    wt = rnd((cout, ctot, 3, 3), dtype, g, 1 / math.sqrt(9 * ctot))
+    bias, bvec, res = rnd((cout,), dtype, g), rnd((B, cout), dtype, g), rnd((B, cout, h, w), dtype, g)
+    ref = (F.conv2d(x.float(), wt.float(), bias.float(), padding=1) + bvec.float()[:, :, None, None] + res.float()) * 0.5
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, ctot)
+    x0 = tok[:, :cin].contiguous().to(dev)
+    x1 = tok[:, cin:].contiguous().to(dev) if c1 else None
+    kw = dict(x1=x1, c1=c1, bias=bias.to(dev), bvec=bvec.to(dev), rows_per_batch=h * w,
+              res=res.permute(0, 2, 3, 1).reshape(B * h * w, cout).contiguous().to(dev), out_scale=0.5)
+    wp = pack_conv3x3(wt).to(dev)
+    assert ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, plan_only=True, **kw)[3] == 4
+    out = ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, **kw)
+    got = out.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    check(got, ref, dtype, f"slab conv {case}")
+    old = os.environ.get("TG_GEMM_FLAGS")
+    os.environ["TG_GEMM_FLAGS"] = "128"                     # dev flag: the planner skips the slab kernel
+    try:
+        tm, tn, sp, kk = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
+        assert kk != 4
+        if kk == 2 and sp == 1:
+            halo = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
+            assert torch.equal(out, halo), "slab and halo kernels accumulate in the same order: outputs must be bit-identical"
+    finally:
+        if old is None:
+            del os.environ["TG_GEMM_FLAGS"]
+        else:
+            os.environ["TG_GEMM_FLAGS"] = old
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 64, 64, 320, 0, 320, 11), (2, 64, 64, 640, 320, 320, 11), (3, 32, 32, 960, 320, 640, 11),
+                                  (1, 64, 64, 64, 0, 320, 11), (2, 32, 32, 128, 0, 320, 11), (16, 32, 32, 640, 0, 640, 0)])
+def test_conv_slab_groupnorm_prologue(dtype, case):
+    """GroupNorm + SiLU applied while the window is staged == tg_groupnorm followed by the plain conv, bit for bit; the
+    coefficients against an fp32 reference; the heuristic (force_tile 0) takes a layer that fills the chip."""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    B, h, w, cin, c1, cout, ft = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    ctot = cin + c1
+    x = rnd((B, ctot, h, w), dtype, g) * 1.5 + 0.3
+    wt = rnd((cout, ctot, 3, 3), dtype, g, 1 / math.sqrt(9 * ctot))
+    bias = rnd((cout,), dtype, g)
+    gamma, beta = (1 + 0.2 * torch.randn(ctot, generator=g)).to(dtype), (0.1 * torch.randn(ctot, generator=g)).to(dtype)
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, ctot)
+    x0 = tok[:, :cin].contiguous().to(dev)
+    x1 = tok[:, cin:].contiguous().to(dev) if c1 else None
+    wp = pack_conv3x3(wt).to(dev)
+    if ft == 0:
+        assert ops.conv3x3_takes_gn(dtype, B, h, w, cin, c1, cout)
+    coef = ops.groupnorm_coef(x0, B, h * w, 32, 1e-5, gamma.to(dev), beta.to(dev), x1=x1)
+    xf = x.float().reshape(B, 32, -1)
+    mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    a_ref = rstd.repeat_interleave(ctot // 32, dim=1) * gamma.float()[None]
+    d_ref = beta.float()[None] - mean.repeat_interleave(ctot // 32, dim=1) * a_ref
+    cf = coef.cpu()
+    assert torch.allclose(cf[:, 0], a_ref, rtol=2e-4, atol=1e-5) and torch.allclose(cf[:, 1], d_ref, rtol=2e-4, atol=2e-4)
+    fused = ops.conv3x3(x0, wp, B, h, w, cin, x1=x1, c1=c1, bias=bias.to(dev), a_coef=coef, a_silu=True, force_tile=ft)
+    hn = ops.groupnorm(x0, B, h * w, 32, 1e-5, gamma.to(dev), beta.to(dev), silu=True, x1=x1)
+    plain = ops.conv3x3(hn, wp, B, h, w, ctot, bias=bias.to(dev), force_tile=ft)
+    assert torch.equal(fused, plain), f"fused GroupNorm prologue differs from norm -> conv: {(fused.float() - plain.float()).abs().max().item()}"
+    ref = F.conv2d(F.silu(F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-5)), wt.float(), bias.float(), padding=1)
+    got = fused.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+    check(got, ref, dtype, f"GroupNorm+SiLU -> conv {case}", scale=1.5)
+
+
+def test_conv_gn_prologue_rejected_outside_the_slab_kernel():
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    x = torch.randn(2 * 64, 128, device=dev).to(torch.bfloat16)        # N = 128: not a slab problem
+    wp = pack_conv3x3(torch.randn(128, 128, 3, 3).to(torch.bfloat16)).to(dev)
+    coef = torch.zeros(2, 2, 128, device=dev)
+    with pytest.raises(RuntimeError, match="slab conv kernel"):
+        ops.conv3x3(x, wp, 2, 8, 8, 128, a_coef=coef, a_silu=True)

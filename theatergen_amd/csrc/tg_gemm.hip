@@ -652,7 +652,27 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
 }  // namespace
 // big-tile kernels (tg_gemm_bt.hip): bt_tile 0 = 256 x 320, 1 = 128 x 320, 2 = 256 x 256
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
+// slab conv kernel (tg_conv_slab.hip): BM x 320 output tiles, GroupNorm(+SiLU) prologue on the staged window
+int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int bm, void* stream);
 namespace {
+
+// Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 32 / 64-wide maps, 128-pixel tiles.  -> pixels
+// per tile, 0 = not taken.  force_tile 11 = regardless of the tile count (tests); the heuristic wants the persistent grid (one
+// workgroup per CU, 256) at least 3/4 full in every round.  TG_GEMM_FLAGS bit 7 (dev) turns it off.  Not for the 16-wide maps:
+// there 128-pixel tiles are 128 workgroups (half the chip) and a 64 x 320 tile (built, measured, dropped) moves 40 KB of weights
+// per 640 matrix-pipe cycles = 64 B/clk per CU, the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.
+inline int slab_bm_of(const tg_gemm_desc* d) {
+  if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return 0;
+  if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
+  const int w = d->out_w;
+  if (w != 32 && w != 64) return 0;
+  if (((long)d->out_h * w) % 128 != 0 || d->M % 128 != 0) return 0;
+  if (d->force_tile == 11) return 128;
+  if (d->force_tile != 0) return 0;
+  { const char* e = getenv("TG_GEMM_FLAGS"); if (e && (strtol(e, nullptr, 0) & 128)) return 0; }
+  const long t = (d->M / 128) * (d->N / 320);
+  return 4 * t >= 3 * ((t + 255) / 256) * 256 ? 128 : 0;
+}
 
 // Big tiles (tg_gemm_bt.hip): force_tile 9 = 128 x 320, 10 = 256 x 256; plain GEMM with one A source, K a multiple of 64,
 // no K split.  What the heuristic (force_tile 0) takes, and why so little (profiles/r2_gemm_findings.md, all on MI355X):
@@ -705,12 +725,15 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     const char* e = getenv("TG_GEMM_FLAGS");          // dev experiments; read per launch so one process can A/B
     p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
   }
+  p.a_coef = d->a_coef; p.a_silu = d->a_silu;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
                 (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
+  if (const int bm = slab_bm_of(d); bm > 0) return tg_conv_slab_launch(d, &p, bm, st);
+  TG_CHECK(d->a_coef == nullptr, TG_ERR_UNSUPPORTED, "tg_gemm: a_coef (GroupNorm prologue) needs a problem the slab conv kernel takes (tg_gemm_plan kernel_kind 4)");
   {
     const int64_t need = plan_workspace_bytes(pl);
     TG_CHECK(need == 0 || (d->workspace != nullptr && d->workspace_bytes >= need), TG_ERR_ARG,
@@ -759,6 +782,7 @@ int validate(const tg_gemm_desc* d) {
   }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
   if (d->a1) TG_CHECK(d->c0 % BK == 0, TG_ERR_ARG, "tg_gemm: two-source A needs c0 %% 64 == 0 (c0=%d)", d->c0);
+  TG_CHECK(d->a_coef == nullptr || d->mode == 1, TG_ERR_ARG, "tg_gemm: a_coef is a conv (mode 1) argument");
   if (d->mode == 1) {
     TG_CHECK(ctot % BK == 0, TG_ERR_ARG, "tg_gemm conv: channels %% 64 required (c=%d)", ctot);
     TG_CHECK(d->K == 9L * ctot, TG_ERR_ARG, "tg_gemm conv: K must be 9*(c0+c1)");
@@ -790,6 +814,13 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
+  if (const int bm = slab_bm_of(d); bm > 0) {
+    if (tile_m) *tile_m = bm;
+    if (tile_n) *tile_n = 320;
+    if (splits) *splits = 1;
+    if (kernel_kind) *kernel_kind = 4;
+    return TG_OK;
+  }
   if (const int bt = bt_tile_of(d); bt >= 0) {
     if (tile_m) *tile_m = bt == 1 ? 128 : 256;
     if (tile_n) *tile_n = bt == 1 ? 320 : 256;
@@ -807,7 +838,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (bt_tile_of(d) >= 0) return 0;
+  if (slab_bm_of(d) > 0 || bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
 }
 

@@ -38,6 +38,8 @@ struct GemmParams {
   int tiles_n;
   long a_rpb, a_bs;
   int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
+  const void* a_coef;   // conv slab kernel: GroupNorm coefficients [batch][2][c0 + c1] fp32 (a, d): A' = act(A * a + d) while staging, or NULL
+  int a_silu;           // ... with SiLU
   int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
                     // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
 };

@@ -27,6 +27,7 @@ struct GnParams {
   float* stats;     // [batch][groups][2] (mean, rstd) — placed after the partials
   int nblk;
   int cx, ry;       // thread grid: cx channel-chunk columns x ry pixel rows
+  float* coef;      // tg_groupnorm_coef: [batch][2][C] (a = rstd * gamma, d = beta - mean * a) instead of the normalised tensor
 };
 
 template <typename T>
@@ -221,6 +222,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
   }
 }
 
+// statistics -> per-(batch, channel) coefficients, the prologue of gn_apply_kernel as a launch of its own (one block per
+// batch item): a = rstd * gamma, d = beta - mean * a, the expressions gn_apply_kernel evaluates per thread
+template <typename T>
+__global__ __launch_bounds__(256) void gn_coef_kernel(GnParams p) {
+  __shared__ float s_stats[2 * 256];
+  const int C = p.c0 + p.c1;
+  const int cpg = C / p.groups;
+  const int b = blockIdx.x;
+  gn_block_stats(p, b, s_stats);
+  const T* gam = reinterpret_cast<const T*>(p.gamma);
+  const T* bet = reinterpret_cast<const T*>(p.beta);
+  float* ca = p.coef + (long)b * 2 * C;
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const int g = ch / cpg;
+    const float mean = s_stats[g * 2];
+    const float rstd = s_stats[g * 2 + 1];
+    const float ga = gam ? to_f32<T>(gam[ch]) : 1.f;
+    const float be = bet ? to_f32<T>(bet[ch]) : 0.f;
+    const float a = rstd * ga;
+    ca[ch] = a;
+    ca[C + ch] = be - mean * a;
+  }
+}
+
 // SMALL MAPS (hw <= 256: the 16x16 and 8x8 levels) in ONE launch: a block owns one batch item x `gpb` whole groups
 // (nc = gpb * cpg / 8 chunk columns of 16 bytes), keeps its whole slab in registers (thread = (chunk column c, pixel lane
 // py), MAXP pixels each), and does mean -> centred variance -> normalise (+SiLU) -> store without going back to memory.
@@ -320,6 +345,14 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnParams p, int gpb, int 
     const float be = bet ? to_f32<T>(bv[j]) : 0.f;
     a[j] = rstd * ga;
     d[j] = be - mean * a[j];
+  }
+  if (p.coef != nullptr) {                       // statistics only (the consumer conv applies them while staging its window)
+    if (py == 0) {
+      float* ca = p.coef + (long)b * 2 * C + ch0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ca[j] = a[j]; ca[C + j] = d[j]; }
+    }
+    return;
   }
   T* out = reinterpret_cast<T*>(p.out);
 #pragma unroll
@@ -451,11 +484,12 @@ extern "C" int64_t tg_groupnorm_scratch_bytes(int32_t batch, int64_t hw, int32_t
   return ((int64_t)batch * nblk * groups * 2 + (int64_t)batch * groups * 2) * 4;
 }
 
-extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
-                            int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu,
-                            void* out, void* partials, void* stream) {
+namespace {
+int groupnorm_impl(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
+                   int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu,
+                   void* out, float* coef, void* partials, void* stream) {
   TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_groupnorm: bad dtype");
-  TG_CHECK(x0 && out && partials, TG_ERR_ARG, "tg_groupnorm: null pointer");
+  TG_CHECK(x0 && (out || coef) && partials, TG_ERR_ARG, "tg_groupnorm: null pointer");
   if (!x1) c1 = 0;
   const int C = c0 + c1;
   TG_CHECK(batch > 0 && hw > 0 && groups > 0 && C % groups == 0 && c0 % 8 == 0 && c1 % 8 == 0, TG_ERR_ARG,
@@ -463,7 +497,8 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
   TG_CHECK(C <= 8 * 256 * GN_MAX_CHUNKS, TG_ERR_ARG, "tg_groupnorm: C too large");
   GnParams p{};
   p.x0 = x0; p.x1 = x1; p.c0 = c0; p.c1 = c1; p.batch = batch; p.hw = hw; p.groups = groups; p.eps = eps;
-  p.gamma = gamma; p.beta = beta; p.silu = silu; p.out = out;
+  p.gamma = gamma; p.beta = beta; p.silu = silu; p.out = out; p.coef = coef;
+  TG_CHECK(coef == nullptr || groups <= 256, TG_ERR_ARG, "tg_groupnorm_coef: groups <= 256");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     int gpb, nc, npy, maxp;
@@ -495,11 +530,32 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
   if (dtype == TG_BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(gn_partial_kernel<f16_t>, grid, dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();
+  if (coef != nullptr) {
+    if (dtype == TG_BF16) hipLaunchKernelGGL(gn_coef_kernel<bf16_t>, dim3(batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gn_coef_kernel<f16_t>, dim3(batch), dim3(256), 0, st, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+  }
   const size_t lds_stats = (size_t)groups * 2 * sizeof(float);
   if (dtype == TG_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), lds_stats, st, p);
   else hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), lds_stats, st, p);
   TG_LAUNCH_CHECK();
   return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
+                            int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu,
+                            void* out, void* partials, void* stream) {
+  TG_CHECK(out != nullptr, TG_ERR_ARG, "tg_groupnorm: null out");
+  return groupnorm_impl(dtype, x0, x1, c0, c1, batch, hw, groups, eps, gamma, beta, silu, out, nullptr, partials, stream);
+}
+
+extern "C" int tg_groupnorm_coef(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
+                                 int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, float* coef,
+                                 void* partials, void* stream) {
+  TG_CHECK(coef != nullptr, TG_ERR_ARG, "tg_groupnorm_coef: null coef");
+  return groupnorm_impl(dtype, x0, x1, c0, c1, batch, hw, groups, eps, gamma, beta, 0, nullptr, coef, partials, stream);
 }
 
 extern "C" int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps,

@@ -5,6 +5,7 @@ every computation is a call into libtheatergen_hip.so.  Activations are token-ma
 ``[rows, channels]`` (``rows = batch * h * w``) in bf16 or fp16.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -67,7 +68,7 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -103,6 +104,12 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.force_tile = force_tile
     d.a_rows_per_batch, d.a_batch_stride = int(a_rows_per_batch), int(a_batch_stride)
     d.pad_mode = int(pad_mode)
+    d.a_coef = _ptr(a_coef)
+    d.a_silu = 1 if a_silu else 0
+    if plan_only:
+        tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)))
+        return tm.value, tn.value, sp.value, kk.value
     need = L.tg_gemm_workspace_bytes(C.byref(d))
     if need < 0:
         _lib.check(-1)
@@ -122,6 +129,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     e1.record()
     if kk.value == 2:
         kname = "conv_halo_kernel<128x128>"
+    elif kk.value == 4:
+        kname = f"conv_slab_kernel<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
     else:
@@ -212,6 +221,45 @@ def groupnorm(x0, batch, hw, groups, eps, gamma, beta, silu=False, x1=None, out=
     _lib.check(L.tg_groupnorm(_dt(x0), _ptr(x0), _ptr(x1), c0, c1, batch, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
                               1 if silu else 0, _ptr(out), _ptr(scratch), _stream()))
     return out
+
+
+def groupnorm_coef(x0, batch, hw, groups, eps, gamma, beta, x1=None):
+    """GroupNorm statistics only -> fp32 [batch, 2, C]: a = rstd * gamma, d = beta - mean * a (``conv3x3(..., a_coef=)``)."""
+    _need_cuda(x0)
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    L = _lib.lib()
+    coef = torch.empty((batch, 2, c0 + c1), dtype=torch.float32, device=x0.device)
+    scratch = workspace(L.tg_groupnorm_scratch_bytes(batch, hw, groups), x0.device)
+    _lib.check(L.tg_groupnorm_coef(_dt(x0), _ptr(x0), _ptr(x1), c0, c1, batch, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+                                   _ptr(coef), _ptr(scratch), _stream()))
+    return coef
+
+
+_slab_plans = {}
+
+
+def conv3x3_takes_gn(dtype, batch, in_h, in_w, cin, c1, cout):
+    """True when tg_gemm runs this stride-1 conv on the slab kernel (tg_gemm_plan kernel_kind 4), which can apply
+    GroupNorm + SiLU to its input while staging it (``a_coef``)."""
+    key = (dtype, batch, in_h, in_w, cin, c1, cout, os.environ.get("TG_GEMM_FLAGS"))
+    hit = _slab_plans.get(key)
+    if hit is None:
+        L = _lib.lib()
+        d = GemmDesc()
+        d.dtype = 0 if dtype == torch.bfloat16 else 1
+        d.mode = 1
+        d.a0 = d.w = d.out = 16                      # plan only: pointers are not dereferenced, just non-NULL and aligned
+        d.a1 = 16 if c1 else None
+        d.c0, d.c1 = int(cin), int(c1)
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.stride, d.upsample = batch, in_h, in_w, in_h, in_w, 1, 0
+        d.M, d.N, d.K = batch * in_h * in_w, int(cout), 9 * (cin + c1)
+        d.ldc = int(cout)
+        d.out_scale = 1.0
+        kk = C.c_int32()
+        hit = L.tg_gemm_plan(C.byref(d), None, None, None, C.byref(kk)) == 0 and kk.value == 4
+        _slab_plans[key] = hit
+    return hit
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):

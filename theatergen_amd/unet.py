@@ -21,6 +21,8 @@ Execution is MI355X-first, not a module-by-module translation:
 """
 from types import SimpleNamespace
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -66,6 +68,10 @@ class _Packed:
         return hit[1]
 
 
+# dev switch: TG_NO_GN_FUSE=1 keeps GroupNorm and conv two ops everywhere (A/B of the fused window staging)
+_FUSE_GN = not os.environ.get("TG_NO_GN_FUSE")
+
+
 class ResnetBlock2D(nn.Module):
     """diffusers 0.21.4 ResnetBlock2D semantics (SURVEY §8(a) R1): h = conv1(silu(GN(x))) + Linear(silu(temb));
     h = conv2(silu(GN(h))); out = (shortcut(x) + h) / output_scale_factor."""
@@ -90,23 +96,33 @@ class ResnetBlock2D(nn.Module):
         assert x.c + c1 == self.in_channels
         w1 = self._p.get("c1", [self.conv1.weight], lambda: pack_conv3x3(self.conv1.weight.detach()))
         w2 = self._p.get("c2", [self.conv2.weight], lambda: pack_conv3x3(self.conv2.weight.detach()))
-        h = ops.groupnorm(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, silu=True,
-                          x1=skip.t if skip is not None else None)
+        # GroupNorm + SiLU ride in the conv's window staging where the slab conv kernel takes the layer (N % 320 == 0, enough
+        # tiles to fill the chip): only the statistics pass (-> per-(image, channel) a, d) remains a launch of its own and
+        # the normalised tensor never reaches HBM; elsewhere norm and conv stay two ops.  Same values bit for bit.
+        x1 = skip.t if skip is not None else None
+        kw1 = dict(bias=self.conv1.bias)
         if tproj is not None:
             off, width = self.temb_slot
-            h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias, bvec=tproj[:, off:off + width],
-                            rows_per_batch=x.hw)
+            kw1.update(bvec=tproj[:, off:off + width], rows_per_batch=x.hw)
+        if _FUSE_GN and ops.conv3x3_takes_gn(x.t.dtype, x.b, x.h, x.w, x.c, c1, self.out_channels):
+            coef = ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, x1=x1)
+            h = ops.conv3x3(x.t, w1, x.b, x.h, x.w, x.c, x1=x1, c1=c1, a_coef=coef, a_silu=True, **kw1)
         else:
-            h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, bias=self.conv1.bias)
-        h = ops.groupnorm(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias, silu=True)
+            h = ops.groupnorm(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, silu=True, x1=x1)
+            h = ops.conv3x3(h, w1, x.b, x.h, x.w, self.in_channels, **kw1)
         if self.conv_shortcut is not None:
             ws = self._p.get("sc", [self.conv_shortcut.weight], lambda: pack_conv1x1(self.conv_shortcut.weight.detach()))
             res = ops.gemm(x.t, ws, x.b * x.hw, self.out_channels, self.in_channels, a1=skip.t if skip is not None else None,
                            c0=x.c, c1=c1, bias=self.conv_shortcut.bias)
         else:
             res = x.t
-        out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, bias=self.conv2.bias, res=res,
-                          out_scale=1.0 / self.output_scale_factor)
+        kw2 = dict(bias=self.conv2.bias, res=res, out_scale=1.0 / self.output_scale_factor)
+        if _FUSE_GN and ops.conv3x3_takes_gn(h.dtype, x.b, x.h, x.w, self.out_channels, 0, self.out_channels):
+            coef = ops.groupnorm_coef(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias)
+            out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, a_coef=coef, a_silu=True, **kw2)
+        else:
+            h = ops.groupnorm(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias, silu=True)
+            out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, **kw2)
         return _Act(out, x.b, x.h, x.w, self.out_channels)
 
 
