@@ -122,7 +122,8 @@ typedef struct {
 int tg_gemm(const tg_gemm_desc* d, void* stream);
 int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
 /* the tile (tokens x channels), the K-split of the tail tiles (1 = none) and the kernel (0 = GEMM, 1 = implicit-GEMM
- * conv, 2 = LDS-halo conv, 3 = big-tile persistent GEMM) the heuristic picks for a descriptor (bench / profiling attribution) */
+ * conv, 2 = LDS-halo conv, 3 = big-tile persistent GEMM, 4 = slab conv (128 x 320 tiles, loader + compute waves, optional
+ * GroupNorm prologue), 5 = loader / compute GEMM (128 x 320 tiles, long K)) the heuristic picks for a descriptor */
 int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind);
 
 /* ---------------------------------------------------------------------------------------------

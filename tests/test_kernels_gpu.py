@@ -772,3 +772,36 @@ def test_conv_gn_prologue_rejected_outside_the_slab_kernel():
     coef = torch.zeros(2, 2, 128, device=dev)
     with pytest.raises(RuntimeError, match="slab conv kernel"):
         ops.conv3x3(x, wp, 2, 8, 8, 128, a_coef=coef, a_silu=True)
+
+
+# ---- loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles, long K, optional K split ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    # M, N, K, force_tile (13 = 1 split, 14 = 2 splits, 0 = heuristic), expected splits
+    (256, 320, 1280, 13, 1),           # two tiles, 20 K-steps
+    (1024, 640, 64, 13, 1),            # ONE K-step (no refill, no second stage)
+    (384, 960, 192, 14, 2),            # 3 K-steps split 2 + 1
+    (4096, 1280, 5120, 0, 2),          # SD-1.5 16x16 level FeedForward net.2: 128 tiles -> the heuristic splits K in 2
+    (16384, 640, 2560, 0, 1),          # FeedForward net.2 at 32x32: 256 tiles
+    (34816, 320, 1024, 13, 1),         # 272 tiles on 256 persistent workgroups
+])
+def test_gemm_loader_compute_kernel(dtype, case, monkeypatch):
+    """vs fp32 matmul with bias + per-batch vector + residual + scale; deterministic; kernel_kind 5 (the heuristic takes it
+    only with the dev switch TG_GEMM_FLAGS bit 8: measured no end-to-end gain, see tg_gemm.hip)"""
+    from theatergen_amd import ops
+    dev = _dev()
+    M, N, K, ft, want_s = case
+    monkeypatch.setenv("TG_GEMM_FLAGS", "256")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = rnd((M, K), dtype, g).to(dev)
+    w = rnd((N, K), dtype, g, 1 / math.sqrt(K)).to(dev)
+    bias, res = rnd((N,), dtype, g).to(dev), rnd((M, N), dtype, g).to(dev)
+    nb = 4
+    bvec = rnd((nb, N), dtype, g).to(dev)
+    ref = (a.float() @ w.float().t() + bias.float() + bvec.float().repeat_interleave(M // nb, dim=0) + res.float()) * 0.5
+    kw = dict(bias=bias, res=res, bvec=bvec, rows_per_batch=M // nb, out_scale=0.5, force_tile=ft)
+    tm, tn, sp, kk = ops.gemm(a, w, M, N, K, plan_only=True, **kw)
+    assert (tm, tn, sp, kk) == (128, 320, want_s, 5)
+    out = ops.gemm(a, w, M, N, K, **kw)
+    check(out, ref.cpu(), dtype, f"loader/compute gemm {case}")
+    assert torch.equal(out, ops.gemm(a, w, M, N, K, **kw))

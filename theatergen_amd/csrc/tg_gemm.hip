@@ -654,7 +654,33 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
 // slab conv kernel (tg_conv_slab.hip): BM x 320 output tiles, GroupNorm(+SiLU) prologue on the staged window
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int bm, void* stream);
+// loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles for long-K plain GEMMs
+int tg_gemm_lc_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 namespace {
+
+// Loader / compute GEMM (tg_gemm_lc.hip): plain GEMM, one A source, N a multiple of 320, K a multiple of 64 and >= 1024, linear
+// epilogue.  -> K splits per tile (1 | 2), 0 = not taken.  force_tile 13 / 14 = 1 / 2 splits regardless of the tile count (tests);
+// the heuristic wants the persistent grid (256 workgroups) at least 3/4 full in every round, with the K split if that is what it
+// takes and every split keeps >= 32 K-steps.  NOT selected by default: in isolation (scripts/dev_lc_bench.py, rotating operands) it
+// beats the 128x128 kernel on the FeedForward output projections (65536x320x1280 98 vs 110 us, 16384x640x2560 81 vs 102,
+// 4096x1280x5120 split in two 86 vs 97, 8192x3840x4096 846 vs 746 TF), in the hipGraph-replayed bench the same launches change
+// nothing (7.910 vs 7.924 images/s, three interleaved rounds): at K = 1280..5120 a 128 x 320 tile is 20..80 K-steps, and its
+// epilogue (the compute waves alone, twelve dependent residual-load -> bounce -> store chains) is as long as a 20-step K loop.
+// TG_GEMM_FLAGS bit 8 (dev) turns the heuristic on.
+inline int lc_splits_of(const tg_gemm_desc* d) {
+  if (d->mode != 0 || d->geglu || d->act != TG_ACT_NONE || d->a1 != nullptr || d->a_rows_per_batch > 0 || d->n_split > 0) return 0;
+  if (d->N % 320 != 0 || d->K % BK != 0 || d->M % 128 != 0 || d->force_split_k > 1) return 0;
+  if (d->force_tile == 13) return 1;
+  if (d->force_tile == 14) return d->K / BK >= 2 ? 2 : 0;
+  if (d->force_tile != 0 || d->K < 1024) return 0;
+  { const char* e = getenv("TG_GEMM_FLAGS"); if (!e || !(strtol(e, nullptr, 0) & 256)) return 0; }
+  const long t = (d->M / 128) * (d->N / 320);
+  auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
+  if (full(t)) return 1;
+  // (split in 2 only where each half keeps >= 32 K-steps: 4096 x 1280 x 1280 measured 39 us split against 30 on the 128x128 kernel)
+  if (d->K / BK >= 64 && full(2 * t)) return 2;
+  return 0;
+}
 
 // Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 32 / 64-wide maps, 128-pixel tiles.  -> pixels
 // per tile, 0 = not taken.  force_tile 11 = regardless of the tile count (tests); the heuristic wants the persistent grid (one
@@ -733,6 +759,20 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
   if (const int bm = slab_bm_of(d); bm > 0) return tg_conv_slab_launch(d, &p, bm, st);
+  if (const int sp = lc_splits_of(d); sp > 0) {
+    const long tiles = (d->M / 128) * (d->N / 320);
+    if (sp > 1) {
+      const int64_t need = tiles * sp * 128 * 320 * 4;
+      TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= need, TG_ERR_ARG, "tg_gemm: the K split needs %lld workspace bytes, got %lld",
+               (long long)need, (long long)d->workspace_bytes);
+    }
+    int rc = tg_gemm_lc_launch(d, &p, sp, st);
+    if (rc != TG_OK || sp == 1) return rc;
+    p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
+    Plan rp = pl;
+    rp.tail = (int)tiles; rp.s = sp;
+    return launch_reduce<T>(p, rp, st);
+  }
   TG_CHECK(d->a_coef == nullptr, TG_ERR_UNSUPPORTED, "tg_gemm: a_coef (GroupNorm prologue) needs a problem the slab conv kernel takes (tg_gemm_plan kernel_kind 4)");
   {
     const int64_t need = plan_workspace_bytes(pl);
@@ -821,6 +861,13 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
     if (kernel_kind) *kernel_kind = 4;
     return TG_OK;
   }
+  if (const int sp = lc_splits_of(d); sp > 0) {
+    if (tile_m) *tile_m = 128;
+    if (tile_n) *tile_n = 320;
+    if (splits) *splits = sp;
+    if (kernel_kind) *kernel_kind = 5;
+    return TG_OK;
+  }
   if (const int bt = bt_tile_of(d); bt >= 0) {
     if (tile_m) *tile_m = bt == 1 ? 128 : 256;
     if (tile_n) *tile_n = bt == 1 ? 320 : 256;
@@ -838,7 +885,9 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (slab_bm_of(d) > 0 || bt_tile_of(d) >= 0) return 0;
+  if (slab_bm_of(d) > 0) return 0;
+  if (const int sp = lc_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
+  if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
 }
 

@@ -131,6 +131,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         kname = "conv_halo_kernel<128x128>"
     elif kk.value == 4:
         kname = f"conv_slab_kernel<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
+    elif kk.value == 5:
+        kname = f"lc_gemm_kernel<{tm.value}x{tn.value}>"
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
     else:
