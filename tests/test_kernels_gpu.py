@@ -672,7 +672,11 @@ def test_gemm_big_tiles_qkv_split_and_geglu(dtype):
 
 # ---- slab conv kernel (tg_conv_slab.hip): BM x 320 tiles, window staged once per 320 channels, GroupNorm + SiLU prologue ----
 SLAB_CASES = [
-    # B, h, w, cin, c1, cout, force_tile (11 = slab kernel regardless of the tile count)
+    # B, h, w, cin, c1, cout, force_tile (11 = slab kernel regardless of the tile count, 12 = channel chunks split in two)
+    (5, 16, 16, 1280, 0, 1280, 12),     # 16-wide maps: a 32-pixel fragment spans two image rows; 20 chunks in 10 + 10
+    (4, 16, 16, 1280, 640, 1280, 12),   # two sources, 30 chunks
+    (16, 16, 16, 640, 0, 1280, 0),      # the heuristic splits the SD-1.5 16x16 level (128 tiles) in two
+    (2, 64, 64, 192, 0, 320, 12),       # 3 chunks in 2 + 1
     (2, 64, 64, 320, 0, 320, 11),       # SD-1.5 level 0; 64 tiles: fewer tiles than workgroup slots
     (2, 64, 64, 640, 320, 320, 11),     # up block 3: two sources (hidden + skip), 15 channel chunks
     (1, 128, 64, 64, 0, 320, 11),       # ONE channel chunk (no staging under the loop), tall map
@@ -705,7 +709,8 @@ def test_conv_slab_kernel(dtype, case):
     kw = dict(x1=x1, c1=c1, bias=bias.to(dev), bvec=bvec.to(dev), rows_per_batch=h * w,
               res=res.permute(0, 2, 3, 1).reshape(B * h * w, cout).contiguous().to(dev), out_scale=0.5)
     wp = pack_conv3x3(wt).to(dev)
-    assert ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, plan_only=True, **kw)[3] == 4
+    plan = ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, plan_only=True, **kw)
+    assert plan[3] == 4 and plan[2] == (2 if ft == 12 or case[0] == 16 else 1)
     out = ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, **kw)
     got = out.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     check(got, ref, dtype, f"slab conv {case}")
@@ -714,7 +719,7 @@ def test_conv_slab_kernel(dtype, case):
     try:
         tm, tn, sp, kk = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
         assert kk != 4
-        if kk == 2 and sp == 1:
+        if kk == 2 and sp == 1 and plan[2] == 1:
             halo = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
             assert torch.equal(out, halo), "slab and halo kernels accumulate in the same order: outputs must be bit-identical"
     finally:
@@ -726,7 +731,8 @@ def test_conv_slab_kernel(dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 64, 64, 320, 0, 320, 11), (2, 64, 64, 640, 320, 320, 11), (3, 32, 32, 960, 320, 640, 11),
-                                  (1, 64, 64, 64, 0, 320, 11), (2, 32, 32, 128, 0, 320, 11), (16, 32, 32, 640, 0, 640, 0)])
+                                  (1, 64, 64, 64, 0, 320, 11), (2, 32, 32, 128, 0, 320, 11), (16, 32, 32, 640, 0, 640, 0),
+                                  (16, 16, 16, 1280, 1280, 1280, 0), (3, 16, 16, 640, 0, 1280, 12)])
 def test_conv_slab_groupnorm_prologue(dtype, case):
     """GroupNorm + SiLU applied while the window is staged == tg_groupnorm followed by the plain conv, bit for bit; the
     coefficients against an fp32 reference; the heuristic (force_tile 0) takes a layer that fills the chip."""

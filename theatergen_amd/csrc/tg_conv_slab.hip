@@ -55,11 +55,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = (int)threadIdx.x & 255;          // thread index within the role
 
   const int ctot = p.c0 + p.c1;
-  const int nchunks = ctot / BK;
-  const int nkt = nchunks * 9;
+  const int nchunks_all = ctot / BK;
+  // K split over channel chunks (the 16-wide maps: M = 4096 is 32 row tiles x 4 column tiles = half the chip): work item
+  // w -> (tile w / S, split w % S), split sp owns chunks [sp * cps, min((sp + 1) * cps, all)), fp32 partial tiles + tg_gemm.hip's
+  // fixed-order reduce kernel (bias / vector / residual / scale applied there)
+  const int S = p.tail_s, cps = p.kt_per_split;
   const int H = p.in_h;
   const int tiles_m = (int)(p.M / BM);
-  const int ntiles = tiles_m * p.tiles_n;
+  const int ntiles = tiles_m * p.tiles_n * S;       // work items
 
   if (loader) {
     // =========================================================== loader waves ===========================================
@@ -142,10 +145,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < SJ; ++j) *reinterpret_cast<u32x4*>(smem + sdst + (unsigned)j * 4096u) = sreg[j];
     };
+    int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
     auto setup_tile = [&](int v) {
       const int lbid = xcd_chunked_block_id(v, ntiles);
-      const int tile_n = lbid % p.tiles_n, tile_m = lbid / p.tiles_n;
+      const int t = lbid / S, sp = lbid - t * S;
+      const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
       const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+      cfirst = sp * cps;
+      nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
+      nkt = nchunks * 9;
       img = (int)(m0 / ((long)H * WI));
       const int y0 = (int)((m0 - (long)img * H * WI) / WI);
 #pragma unroll
@@ -162,10 +170,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // this runs while the compute waves are in the previous tile's epilogue (which bounces through the slab region)
     auto prologue = [&](int v) {
       setup_tile(v);
-      issue_w(0, 0, 0);
-      load_slab(0);
-      issue_w(0, 1, 1);
-      issue_w(0, 2, 2);
+      issue_w(cfirst, 0, 0);
+      load_slab(cfirst);
+      issue_w(cfirst, 1, 1);
+      issue_w(cfirst, 2, 2);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WJ) : "memory");  // all but weight tiles 1 and 2
       slab_landed();
 #pragma unroll
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int tap = 0; tap < 9; ++tap, ++kt) {
           // the next chunk's window: requested at tap 0, landed by the seam of tap 2, normalised in registers in taps 3..8
           // (two rows in taps 3..5, one in taps 6..8: a loader never holds up a barrier with a long VALU stretch)
-          if (tap == 0 && more) load_slab(cc + 1);
+          if (tap == 0 && more) load_slab(cfirst + cc + 1);
           if (more) {
 #pragma unroll
             for (int j = 0; j < SJ; ++j)
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_s_barrier();
           if (kt + 3 < nkt) {                       // every compute wave has its last fragments of stage tap % 3: refill it
             const int t3 = tap + 3;
-            issue_w(t3 >= 9 ? cc + 1 : cc, t3 >= 9 ? t3 - 9 : t3, tap % 3);
+            issue_w(cfirst + (t3 >= 9 ? cc + 1 : cc), t3 >= 9 ? t3 - 9 : t3, tap % 3);
           }
           if (tap == 8 && more) {                   // chunk boundary: the slab has been read for the last time
             write_slab();
@@ -275,8 +283,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
     const int lbid = xcd_chunked_block_id(v, ntiles);
-    const int tile_n = lbid % p.tiles_n, tile_m = lbid / p.tiles_n;
+    const int t = lbid / S, sp = lbid - t * S;
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+    const int nchunks = nchunks_all - sp * cps < cps ? nchunks_all - sp * cps : cps;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -331,21 +341,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (measured and dropped, scripts/dev_slab_exp.py same-process A/B: the loaders touching the tile's residual lines a few
     // K-steps ahead so that the epilogue's loads hit L2: 2 % slower; s_setprio on either role: no gain)
     epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                   reinterpret_cast<float*>(smem) + wave * (32 * 68), -1, m0, n0);
+                                   reinterpret_cast<float*>(smem) + wave * (32 * 68), S > 1 ? lbid : -1, m0, n0);
   }
 }
 
 template <typename T, int WI, bool PRO>
-int launch_slab(const tg_gemm_desc* d, GemmParams p, hipStream_t st) {
+int launch_slab(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st) {
   constexpr int BM = 128, TH = BM / WI, SLAB = (TH + 2) * (WI + 2), SJ = (SLAB + 31) / 32;
   constexpr size_t slab = (size_t)SJ * 32 * 128, scratch = 4 * 32 * 68 * 4;
   const size_t lds = (slab > scratch ? slab : scratch) + 3 * (size_t)320 * 128;
   const long tiles_m = d->M / BM, tiles_n = d->N / 320;
+  const int nchunks = (d->c0 + (d->a1 ? d->c1 : 0)) / BK;
   p.tiles_n = (int)tiles_n;
-  p.full_tiles = (int)(tiles_m * tiles_n);
-  p.tail_s = 1;
+  p.full_tiles = 0;                               // with splits > 1 every tile is a "tail" tile of the reduce kernel
+  p.tail_s = splits;
+  p.kt_per_split = (nchunks + splits - 1) / splits;   // channel chunks per split
   p.tile_bm = BM; p.tile_bn = 320;
-  long grid = tiles_m * tiles_n;
+  long grid = tiles_m * tiles_n * splits;
   if (grid > 256) grid = 256;                     // one persistent workgroup per CU
   auto k = conv_slab_kernel<T, WI, PRO>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -356,22 +368,23 @@ int launch_slab(const tg_gemm_desc* d, GemmParams p, hipStream_t st) {
 }
 
 template <typename T>
-int launch_slab_dtype(const tg_gemm_desc* d, const GemmParams& p, hipStream_t st) {
+int launch_slab_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hipStream_t st) {
   const int w = d->out_w;
   const bool pro = d->a_coef != nullptr;
-  if (w == 64) return pro ? launch_slab<T, 64, true>(d, p, st) : launch_slab<T, 64, false>(d, p, st);
-  if (w == 32) return pro ? launch_slab<T, 32, true>(d, p, st) : launch_slab<T, 32, false>(d, p, st);
+  if (w == 64) return pro ? launch_slab<T, 64, true>(d, p, splits, st) : launch_slab<T, 64, false>(d, p, splits, st);
+  if (w == 32) return pro ? launch_slab<T, 32, true>(d, p, splits, st) : launch_slab<T, 32, false>(d, p, splits, st);
+  if (w == 16) return pro ? launch_slab<T, 16, true>(d, p, splits, st) : launch_slab<T, 16, false>(d, p, splits, st);
   tg_set_error("tg_gemm conv: no slab kernel for width %d", w);
   return TG_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// Called by tg_gemm.hip's planner (not part of the C ABI); GemmParams arrives filled except for the tile bookkeeping.
-int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int bm, void* stream) {
+// Called by tg_gemm.hip's planner (not part of the C ABI); GemmParams arrives filled except for the tile bookkeeping.  With
+// splits > 1 the caller runs the reduce kernel over the tiles_m * tiles_n tail tiles of `splits` partials each.
+int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (bm != 128) { tg_set_error("tg_gemm conv: slab tiles are 128 pixels"); return TG_ERR_ARG; }
-  if (d->dtype == TG_BF16) return launch_slab_dtype<bf16_t>(d, p, st);
-  return launch_slab_dtype<f16_t>(d, p, st);
+  if (d->dtype == TG_BF16) return launch_slab_dtype<bf16_t>(d, p, splits, st);
+  return launch_slab_dtype<f16_t>(d, p, splits, st);
 }

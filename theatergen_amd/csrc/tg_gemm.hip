@@ -653,10 +653,34 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
 // big-tile kernels (tg_gemm_bt.hip): bt_tile 0 = 256 x 320, 1 = 128 x 320, 2 = 256 x 256
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
 // slab conv kernel (tg_conv_slab.hip): BM x 320 output tiles, GroupNorm(+SiLU) prologue on the staged window
-int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int bm, void* stream);
+int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 // loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles for long-K plain GEMMs
 int tg_gemm_lc_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 namespace {
+
+// Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 16 / 32 / 64-wide maps, 128-pixel x 320-channel
+// tiles.  -> K splits per tile (over 64-channel chunks), 0 = not taken.  force_tile 11 / 12 = 1 / 2 splits regardless of the tile
+// count (tests); the heuristic wants the persistent grid (one workgroup per CU, 256) at least 3/4 full in every round, splitting
+// the channel chunks in 2 if that is what it takes (the 16-wide maps: 128 tiles; every split keeps >= 5 chunks = 45 K-steps).
+// TG_GEMM_FLAGS bit 7 (dev) turns it off.  (A 64 x 320 tile for the 16-wide maps was built, measured and dropped: 40 KB of weights
+// per 640 matrix-pipe cycles = 64 B/clk per CU is the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.)
+inline int slab_splits_of(const tg_gemm_desc* d) {
+  if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return 0;
+  if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
+  const int w = d->out_w;
+  if (w != 16 && w != 32 && w != 64) return 0;
+  if (((long)d->out_h * w) % 128 != 0 || d->M % 128 != 0) return 0;
+  const int chunks = (d->c0 + (d->a1 ? d->c1 : 0)) / BK;
+  if (d->force_tile == 11) return 1;
+  if (d->force_tile == 12) return chunks >= 2 ? 2 : 0;
+  if (d->force_tile != 0) return 0;
+  { const char* e = getenv("TG_GEMM_FLAGS"); if (e && (strtol(e, nullptr, 0) & 128)) return 0; }
+  const long t = (d->M / 128) * (d->N / 320);
+  auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
+  if (full(t)) return 1;
+  if (chunks >= 10 && full(2 * t)) return 2;
+  return 0;
+}
 
 // Loader / compute GEMM (tg_gemm_lc.hip): plain GEMM, one A source, N a multiple of 320, K a multiple of 64 and >= 1024, linear
 // epilogue.  -> K splits per tile (1 | 2), 0 = not taken.  force_tile 13 / 14 = 1 / 2 splits regardless of the tile count (tests);
@@ -680,24 +704,6 @@ inline int lc_splits_of(const tg_gemm_desc* d) {
   // (split in 2 only where each half keeps >= 32 K-steps: 4096 x 1280 x 1280 measured 39 us split against 30 on the 128x128 kernel)
   if (d->K / BK >= 64 && full(2 * t)) return 2;
   return 0;
-}
-
-// Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 32 / 64-wide maps, 128-pixel tiles.  -> pixels
-// per tile, 0 = not taken.  force_tile 11 = regardless of the tile count (tests); the heuristic wants the persistent grid (one
-// workgroup per CU, 256) at least 3/4 full in every round.  TG_GEMM_FLAGS bit 7 (dev) turns it off.  Not for the 16-wide maps:
-// there 128-pixel tiles are 128 workgroups (half the chip) and a 64 x 320 tile (built, measured, dropped) moves 40 KB of weights
-// per 640 matrix-pipe cycles = 64 B/clk per CU, the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.
-inline int slab_bm_of(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return 0;
-  if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
-  const int w = d->out_w;
-  if (w != 32 && w != 64) return 0;
-  if (((long)d->out_h * w) % 128 != 0 || d->M % 128 != 0) return 0;
-  if (d->force_tile == 11) return 128;
-  if (d->force_tile != 0) return 0;
-  { const char* e = getenv("TG_GEMM_FLAGS"); if (e && (strtol(e, nullptr, 0) & 128)) return 0; }
-  const long t = (d->M / 128) * (d->N / 320);
-  return 4 * t >= 3 * ((t + 255) / 256) * 256 ? 128 : 0;
 }
 
 // Big tiles (tg_gemm_bt.hip): force_tile 9 = 128 x 320, 10 = 256 x 256; plain GEMM with one A source, K a multiple of 64,
@@ -758,7 +764,20 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
-  if (const int bm = slab_bm_of(d); bm > 0) return tg_conv_slab_launch(d, &p, bm, st);
+  if (const int sp = slab_splits_of(d); sp > 0) {
+    const long tiles = (d->M / 128) * (d->N / 320);
+    if (sp > 1) {
+      const int64_t need = tiles * sp * 128 * 320 * 4;
+      TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= need, TG_ERR_ARG, "tg_gemm conv: the K split needs %lld workspace bytes, got %lld",
+               (long long)need, (long long)d->workspace_bytes);
+    }
+    int rc = tg_conv_slab_launch(d, &p, sp, st);
+    if (rc != TG_OK || sp == 1) return rc;
+    p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
+    Plan rp = pl;
+    rp.tail = (int)tiles; rp.s = sp;
+    return launch_reduce<T>(p, rp, st);
+  }
   if (const int sp = lc_splits_of(d); sp > 0) {
     const long tiles = (d->M / 128) * (d->N / 320);
     if (sp > 1) {
@@ -854,10 +873,10 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
-  if (const int bm = slab_bm_of(d); bm > 0) {
-    if (tile_m) *tile_m = bm;
+  if (const int sp = slab_splits_of(d); sp > 0) {
+    if (tile_m) *tile_m = 128;
     if (tile_n) *tile_n = 320;
-    if (splits) *splits = 1;
+    if (splits) *splits = sp;
     if (kernel_kind) *kernel_kind = 4;
     return TG_OK;
   }
@@ -885,7 +904,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (slab_bm_of(d) > 0) return 0;
+  if (const int sp = slab_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (const int sp = lc_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
