@@ -25,9 +25,13 @@ FAMILIES = [
     ("bt_gemm_kernel<256x256>", lambda n: "bt_gemm_kernel" in n and "Li256ELi256E" in n),
     ("gemm_glds_kernel<conv,128x128>", lambda n: "gemm_glds_kernel" in n and "Li128ELi128ELi2ELi2ELb1E" in n),
     ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n),
+    ("conv_slab_kernel<128x320,w64>", lambda n: "conv_slab_kernel" in n and "Li64E" in n),
+    ("conv_slab_kernel<128x320,w32>", lambda n: "conv_slab_kernel" in n and "Li32E" in n),
+    ("conv_slab_kernel<128x320,w16,split2>", lambda n: "conv_slab_kernel" in n and "Li16E" in n),
+    ("splitk_reduce_kernel", lambda n: "splitk_reduce_kernel" in n),
     ("attention_kernel<d40>", lambda n: "attention_kernel" in n and "Li48ELi64E" in n),
     ("attention_kernel<other>", lambda n: "attention_kernel" in n and "Li48ELi64E" not in n),
-    ("groupnorm", lambda n: "gn_apply_kernel" in n or "gn_partial_kernel" in n or "gn_small_kernel" in n),
+    ("groupnorm", lambda n: "gn_apply_kernel" in n or "gn_partial_kernel" in n or "gn_small_kernel" in n or "gn_coef_kernel" in n),
     ("layernorm", lambda n: "layernorm_kernel" in n),
 ]
 
