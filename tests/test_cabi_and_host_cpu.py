@@ -307,3 +307,66 @@ def test_static_slots_identity_is_the_object_not_the_address():
     with torch.inference_mode():
         t = torch.ones(2)
     assert tensor_version(t) is None and tensor_version(b) == 0
+
+
+def test_gemm_planner_kernel_choice(monkeypatch):
+    """tg_gemm_plan is host logic: which kernel / tile / split a descriptor gets (no launch, works without a GPU).
+    kernel_kind: 0 GEMM, 1 implicit-GEMM conv, 2 LDS-halo conv, 3 big-tile GEMM, 4 slab conv (GroupNorm prologue), 5 loader / compute GEMM."""
+    import ctypes as C
+    from theatergen_amd import _lib
+    h = _lib.lib()
+    monkeypatch.delenv("TG_GEMM_FLAGS", raising=False)
+
+    def conv(batch, hh, ww, cin, cout, c1=0, stride=1, force_tile=0, a_coef=None):
+        d = _lib.GemmDesc()
+        d.dtype, d.mode = 0, 1
+        d.a0 = d.w = d.out = 16
+        d.a1 = 16 if c1 else None
+        d.c0, d.c1 = cin, c1
+        oh, ow = (hh + 2 - 3) // stride + 1, (ww + 2 - 3) // stride + 1
+        d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.stride, d.upsample = batch, hh, ww, oh, ow, stride, 0
+        d.M, d.N, d.K = batch * oh * ow, cout, 9 * (cin + c1)
+        d.ldc, d.out_scale, d.force_tile = cout, 1.0, force_tile
+        d.a_coef = a_coef
+        return d
+
+    def plan(d):
+        tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert h.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)) == 0, h.tg_last_error()
+        return tm.value, tn.value, sp.value, kk.value
+
+    # SD-1.5 ResnetBlock convs at CFG batch 16 (the bench): slab kernel on the 64 / 32-wide maps, split in two on the 16-wide maps
+    assert plan(conv(16, 64, 64, 320, 320)) == (128, 320, 1, 4)
+    assert plan(conv(16, 64, 64, 640, 320, c1=320)) == (128, 320, 1, 4)
+    assert plan(conv(16, 32, 32, 640, 640)) == (128, 320, 1, 4)
+    assert plan(conv(16, 16, 16, 1280, 1280)) == (128, 320, 2, 4)
+    d = conv(16, 16, 16, 1280, 1280)
+    assert h.tg_gemm_workspace_bytes(C.byref(d)) == 32 * 4 * 2 * 128 * 320 * 4
+    # CFG batch 2 (configs 1 / 4 / 5): 64 tiles do not fill 256 CUs -> the halo kernel; stride 2 -> implicit GEMM; N = 128 -> never
+    assert plan(conv(2, 64, 64, 320, 320))[3] == 2
+    assert plan(conv(16, 64, 64, 320, 320, stride=2))[3] == 1
+    assert plan(conv(16, 64, 64, 128, 128))[3] != 4
+    assert plan(conv(2, 64, 64, 320, 320, force_tile=11)) == (128, 320, 1, 4)
+    # the dev switch turns the slab kernel off
+    monkeypatch.setenv("TG_GEMM_FLAGS", "128")
+    assert plan(conv(16, 64, 64, 320, 320))[3] == 2
+    monkeypatch.delenv("TG_GEMM_FLAGS")
+    # GroupNorm prologue outside the slab kernel is refused before any launch
+    bad = conv(2, 8, 8, 128, 128, a_coef=16)
+    assert h.tg_gemm(C.byref(bad), None) != 0 and b"slab conv kernel" in h.tg_last_error()
+
+    def gemm(M, N, K, force_tile=0, geglu=0):
+        d = _lib.GemmDesc()
+        d.dtype, d.mode = 0, 0
+        d.a0 = d.w = d.out = 16
+        d.c0 = K
+        d.M, d.N, d.K = M, N, K
+        d.ldc, d.out_scale, d.force_tile, d.geglu = (N // 2 if geglu else N), 1.0, force_tile, geglu
+        return d
+    assert plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(65536, 320, 320))[3] == 0
+    assert plan(gemm(65536, 2560, 320, geglu=1)) == (256, 256, 1, 3)          # fused GEGLU FF1 on the big tile
+    assert plan(gemm(16384, 640, 2560))[3] == 0                              # loader / compute GEMM: not selected by default
+    assert plan(gemm(16384, 640, 2560, force_tile=13)) == (128, 320, 1, 5)
+    assert plan(gemm(4096, 1280, 5120, force_tile=14)) == (128, 320, 2, 5)
+    monkeypatch.setenv("TG_GEMM_FLAGS", "256")
+    assert plan(gemm(16384, 640, 2560)) == (128, 320, 1, 5) and plan(gemm(4096, 1280, 5120)) == (128, 320, 2, 5)

@@ -696,8 +696,13 @@ inline int lc_splits_of(const tg_gemm_desc* d) {
   if (d->N % 320 != 0 || d->K % BK != 0 || d->M % 128 != 0 || d->force_split_k > 1) return 0;
   if (d->force_tile == 13) return 1;
   if (d->force_tile == 14) return d->K / BK >= 2 ? 2 : 0;
-  if (d->force_tile != 0 || d->K < 1024) return 0;
-  { const char* e = getenv("TG_GEMM_FLAGS"); if (!e || !(strtol(e, nullptr, 0) & 256)) return 0; }
+  if (d->force_tile != 0) return 0;
+  {
+    const char* e = getenv("TG_GEMM_FLAGS");
+    const long f = e ? strtol(e, nullptr, 0) : 0;
+    if (!(f & 256)) return 0;
+    if (d->K < ((f & 512) ? 256 : 1024)) return 0;        // dev bit 9: short-K GEMMs too (A/B experiment)
+  }
   const long t = (d->M / 128) * (d->N / 320);
   auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
   if (full(t)) return 1;
