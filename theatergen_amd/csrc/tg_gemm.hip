@@ -22,8 +22,9 @@
 namespace {
 
 struct TileCfg { int bm, bn, bk; };
-const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}};
-constexpr int kNumTiles = 6;  // id 4 = 128x128 with 3 stages (forced only);
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}, {128, 128, 32}};
+constexpr int kNumTiles = 7;  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
+// workgroups per CU instead of two; forced / dev switch: see make_plan)
 // id 5 = 256x256, 8 waves of 128x64, fragments read per k-step (230 VGPRs): +11..22 % over 128x128 on large plain GEMMs
 // (8192x4096x4096 929 vs 839 TF, 16384x5120x2560 1001 vs 818) but no gain at the SD-1.5 UNet's K = 320..1280 with the GEGLU
 // epilogue (scripts/dev_big_tile.py), so it is forced-only for now
@@ -574,6 +575,16 @@ Plan make_plan(const tg_gemm_desc* d) {
     // few 128x128 tiles (the 8x8 level, M = 1024): 64x64 tiles put 4x as many blocks on the chip (3 per CU):
     // 1024x1280x1280 22 -> 13 us, K = 5120 69 -> 39 us (scripts/dev_tile_sweep.py)
     else if (d->mode == 0 && !d->geglu && ((M + 127) / 128) * ((N + 127) / 128) <= 128) t = 1;
+    // dev A/B (TG_GEMM_FLAGS bit 14): short-K plain GEMMs on the 32-wide K stages (three co-resident workgroups per CU)
+    // short-K plain GEMMs (K <= 640: the 64x64 / 32x32 levels' attention and proj_in / proj_out projections) take the 128x128 tile
+    // on three 32-wide K stages: 48 KB of LDS = THREE co-resident workgroups per CU instead of two, more prologue / epilogue
+    // latency of one block under another's K loop.  Same K order: bit-identical results.  Graph-replay A/B, three interleaved rounds
+    // (scripts/dev_env_ab.sh TG_T7_MAXK "0 640 1280 5120"): 8.328 -> 8.350 images/s at 640 (+0.27 %), 8.302 at 1280, 8.299 at 5120.
+    {
+      const char* mk = getenv("TG_T7_MAXK");           // dev knob
+      const long maxk = mk ? strtol(mk, nullptr, 0) : 640;
+      if (t == 0 && d->mode == 0 && !d->geglu && K <= maxk && K % 32 == 0) t = 6;
+    }
     if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
@@ -592,7 +603,7 @@ Plan make_plan(const tg_gemm_desc* d) {
   // convs (~6 ways: 204 -> 91 us), the K >= 11520 halo convs of the 32x32 / 16x16 levels (-16 .. -20 %) and the
   // longest-K 8x8 projections; every other layer measured faster unsplit (partials cost more than the idle CUs).
   long S = 512;
-  if (!halo && t == 1) S = 768;
+  if (!halo && (t == 1 || t == 6)) S = 768;
   if (!halo && (t == 4 || t == 5)) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
@@ -825,6 +836,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 2: return launch_cfg2<T, 128, 64, 4, 1, 3>(d, p, pl, st);
     case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
     case 4: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
+    case 6: return launch_cfg2<T, 128, 128, 2, 2, 3, 32>(d, p, pl, st);   // three 16 KB K stages: 3 blocks / CU
     default: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);   // 8 waves of 128x64, 128 KB, 1 block / CU
   }
 }
