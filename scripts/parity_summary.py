@@ -13,8 +13,8 @@ for r in recs:                       # the log is appended across runs: keep the
     last[(r["what"], r.get("dtype", ""))] = r
 recs = list(last.values())
 out = {"source": "tests/parity_metrics.py log of `pytest -m gpu` on MI355X" + (" (" + note + ")" if note else "")}
-for key, tag in (("single_kernel_bf16", "bfloat16"), ("single_kernel_fp16", "float16")):
-    ks = [r for r in recs if r["what"].startswith("kernel:") and tag in r.get("dtype", "")]
+for key, tag in (("single_kernel_bf16", ".bfloat16"), ("single_kernel_fp16", ".float16")):
+    ks = [r for r in recs if r["what"].startswith("kernel:") and r.get("dtype", "").endswith(tag)]
     if ks:
         out[key] = {"n": len(ks), "worst_rel_l2": max(r["rel_l2"] for r in ks), "worst_max_rel": max(r["max_rel"] for r in ks)}
 out["comparisons"] = [{k: r[k] for k in ("what", "rel_l2", "max_rel", "l2_tol", "max_tol") if k in r}
