@@ -233,8 +233,8 @@ def bench_sd21_editing(args):
     """BASELINE.json configs[3]: SD-2.1 plan 768x768 (latent 96x96, v-prediction, ctx 1024, 20 heads x 64 on the guidance
     layers), ONE edited image with 4 character boxes: per DDIM step the CFG UNet call with the attention-map side channel on
     the 4 guidance keys (cond half), compute_ca_lossv3 over the 4 boxes with its analytic d loss / d A (HIP reductions), and
-    the fused CFG + DDIM + frozen-mask replace epilogue fed by the 4-object composed latents.  Eager launches (the capture
-    side channel fills a host dict and the guidance table is built on the host per call).  NOT the north-star line."""
+    the fused CFG + DDIM + frozen-mask replace epilogue fed by the 4-object composed latents.  The UNet call (with the capture
+    side channel) replays from a hipGraph; the guidance table is built on the host per call.  NOT the north-star line."""
     from theatergen_amd import guidance as G
     from theatergen_amd import latents as L
     from theatergen_amd import ops, story
@@ -279,14 +279,42 @@ def bench_sd21_editing(args):
     parts = {"unet": 0.0, "guidance": 0.0, "epilogue": 0.0}
     map_bytes = 0
 
+    # The CFG UNet call with its attention-map side channel is captured in a hipGraph (static buffers: model_in, the device-side
+    # schedule, the saved maps live in the graph's pool); the guidance losses (host-built item table) and the step epilogue stay
+    # eager launches.  Falls back to eager launches if the capture is refused.
+    saved = {}
+    kw = {"save_attn_to_dict": saved, "save_keys": keys, "return_cond_ca_only": True}
+    out = {}
+
+    def unet_call():
+        out["np"] = unet(model_in, dsch, enc, cross_attention_kwargs=kw, return_dict=False, out_dtype=torch.float32)[0]
+    graph = None
+    with torch.no_grad():
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                unet_call()                                   # warm-up: allocator, packed weights, K / V^T caches
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                unet_call()
+            graph = gr
+        except Exception as e:                                # noqa: BLE001 - any capture failure means eager launches
+            sys.stderr.write(f"[bench sd21] hipGraph capture of the UNet call refused ({type(e).__name__}: {e}); eager launches\n")
+            torch.cuda.synchronize()
+            saved.clear()
+
     def one_step(timed):
         nonlocal map_bytes
-        saved = {}
-        kw = {"save_attn_to_dict": saved, "save_keys": keys, "return_cond_ca_only": True}
-        out = {}
 
         def f_unet():
-            out["np"] = unet(model_in, dsch, enc, cross_attention_kwargs=kw, return_dict=False, out_dtype=torch.float32)[0]
+            if graph is not None:
+                graph.replay()
+            else:
+                saved.clear()
+                unet_call()
 
         def f_guid():
             out["loss"], out["grads"] = G.compute_ca_lossv3(saved, boxes, positions, keys, return_grads=True,
@@ -351,7 +379,8 @@ def bench_sd21_editing(args):
         "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[3]: SD-2.1 plan 768x768, 1 image x 4 character boxes, {steps} DDIM steps (v-prediction), "
                                "CFG 7.5, IP 77+4 tokens; per step: CFG-batch-2 UNet with attention capture on 4 keys (12x12 / 24x24 x 20 heads "
-                               "x 77 tokens), compute_ca_lossv3 + d loss / d A over 4 boxes, CFG + DDIM + frozen-mask replace; eager launches",
+                               "x 77 tokens), compute_ca_lossv3 + d loss / d A over 4 boxes, CFG + DDIM + frozen-mask replace; UNet call "
+                               + ("replayed from a hipGraph" if graph is not None else "as eager launches") + ", guidance + epilogue eager",
                    "plan": "sd21", "ddim_steps": steps, "boxes": 4},
         "images_per_s": round(1.0 / (ms_step * 1e-3 * steps), 4),
         "per_step_ms": {k: round(v / 5, 3) for k, v in parts.items()}, "compose_align_ms_once": round(compose_ms, 2),
