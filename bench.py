@@ -212,7 +212,7 @@ def dry_launch(args, D, rank, world):
     ok = worst == float(n) and got.shape[0] == 2 * n and [float(v) for v in got[::2, 0]] == [float(r) for r in range(n)]
     if rank == 0:
         print(json.dumps({"dry": True, "n_gpus": n, "collectives_ok": bool(ok)}), flush=True)
-    if D.is_dist():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if not ok:
         raise SystemExit(1)
@@ -610,7 +610,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps, args.cpu_loop_steps)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if D.is_dist():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -41,6 +41,9 @@ extern "C" {
 #define TG_ACT_GELU 2        /* exact (erf) GELU */
 #define TG_ACT_QUICK_GELU 3  /* x * sigmoid(1.702 x): OpenAI CLIP's activation (text / image encoders) */
 
+/* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
+ * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
+#define TG_ABI_VERSION 300
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -153,6 +156,9 @@ typedef struct {
   float w1;
   void* out; int64_t out_ld, out_bs;
   int32_t causal;   /* 1: key j is visible to query i only if j <= i (segment 0; the CLIP text encoder's mask) */
+  const float* w1_dev;  /* non-NULL: segment 1's weight is READ FROM THE DEVICE at run time (one fp32) and `w1` is ignored — the IP scale that
+                         * IPAdapter.set_scale mutates per character and ip_adapter/custom_pipelines.py:328-333 gates per step: a captured
+                         * hipGraph of the step replays with the current value */
 } tg_attn_desc;
 
 int tg_attention(const tg_attn_desc* d, void* stream);

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     h = _lib.lib()          # binds every symbol: AttributeError if one is missing
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.tg_version() >= 100
+    assert h.tg_version() == _lib.ABI_VERSION
     assert h.tg_last_error() is not None
 
 

@@ -46,7 +46,7 @@ def rnd(shape, dtype, g, scale=1.0):
 
 def test_library_loads_and_reports_version():
     from theatergen_amd import _lib
-    assert _lib.lib().tg_version() >= 100
+    assert _lib.lib().tg_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -254,12 +254,32 @@ class IPAttnProcessor(nn.Module):
         super().__init__()
         self.hidden_size = hidden_size
         self.cross_attention_dim = cross_attention_dim
+        self._scale_dev = None          # fp32 [1] on the compute device: what the kernel reads (see the ``scale`` property)
         self.scale = scale
         self.num_tokens = num_tokens
         self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self._packed = None
         self._kv = StaticSlots()
+
+    # ``scale`` stays the plain mutable attribute of the reference (``IPAdapter.set_scale`` assigns it per character,
+    # ip_adapter/ip_adapter.py:155-158; ``custom_pipelines.py:328-333`` toggles 0.0 <-> s per step), but the value the attention
+    # kernel multiplies with lives in a DEVICE scalar: an assignment refreshes that scalar (one 4-byte fill on the current
+    # stream), so a hipGraph captured with one scale replays with the next one — no re-capture, no host sync.
+    @property
+    def scale(self):
+        return self._scale
+
+    @scale.setter
+    def scale(self, value):
+        self._scale = value
+        if self._scale_dev is not None:
+            self._scale_dev.fill_(float(value))
+
+    def scale_device(self, device):
+        if self._scale_dev is None or self._scale_dev.device != device:
+            self._scale_dev = torch.full((1,), float(self._scale), dtype=torch.float32, device=device)
+        return self._scale_dev
 
     def _ip_weight(self):
         ws = (self.to_k_ip.weight, self.to_v_ip.weight)
@@ -338,7 +358,7 @@ class IPAttnProcessor(nn.Module):
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
         ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
                       o, inner, N * inner, k1=kip, k1_ld=inner, k1_bs=T * inner, vt1=vtip, vt1_ld=ldi, vt1_bs=inner * ldi,
-                      len1=T, w1=float(self.scale))
+                      len1=T, w1=float(self.scale), w1_dev=self.scale_device(x.device))
         out = _finish(attn, o, B, N, C, shape4, x, _fused_residual)
         if return_attntion_probs or save_attn_to_dict is not None:
             probs = _save_probs(attn, q, inner, k, inner, B, N, L, save_attn_to_dict, save_keys, attn_key,

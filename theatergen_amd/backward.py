@@ -336,7 +336,13 @@ class UNetInputGrad:
         missing = set(want_keys) - set(saved.keys())
         if missing:
             raise RuntimeError(f"guidance keys {sorted(missing)} do not name cross-attention layers of this UNet")
+        # plain ``AttnProcessor`` on attn2 mirrors the reference's offload quirk (maps after the first are ``.cpu()`` tensors,
+        # attention_processor.py:386-389); the loss kernels and the softmax backward read DEVICE memory: bring every map back
+        saved = {k: (v if v.is_cuda else v.to(sample.device)) for k, v in saved.items()}
         loss, grads = loss_fn(saved)
+        for k, gk in grads.items():
+            if not gk.is_cuda:
+                raise RuntimeError(f"latent_backward_guidance: d loss / d map for key {k} is not a device tensor")
         state["loss_grads"] = {tuple(k): g for k, g in grads.items()}
         grad = tape.backward(sample_c)
         if grad is None:
@@ -362,6 +368,7 @@ def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, b
         max_iter = max_iter[index] if len(max_iter) > index else max_iter[-1]
     engine = UNetInputGrad(unet)
     lat32 = latents.detach().to(torch.float32).contiguous()
+    cond_embeddings = unet.register_conditioning(cond_embeddings)      # K / V^T of the conditioning projected once, not per iteration
 
     def loss_fn(saved):
         return G.compute_ca_lossv3(saved_attn=saved, bboxes=bboxes, object_positions=object_positions, guidance_attn_keys=keys,

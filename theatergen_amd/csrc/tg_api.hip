@@ -16,7 +16,7 @@ void tg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tg_last_error(void) { return g_err; }
-extern "C" int tg_version(void) { return 100; }
+extern "C" int tg_version(void) { return TG_ABI_VERSION; }
 
 template <typename T>
 __global__ void debug_mfma32_kernel(const typename Vec<T>::v8* a, const typename Vec<T>::v8* b, f32x16* d) {

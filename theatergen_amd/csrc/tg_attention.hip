@@ -48,6 +48,7 @@ struct AttnParams {
   int len1;
   float scale_log2;
   float w1;
+  const float* w1_dev;
   void* out; long out_ld, out_bs;
   int causal;
 };
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
         ps += e;
       }
     const float l1 = ps + __shfl_xor(ps, 32, 64);
-    const float f = p.w1 / l1;
+    const float f = (p.w1_dev != nullptr ? *p.w1_dev : p.w1) / l1;      // device scalar: the IP scale may change between replays of a captured graph
 #pragma unroll
     for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
@@ -500,6 +501,7 @@ extern "C" int tg_attention(const tg_attn_desc* d, void* stream) {
   p.k1 = d->k1; p.k1_ld = d->k1_ld; p.k1_bs = d->k1_bs; p.vt1 = d->vt1; p.vt1_ld = d->vt1_ld; p.vt1_bs = d->vt1_bs; p.len1 = d->len1;
   p.scale_log2 = d->scale * 1.4426950408889634f;
   p.w1 = d->w1;
+  p.w1_dev = d->w1_dev;
   p.out = d->out; p.out_ld = d->out_ld; p.out_bs = d->out_bs;
   p.causal = d->causal;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -22,7 +22,10 @@ def env_world():
 def init(backend=None, device=None):
     """Initialise the process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    # a torchrun environment (RANK set) gets its process group even at world size 1: the N = 1 leg of a scaling run then goes
+    # through the same RCCL initialisation (library load, ``device_id`` binding) as N > 1; the collectives below are no-ops there
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -34,8 +37,10 @@ def init(backend=None, device=None):
     return rank, world, local
 
 
-def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def is_dist(force=False):
+    """True when collectives have to run: a process group of more than one rank — or, with ``force``, any initialised group
+    (the world-size-1 RCCL test exercises the real library calls on one GPU)."""
+    return dist.is_available() and dist.is_initialized() and (force or dist.get_world_size() > 1)
 
 
 def shard(items, rank, world):
@@ -43,17 +48,17 @@ def shard(items, rank, world):
     return [it for i, it in enumerate(items) if i % world == rank]
 
 
-def broadcast_conditioning(tensors, src=0):
+def broadcast_conditioning(tensors, src=0, force=False):
     """In-place broadcast of a dict of tensors (shared text / image embeddings) from ``src``."""
-    if is_dist():
+    if is_dist(force):
         for k in sorted(tensors):
             dist.broadcast(tensors[k], src=src)
     return tensors
 
 
-def gather_latents(local):
+def gather_latents(local, force=False):
     """all_gather of per-rank final latents [n_local, C, h, w] -> [world * n_local, C, h, w] (rank-major)."""
-    if not is_dist():
+    if not is_dist(force):
         return local
     world = dist.get_world_size()
     local = local.contiguous()
@@ -66,13 +71,13 @@ def gather_latents(local):
     return out
 
 
-def barrier():
-    if is_dist():
+def barrier(force=False):
+    if is_dist(force):
         dist.barrier()
 
 
-def max_over_ranks(value, device):
-    if not is_dist():
+def max_over_ranks(value, device, force=False):
+    if not is_dist(force):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -184,7 +184,8 @@ def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, ups
 
 
 def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch, heads, head_dim, n_q, scale,
-              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0, causal=False):
+              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0, causal=False, w1_dev=None):
+    """``w1_dev``: fp32 device scalar read by the kernel instead of the launch constant ``w1`` (graph-replayable IP scale)"""
     _need_cuda(q)
     d = AttnDesc()
     d.dtype = _dt(q)
@@ -199,6 +200,10 @@ def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch,
     d.scale, d.w1 = float(scale), float(w1)
     d.out, d.out_ld, d.out_bs = _ptr(out), int(out_ld), int(out_bs)
     d.causal = 1 if causal else 0
+    if w1_dev is not None:
+        if w1_dev.dtype != torch.float32 or not w1_dev.is_cuda:
+            raise RuntimeError("attention: w1_dev must be an fp32 device tensor")
+        d.w1_dev = w1_dev.data_ptr()
     _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
     return out
 
@@ -406,6 +411,9 @@ def masked_compose_(dst, src, mask):
 
 
 def guidance_topk(attn, token, mask, k_fg, k_bg, fg_w, bg_w, scale, out, grad=None):
+    for t in (attn, mask, out, grad):
+        if t is not None:
+            _need_cuda(t)
     heads, hw, n_tok = attn.shape
     _lib.check(_lib.lib().tg_guidance_topk(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), int(k_fg), int(k_bg),
                                            float(fg_w), float(bg_w), float(scale), _ptr(out), _ptr(grad), _stream()))
@@ -413,6 +421,9 @@ def guidance_topk(attn, token, mask, k_fg, k_bg, fg_w, bg_w, scale, out, grad=No
 
 def guidance_ref(attn, token, ref, mask, eps, scale, out, grad=None):
     """attn fp32 [heads, hw, tokens]; ref fp32 [heads, hw] contiguous"""
+    for t in (attn, ref, mask, out, grad):
+        if t is not None:
+            _need_cuda(t)
     heads, hw, n_tok = attn.shape
     if ref.dtype != torch.float32 or ref.numel() != heads * hw or not ref.is_contiguous():
         raise RuntimeError("guidance_ref: ref must be a contiguous fp32 [heads, hw] column")
@@ -421,6 +432,9 @@ def guidance_ref(attn, token, ref, mask, eps, scale, out, grad=None):
 
 
 def guidance_ratio(attn, token, mask, scale, out, grad=None):
+    for t in (attn, mask, out, grad):
+        if t is not None:
+            _need_cuda(t)
     heads, hw, n_tok = attn.shape
     _lib.check(_lib.lib().tg_guidance_ratio(_ptr(attn), heads, hw, n_tok, int(token), _ptr(mask), float(scale), _ptr(out),
                                             _ptr(grad), _stream()))
@@ -476,7 +490,10 @@ def sumpool2x2(du, batch, h, w):
 class GuidanceBatch:
     """Collects the terms of one ``compute_ca_lossv3`` call (one per attention map x object x token position) and evaluates
     them with ONE ``tg_guidance_batch`` launch + an in-order fold instead of one dependent launch each.  Terms whose
-    gradient columns would collide (same grad tensor and token in one call) are split over consecutive launches."""
+    gradient columns would collide (same grad tensor and token in one call: two objects sharing a token position, or a
+    reference-attention term next to the box term of the same key and token) are deferred to a following launch, so the
+    order of additions into the loss is LAUNCH-MAJOR, item order within each launch — fixed and deterministic for a given
+    call, identical to the per-term launches whenever no column collides (the shipped flow), one fp32 re-association otherwise."""
     KIND_TOPK, KIND_RATIO, KIND_REF = 0, 1, 2
 
     def __init__(self, device):
@@ -485,6 +502,11 @@ class GuidanceBatch:
 
     def add(self, kind, attn, token, mask, scale, grad=None, ref=None, k_fg=0, k_bg=0, fg_w=0.0, bg_w=0.0, eps=0.0):
         heads, hw, n_tok = attn.shape
+        for t in (attn, grad, mask, ref):             # raw device pointers go into the item table: a host tensor would fault the GPU
+            if t is not None:
+                _need_cuda(t)
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise RuntimeError("guidance: attention maps, gradients, masks and reference columns must be contiguous fp32")
         if not (0 <= int(token) < n_tok):
             raise RuntimeError(f"guidance: token position {token} outside the {n_tok} text tokens")
         if kind == self.KIND_TOPK and not (1 <= k_fg <= hw and 1 <= k_bg <= hw):
@@ -516,6 +538,8 @@ class GuidanceBatch:
             max_hw = max([it.hw for it in now if it.kind == self.KIND_TOPK] + [0])
             _lib.check(_lib.lib().tg_guidance_batch(table.data_ptr(), len(now), max_hw, max(it.heads for it in now),
                                                     partials.data_ptr(), _ptr(loss), _stream()))
-            self.keep += [table, partials]
             items = later
+        # nothing is pinned beyond the last launch: every tensor above is used on the current stream only, and the caching
+        # allocator hands a freed block back to that same stream (stream-ordered reuse), so dropping the references is safe
+        self.keep = []
         return loss

@@ -120,10 +120,7 @@ class DenoiseEngine:
         self.controlnet.cond_embedding(self.cn_cond, static=True)
 
     def _refresh_kv(self):
-        from .attention_processor import Attention, IPAttnProcessor
-        for m in self.unet.modules():
-            if isinstance(m, Attention) and isinstance(m.processor, IPAttnProcessor):
-                m.processor.register_static(m, self.enc)       # cache keyed by the tensor OBJECT self.enc (never its address)
+        self.unet.register_conditioning(self.enc)              # cache keyed by the tensor OBJECT self.enc (never its address)
 
     def set_frozen(self, frozen_latents, frozen_mask, frozen_steps):
         """Stage-2 frozen-mask replace (reference pipelines.py:733-738, 833-834): ``frozen_latents`` fp32
@@ -162,11 +159,11 @@ class DenoiseEngine:
                           model_in=self.model_in)
 
     def _signature(self):
-        """Launch constants baked into a captured graph: the IP scales (IPAdapter.set_scale mutates them between
-        characters, reference pipelines.py:196, 213) and the frozen-mask configuration."""
-        from .attention_processor import IPAttnProcessor
-        scales = tuple(float(p.scale) for p in self.unet.attn_processors.values() if isinstance(p, IPAttnProcessor))
-        return scales, self.frozen is not None, self.frozen_steps, self.g
+        """Launch constants baked into a captured graph: the frozen-mask configuration and the guidance scale.  The IP scales
+        are NOT among them: ``IPAttnProcessor.scale`` is read from a device scalar by the attention kernel, so
+        ``IPAdapter.set_scale`` between characters (reference pipelines.py:196, 213) and the per-step gating of
+        ``ip_adapter/custom_pipelines.py:328-333`` replay the same graph."""
+        return self.frozen is not None, self.frozen_steps, self.g
 
     def _reset(self, latents):
         self.latents.copy_(latents.to(device=self.dev, dtype=torch.float32))
@@ -225,12 +222,17 @@ class DenoiseEngine:
             self._own_stream = torch.cuda.Stream(device=self.dev)
         return self._own_stream
 
-    def run(self, latents):
-        """latents [n_img, C, h, w] (any float dtype / device) -> latents_all fp32 [steps+1, n_img, C, h, w] on the GPU."""
+    def run(self, latents, before_step=None):
+        """latents [n_img, C, h, w] (any float dtype / device) -> latents_all fp32 [steps+1, n_img, C, h, w] on the GPU.
+        ``before_step(i)`` (optional) runs on the host before step i is launched — the place of the per-step
+        ``set_scale(0.0)`` / ``set_scale(s)`` gating of reference ``ip_adapter/custom_pipelines.py:328-333``; the IP scale is a
+        device scalar, so the same captured graph replays whatever it is set to."""
         with torch.no_grad():
             self._ensure_graph(latents)
             self._reset(latents)
-            for _ in range(self.steps):
+            for i in range(self.steps):
+                if before_step is not None:
+                    before_step(i)
                 if self.use_graph:
                     self.graph.replay()
                 else:

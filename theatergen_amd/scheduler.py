@@ -96,7 +96,12 @@ class DDIMScheduler:
     def add_noise(self, original_samples, noise, timesteps):
         """diffusers ``add_noise``: ``sqrt(a_t) x0 + sqrt(1 - a_t) noise`` broadcast over a vector of timesteps, as the
         stage-2 path calls it with ALL 50 timesteps at once (reference models/pipelines.py:629-631: [1, C, h, w] latents
-        -> [50, C, h, w]).  One ``tg_add_noise`` launch on the device; result in the dtype of ``original_samples``."""
+        -> [50, C, h, w]).  One ``tg_add_noise`` launch on the device; result in the dtype of ``original_samples``.
+
+        Deliberate deviation: diffusers 0.21.4 casts ``alphas_cumprod`` to the sample dtype and rounds both products
+        and their sum in half precision; here the two products and the sum are formed in fp32 and rounded ONCE to the sample
+        dtype — at most one storage-dtype ulp away from the reference, closer to the exact value (the oracle,
+        ``oracle/ddim.py::add_noise``, is fp32 as well; parity tests state 1 ulp / rel 2^-8 bf16, 2^-11 fp16 for this op)."""
         ts = torch.as_tensor(timesteps).reshape(-1).to("cpu", torch.long)
         ca, cb = self.add_noise_coeffs(ts)
         dev = original_samples.device

@@ -397,6 +397,22 @@ class UNet2DConditionModel(nn.Module):
     def set_default_attn_processor(self):
         self.set_attn_processor(AttnProcessor())
 
+    def register_conditioning(self, encoder_hidden_states):
+        """Opt-in cache for EAGER loops (``for t in timesteps: unet(x, t, enc)`` — the reference's loop shape, also the forward
+        of ``latent_backward_guidance``): project the step-invariant text / image K and V^T of ``encoder_hidden_states`` for
+        every IP cross-attention layer once, into buffers owned by that tensor OBJECT; calls that pass the same tensor reuse
+        them (and re-project if its ``_version`` or the weights changed).  Without this an unregistered tensor is projected
+        on every call (safe default: identity by address would alias a fresh ``torch.cat`` at a recycled address).
+        ``DenoiseEngine.set_conditioning`` does the same for its static buffer.  Returns the tensor (in ``unet.dtype``,
+        contiguous: pass THIS object to the calls)."""
+        enc = encoder_hidden_states
+        if enc.dtype != self.dtype or not enc.is_contiguous():
+            enc = enc.to(self.dtype).contiguous()
+        for m in self.modules():
+            if isinstance(m, Attention) and isinstance(m.processor, IPAttnProcessor):
+                m.processor.register_static(m, enc)
+        return enc
+
     # ---- forward --------------------------------------------------------------------------------------
     def _timestep_dev(self, timestep, B):
         """-> (device fp32 tensor, stride) for the embedding kernel; Python numbers are cached per value."""
