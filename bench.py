@@ -55,6 +55,8 @@ def parse():
                          "guidance); sdxl = configs[4] (1024px, IP-Adapter-Plus, use --dtype fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short configs[3] (SD-2.1 768px editing step) / configs[4] (SDXL 1024px) legs of the default line")
     ap.add_argument("--cpu-calls", type=int, default=3)
     ap.add_argument("--cpu-loop-steps", type=int, default=0,
                     help="also run BASELINE.json configs[0] as an actual loop on the CPU oracle: SD-1.5 512x512, ONE character box, this "
@@ -83,6 +85,30 @@ def build_model(plan, dtype, device, num_tokens=4, scale=0.4):
     adapter = IPAdapter(SDPipe(unet), None, None, device, num_tokens=num_tokens)
     adapter.set_scale(scale)
     return cfg, sd, unet, adapter
+
+
+def gemm_by_kernel(step_fn):
+    """One eager invocation of ``step_fn`` with HIP events around every GEMM / conv launch (ops.gemm profiling mode) ->
+    ({kernel label: {launches, ms, tflops}}, total ms of those launches, total algorithmic flop).  The per-plan ``roofline.by_kernel`` block."""
+    from theatergen_amd import ops
+    with torch.no_grad():
+        step_fn()                                        # warm (eager): allocator, packed weights
+        torch.cuda.synchronize()
+        ops.gemm_profile_start()
+        step_fn()
+        torch.cuda.synchronize()
+        recs = ops.gemm_profile_stop()
+    by = {}
+    for r in recs:
+        k = by.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0))
+        k["launches"] += 1
+        k["ms"] += r["ms"]
+        k["flops"] += r["flops"]
+    tot_ms = sum(v["ms"] for v in by.values())
+    tot_fl = sum(v["flops"] for v in by.values())
+    table = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+             for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
+    return table, tot_ms, tot_fl
 
 
 def roofline_leg(unet, engine):
@@ -288,18 +314,29 @@ def bench_sd21_editing(args):
 
     def unet_call():
         out["np"] = unet(model_in, dsch, enc, cross_attention_kwargs=kw, return_dict=False, out_dtype=torch.float32)[0]
+
+    def guid_call():
+        out["loss"], out["grads"] = G.compute_ca_lossv3(saved, boxes, positions, keys, return_grads=True,
+                                                        use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+
+    def epi_call():
+        ops.step_epilogue(out["np"], latents, 7.5, coef, step_idx, advance=True, prediction_type=1, frozen=composed,
+                          frozen_mask=frozen_mask, frozen_steps=steps, history=None, model_in=model_in)
+
+    def full_step():
+        unet_call(); guid_call(); epi_call()
     graph = None
     with torch.no_grad():
         try:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
-                unet_call()                                   # warm-up: allocator, packed weights, K / V^T caches
+                full_step()                                   # warm-up: allocator, packed weights, K / V^T caches, guidance item table + masks
             torch.cuda.current_stream(device).wait_stream(side)
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                unet_call()
+                full_step()                                   # round 3: the WHOLE step (UNet + capture, guidance losses + d loss / d A, epilogue)
             graph = gr
         except Exception as e:                                # noqa: BLE001 - any capture failure means eager launches
             sys.stderr.write(f"[bench sd21] hipGraph capture of the UNet call refused ({type(e).__name__}: {e}); eager launches\n")
@@ -308,28 +345,17 @@ def bench_sd21_editing(args):
 
     def one_step(timed):
         nonlocal map_bytes
-
-        def f_unet():
-            if graph is not None:
-                graph.replay()
-            else:
-                saved.clear()
-                unet_call()
-
-        def f_guid():
-            out["loss"], out["grads"] = G.compute_ca_lossv3(saved, boxes, positions, keys, return_grads=True,
-                                                            use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
-
-        def f_epi():
-            ops.step_epilogue(out["np"], latents, 7.5, coef, step_idx, advance=True, prediction_type=1, frozen=composed,
-                              frozen_mask=frozen_mask, frozen_steps=steps, history=None, model_in=model_in)
-        if timed:
-            parts["unet"] += _ev_ms(f_unet)
-            parts["guidance"] += _ev_ms(f_guid)
-            parts["epilogue"] += _ev_ms(f_epi)
+        if timed:                                             # per-part times: eager launches, HIP events around each part
+            saved.clear()
+            parts["unet"] += _ev_ms(unet_call)
+            parts["guidance"] += _ev_ms(guid_call)
+            parts["epilogue"] += _ev_ms(epi_call)
             map_bytes = sum(2 * v.numel() * 4 for v in saved.values())       # maps read once, gradients written once
+        elif graph is not None:
+            graph.replay()
         else:
-            f_unet(); f_guid(); f_epi()
+            saved.clear()
+            full_step()
         return out
 
     with torch.no_grad():
@@ -369,6 +395,8 @@ def bench_sd21_editing(args):
         torch.cuda.synchronize()
         guide_ms = (time.perf_counter() - t1) / 3 * 1e3
     assert torch.isfinite(gg).all() and float(gg.abs().max()) > 0
+    saved.clear()
+    by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(unet_call)
     ms_step = elapsed / n_timed * 1e3
     unet_ms = parts["unet"] / 5
     ach = PLAN_FLOP_PER_CFG_CALL["sd21"] / (unet_ms * 1e-3) / 1e12
@@ -379,8 +407,8 @@ def bench_sd21_editing(args):
         "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[3]: SD-2.1 plan 768x768, 1 image x 4 character boxes, {steps} DDIM steps (v-prediction), "
                                "CFG 7.5, IP 77+4 tokens; per step: CFG-batch-2 UNet with attention capture on 4 keys (12x12 / 24x24 x 20 heads "
-                               "x 77 tokens), compute_ca_lossv3 + d loss / d A over 4 boxes, CFG + DDIM + frozen-mask replace; UNet call "
-                               + ("replayed from a hipGraph" if graph is not None else "as eager launches") + ", guidance + epilogue eager",
+                               "x 77 tokens), compute_ca_lossv3 + d loss / d A over 4 boxes, CFG + DDIM + frozen-mask replace; the whole step "
+                               + ("replayed from ONE hipGraph" if graph is not None else "as eager launches") + " (per_step_ms: eager parts, HIP events)",
                    "plan": "sd21", "ddim_steps": steps, "boxes": 4},
         "images_per_s": round(1.0 / (ms_step * 1e-3 * steps), 4),
         "per_step_ms": {k: round(v / 5, 3) for k, v in parts.items()}, "compose_align_ms_once": round(compose_ms, 2),
@@ -390,12 +418,15 @@ def bench_sd21_editing(args):
                                          "host wall time, eager; the reference runs up to 5 per step for the first 10 steps (dead code in its shipped flow)",
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": None, "kernel": "whole CFG-batch-2 UNet call incl. attention capture (4.30 TFLOP algorithmic, SURVEY 8(d))",
-                     "avg_launch_us": round(unet_ms * 1e3, 1)},
+                     "avg_launch_us": round(unet_ms * 1e3, 1),
+                     "all_gemm_kernels": {"achieved": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(gemm_ms, 3),
+                                          "note": "eager launches, HIP events per launch (event overhead ~2 us each)"},
+                     "by_kernel": by_kernel},
         "guidance": {"bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 5),
                      "bytes_per_step": map_bytes, "ms": round(parts["guidance"] / 5, 3),
                      "note": "4 maps x 20 heads x (144 | 576) x 77 fp32 read + gradients written; latency-bound (1.5 MB per step)"},
     }
-    print(json.dumps(result), flush=True)
+    return result
 
 
 def bench_sdxl(args):
@@ -438,6 +469,7 @@ def bench_sdxl(args):
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(hist[-1]).all()
     s_step = elapsed / (args.steps * steps)
+    by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(eng._step)
     ach = PLAN_FLOP_PER_CFG_CALL["sdxl"] / s_step / 1e12
     result = {
         "metric": "SDXL 1024px IP-Adapter-Plus: seconds per DDIM step (CFG batch 2)", "value": round(s_step, 5), "unit": "s/step",
@@ -453,9 +485,12 @@ def bench_sdxl(args):
                           "(ip_adapter.py:347-359): 2 x 5.13 GMAC",
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": None, "kernel": "whole CFG-batch-2 UNet step (13.56 TFLOP algorithmic, SURVEY 8(d)) incl. the step epilogue",
-                     "avg_launch_us": round(s_step * 1e6, 1)},
+                     "avg_launch_us": round(s_step * 1e6, 1),
+                     "all_gemm_kernels": {"achieved": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(gemm_ms, 3),
+                                          "note": "eager launches, HIP events per launch (event overhead ~2 us each)"},
+                     "by_kernel": by_kernel},
     }
-    print(json.dumps(result), flush=True)
+    return result
 
 
 def main():
@@ -467,7 +502,8 @@ def main():
         if args.gpus != 1:
             raise SystemExit("bench.py: --plan sd21 / sdxl are single-GPU lines")
         torch.cuda.set_device(0)
-        return bench_sd21_editing(args) if args.plan == "sd21" else bench_sdxl(args)
+        print(json.dumps(bench_sd21_editing(args) if args.plan == "sd21" else bench_sdxl(args)), flush=True)
+        return
     rank, world, local = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -608,10 +644,41 @@ def main():
             result["roofline"] = roofline_leg(unet, engine)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps, args.cpu_loop_steps)
+    if rank == 0 and world == 1 and not args.stage2 and not args.with_vae and not args.no_other_configs:
+        # BASELINE.json configs[3] / configs[4], short runs of the same code as --plan sd21 / --plan sdxl, folded into THIS line
+        # so that the driver's one bench call records them (they are parity-test configurations, not the metric)
+        del engines, engine, unet, adapter, prepared
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        result["other_configs"] = other_configs_leg(args)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def other_configs_leg(args):
+    import copy
+    import gc
+    out = {}
+    for key, plan, dtype, fn in (("configs[3] sd21 768px editing step", "sd21", "bf16", bench_sd21_editing),
+                                 ("configs[4] sdxl 1024px ip-adapter-plus", "sdxl", "fp16", bench_sdxl)):
+        a = copy.copy(args)
+        a.plan, a.dtype, a.steps, a.warmup, a.ddim_steps = plan, dtype, 1, 1, (10 if plan == "sd21" else 6)
+        try:
+            r = fn(a)
+            keep = ("metric", "value", "unit", "dtype", "images_per_s", "per_step_ms", "latent_backward_guidance_iteration_ms",
+                    "resampler_us_per_character", "guidance")
+            c = {k: r[k] for k in keep if k in r}
+            c["workload"] = r["config"]["workload"]
+            c["roofline"] = r["roofline"]
+            out[key] = c
+        except Exception as e:                                # noqa: BLE001 - a failure here must not cost the headline line
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

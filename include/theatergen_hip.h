@@ -120,13 +120,25 @@ typedef struct {
    * problem is not one the slab kernel takes (ask tg_gemm_plan first). */
   int32_t a_silu;        /* 1: act = SiLU, 0: identity */
   const void* a_coef;
+  /* mode 0, one A source, K = the LayerNorm width, linear or GEGLU epilogue without residual / per-batch vector (tg_gemm_plan
+   * kernel_kind 6): LayerNorm(K, ln_eps) of every A ROW folded into the GEMM — BasicTransformerBlock's norm1 -> attn1 q|k|v,
+   * norm2 -> attn2.to_q, norm3 -> ff.net.0.proj (models/attention.py:186-236) without the normalised tensor or a layernorm launch:
+   *     out[m, n] = epilogue( rstd[m] * (sum_k A[m, k] W'[n, k] - mean[m] * ln_u[n]) + ln_v[n] )
+   * with W' = W * gamma (the caller packs it in the storage dtype and passes it as `w`), ln_u[n] = sum_k W'[n, k] over the PACKED
+   * (rounded) values, ln_v[n] = sum_k beta[k] W[n, k] + bias[n]; fp32 [N], 16-byte aligned; `bias` must be NULL (it lives in
+   * ln_v).  mean / rstd are taken inside the kernel from the A tiles it stages (biased variance over the stored values, as
+   * nn.LayerNorm).  NULL = plain GEMM. */
+  const float* ln_u;
+  const float* ln_v;
+  float ln_eps;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
 int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
 /* the tile (tokens x channels), the K-split of the tail tiles (1 = none) and the kernel (0 = GEMM, 1 = implicit-GEMM
  * conv, 2 = LDS-halo conv, 3 = big-tile persistent GEMM, 4 = slab conv (128 x 320 tiles, loader + compute waves, optional
- * GroupNorm prologue), 5 = loader / compute GEMM (128 x 320 tiles, long K)) the heuristic picks for a descriptor */
+ * GroupNorm prologue), 5 = loader / compute GEMM (128 x 320 tiles, long K), 6 = LayerNorm-fused projection (ln_u)) the heuristic
+ * picks for a descriptor */
 int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind);
 
 /* ---------------------------------------------------------------------------------------------
@@ -329,6 +341,23 @@ typedef struct {
 } tg_guidance_item;
 int tg_guidance_batch(const tg_guidance_item* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
                       float* partials, float* out, void* stream);
+
+/* Plan form of tg_guidance_batch (round 3; utils/guidance.py:244-286 per denoising step): the item table refers to the call's
+ * tensors by SLOT INDEX; the slot pointers (device memory: attention maps, gradient tensors, box masks, reference columns) are
+ * passed per call from HOST memory (`slots_host[n_slots]`, copied into the kernel arguments).  A table depends only on the boxes,
+ * token positions, keys, map shapes and loss options, so callers build it once and keep it on the device: a call is then two
+ * launches and no host -> device copy (capturable in a hipGraph).  Grid: one block per (item, 4 heads), one head per wave;
+ * `head_terms` fp32 [n_items * max_heads] scratch; the fold adds heads in head order and items in item order (bit-identical to
+ * tg_guidance_batch and to the per-term entry points).  Same no-shared-(grad, token)-column rule per call. */
+#define TG_GUIDANCE_MAX_SLOTS 64
+typedef struct {
+  int32_t attn_slot, grad_slot /* -1: none */, mask_slot, ref_slot /* -1: none (kind 2 only) */;
+  int32_t heads, hw, n_tok, token;
+  int32_t kind, k_fg, k_bg, reserved;
+  float fg_w, bg_w, scale, eps;
+} tg_guidance_pitem;
+int tg_guidance_plan_run(const tg_guidance_pitem* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
+                         const void* const* slots_host, int32_t n_slots, float* head_terms, float* out, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

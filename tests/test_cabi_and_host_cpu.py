@@ -370,3 +370,56 @@ def test_gemm_planner_kernel_choice(monkeypatch):
     assert plan(gemm(4096, 1280, 5120, force_tile=14)) == (128, 320, 2, 5)
     monkeypatch.setenv("TG_GEMM_FLAGS", "256")
     assert plan(gemm(16384, 640, 2560)) == (128, 320, 1, 5) and plan(gemm(4096, 1280, 5120)) == (128, 320, 2, 5)
+
+
+def test_shift_tensor_ignore_last_dim_matches_reference_formula():
+    """utils/utils.py:143-178 with ignore_last_dim=True (attention maps [heads, H, W, tokens]): restated index arithmetic"""
+    import torch
+    from theatergen_amd.utils import shift_tensor
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(2, 16, 24, 5, generator=g)
+    for (dx, dy) in ((3, -2), (-5, 4), (0, 0), (24, 1)):
+        got = shift_tensor(t, dx, dy, ignore_last_dim=True)
+        ref = torch.zeros_like(t)
+        ow, oh = 24 - abs(dx), 16 - abs(dy)
+        ys, yd = (0, dy) if dy >= 0 else (-dy, 0)
+        xs, xd = (0, dx) if dx >= 0 else (-dx, 0)
+        ref[..., yd:yd + oh, xd:xd + ow, :] = t[..., ys:ys + oh, xs:xs + ow, :]
+        assert got.shape == t.shape and torch.equal(got, ref)
+    # normalised offsets quantised to the 8 x 8 base grid (:150-153)
+    got = shift_tensor(t, 0.25, -0.125, base_w=8, base_h=8, offset_normalized=True, ignore_last_dim=True)
+    assert torch.equal(got, shift_tensor(t, round(0.25 * 8) * 3, round(-0.125 * 8) * 2, ignore_last_dim=True))
+
+
+def test_processor_branches_outside_the_hot_path_fail_loudly():
+    """The diffusers processor features the TheaterGen flow never uses (ip_adapter/attention_processor.py:316-331, 340-354:
+    attention_mask / prepare_attention_mask, attn_process_fn, group_norm / spatial_norm / norm_cross, added_kv) are refused with an
+    explicit error — never silently ignored, never a CPU fallback."""
+    import pytest
+    import torch
+    from theatergen_amd.attention_processor import Attention, AttnProcessor, IPAttnProcessor
+    attn = Attention(query_dim=64, heads=2, dim_head=32)
+    x = torch.zeros(1, 8, 64)
+    with pytest.raises(NotImplementedError):
+        AttnProcessor()(attn, x, attention_mask=torch.zeros(1, 8, 8))
+    with pytest.raises(NotImplementedError):
+        AttnProcessor()(attn, x, attn_process_fn=lambda p: p)
+    with pytest.raises(RuntimeError):
+        AttnProcessor()(attn, x)                                     # CPU tensor: no fallback
+    cross = Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32)
+    with pytest.raises(NotImplementedError):
+        IPAttnProcessor(64, 32)(cross, x, encoder_hidden_states=torch.zeros(1, 9, 32), attention_mask=torch.zeros(1, 8, 9))
+    for kw in (dict(norm_num_groups=32), dict(spatial_norm_dim=8), dict(cross_attention_norm="layer_norm"), dict(added_kv_proj_dim=16)):
+        with pytest.raises(ValueError):
+            Attention(query_dim=64, heads=2, dim_head=32, **kw)
+
+
+def test_ip_scale_is_a_plain_mutable_attribute():
+    """IPAdapter.set_scale assigns ``processor.scale`` (ip_adapter/ip_adapter.py:155-158): it must read back as assigned"""
+    from theatergen_amd.attention_processor import IPAttnProcessor
+    p = IPAttnProcessor(64, 32, scale=0.4, num_tokens=4)
+    assert p.scale == 0.4
+    p.scale = 0.0
+    assert p.scale == 0.0
+    p.scale = 1
+    assert p.scale == 1 and "scale" not in dict(p.named_parameters())

@@ -811,3 +811,70 @@ def test_gemm_loader_compute_kernel(dtype, case, monkeypatch):
     out = ops.gemm(a, w, M, N, K, **kw)
     check(out, ref.cpu(), dtype, f"loader/compute gemm {case}")
     assert torch.equal(out, ops.gemm(a, w, M, N, K, **kw))
+
+
+LN_CASES = [  # (rows, C, row mean offset, row scale): the offset / scale stress the mean * u cancellation and E[x^2] - mean^2
+    (4096, 320, 0.0, 1.0), (2100, 640, 0.5, 2.0), (1024, 1280, 3.0, 0.5), (384, 320, -8.0, 0.25),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", LN_CASES)
+def test_gemm_layernorm_folded(dtype, case):
+    """tg_gemm ln_u / ln_v (kernel_kind 6): LayerNorm folded into the projection that consumes it vs the fp32 reference
+    ``F.linear(F.layer_norm(x), W, b)`` — the three shapes the UNet uses: attn2.to_q (N = C), attn1 q|k|v with the V^T split
+    (N = 3C), FeedForward GEGLU (N = 8C, packed a|gate rows) — and vs the two-launch path (tg_layernorm then tg_gemm)."""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_geglu, pack_ln_linear
+    dev = _dev()
+    M, C, off, sc = case
+    g = torch.Generator().manual_seed(M + C)
+    x = ((torch.randn(M, C, generator=g) + off * torch.randn(M, 1, generator=g)) * sc).to(dtype)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.3 * torch.randn(C, generator=g)).to(dtype)
+    eps = 1e-5
+    xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps)
+    xd = x.to(dev)
+    # (a) N = C, no bias
+    w = rnd((C, C), dtype, g, 1 / math.sqrt(C))
+    wl, u, v = pack_ln_linear(w.to(dev), None, gamma.to(dev), beta.to(dev))
+    tm, tn, sp, kind = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)
+    assert kind == 6 and sp == 1
+    got = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
+    check(got, xn @ w.float().t(), dtype, f"ln-folded to_q {case}", scale=1.5)
+    two = ops.linear(ops.layernorm(xd, gamma.to(dev), beta.to(dev), eps), w.to(dev))
+    check(got, two.float(), dtype, f"ln-folded vs two-launch {case}", scale=2.0)
+    # (b) q | k | v^T split (rows_per_batch divides M)
+    B = 2 if M % 2 == 0 else 1
+    rows = M // B
+    ldt = (rows + 7) // 8 * 8
+    w3 = rnd((3 * C, C), dtype, g, 1 / math.sqrt(C))
+    wl3, u3, v3 = pack_ln_linear(w3.to(dev), None, gamma.to(dev), beta.to(dev))
+    qk = torch.zeros((M, 2 * C), dtype=dtype, device=dev)
+    vt = torch.zeros((B, C, ldt), dtype=dtype, device=dev)
+    ops.gemm(xd, wl3, M, 3 * C, C, rows_per_batch=rows, out=qk, n_split=2 * C, out_t=vt, ldt=ldt, ln=(u3, v3, eps))
+    ref3 = xn @ w3.float().t()
+    check(qk, ref3[:, :2 * C], dtype, f"ln-folded q|k {case}", scale=1.5)
+    check(vt[:, :, :rows], ref3[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, f"ln-folded v^T {case}", scale=1.5)
+    # (c) GEGLU with bias
+    N = 8 * C
+    wf, bf = rnd((N, C), dtype, g, 1 / math.sqrt(C)), rnd((N,), dtype, g)
+    y = xn @ wf.float().t() + bf.float()
+    wp, bp = pack_geglu(wf.to(dev), bf.to(dev))
+    wlg, ug, vg = pack_ln_linear(wp, bp, gamma.to(dev), beta.to(dev))
+    gg = ops.gemm(xd, wlg, M, N, C, geglu=True, ln=(ug, vg, eps))
+    assert gg.shape == (M, N // 2)
+    check(gg, y[:, :N // 2] * F.gelu(y[:, N // 2:]), dtype, f"ln-folded geglu {case}", scale=1.5)
+
+
+def test_gemm_layernorm_fold_argument_errors():
+    from theatergen_amd import ops
+    dev = _dev()
+    x = torch.zeros(256, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev)
+    u = torch.zeros(64, dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, 256, 64, 64, ln=(u, u, 1e-5), res=x)            # no residual with the fold
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, 256, 64, 64, ln=(u, u, 0.0))                    # eps must be positive
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, 256, 64, 64, ln=(u, u, 1e-5), force_split_k=2)

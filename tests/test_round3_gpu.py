@@ -303,3 +303,53 @@ def test_config4_sd21_editing_step_vs_oracle():
             pm.check(r["lat"], ref, f"config 4 step {i}: latents after CFG + v-DDIM + frozen-mask replace", 1.5e-2, 3e-2)
             m = fmask.bool()
             assert torch.equal(r["lat"][0][:, m], frozen[i + 1][0][:, m]), "inside the mask the composed latents are copied verbatim"
+
+
+def test_guidance_plan_cached_on_device_and_graph_capturable():
+    """the item table of a ``compute_ca_lossv3`` call (slot indices, no pointers) and the box masks are built once
+    and stay on the device — a second call with the same boxes / positions / keys uploads nothing — and the whole call can be
+    captured in a hipGraph: replayed on new map contents it gives the bits of an eager call."""
+    from tests.golden import gen_common as gc
+    from theatergen_amd import guidance as G
+    from theatergen_amd import ops
+    dev = torch.device(DEV)
+    keys = gc.GUIDANCE_KEYS
+    hw = {keys[0]: 144, keys[1]: 576, keys[2]: 576, keys[3]: 576}
+    g = torch.Generator().manual_seed(99)
+
+    def fresh():
+        out = {}
+        for k in keys:
+            a = torch.rand(1, 20, hw[k], 77, generator=g)
+            out[k] = (a / a.sum(-1, keepdim=True)).to(dev)
+        return out
+    boxes, pos = gc.GUIDANCE_BOXES[4], gc.GUIDANCE_POSITIONS[4]
+    maps = fresh()
+
+    def call(m):
+        return G.compute_ca_lossv3(m, boxes, pos, keys, return_grads=True, **GUIDE_TOPK)
+    l1, g1 = call(maps)
+    n_tables, n_masks = len(ops.GuidanceBatch._tables), len(G._mask_cache)
+    l2, g2 = call(maps)
+    assert len(ops.GuidanceBatch._tables) == n_tables and len(G._mask_cache) == n_masks, "second call rebuilt its plan"
+    assert l1.item() == l2.item() and all(torch.equal(g1[k], g2[k]) for k in keys)
+    # capture
+    static = {k: v.clone() for k, v in maps.items()}
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        call(static)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lg, gg = call(static)
+    new = fresh()
+    for k in keys:
+        static[k].copy_(new[k])
+    graph.replay()
+    torch.cuda.synchronize()
+    le, ge = call(new)
+    assert lg.item() == le.item(), (lg.item(), le.item())
+    for k in keys:
+        assert torch.equal(gg[k], ge[k])

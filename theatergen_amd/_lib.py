@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("act", i32), ("geglu", i32), ("out_scale", f32), ("out", vp), ("ldc", i64), ("n_split", i64),
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
         ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
-        ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp),
+        ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32),
     ]
 
 
@@ -49,6 +49,17 @@ class GuidanceItem(C.Structure):
         ("fg_w", f32), ("bg_w", f32), ("scale", f32), ("eps", f32),
     ]
 
+
+class GuidancePItem(C.Structure):
+    _fields_ = [
+        ("attn_slot", i32), ("grad_slot", i32), ("mask_slot", i32), ("ref_slot", i32),
+        ("heads", i32), ("hw", i32), ("n_tok", i32), ("token", i32),
+        ("kind", i32), ("k_fg", i32), ("k_bg", i32), ("reserved", i32),
+        ("fg_w", f32), ("bg_w", f32), ("scale", f32), ("eps", f32),
+    ]
+
+
+GUIDANCE_MAX_SLOTS = 64
 
 # name -> (restype, argtypes); every symbol declared in include/theatergen_hip.h
 SIGNATURES = {
@@ -82,6 +93,7 @@ SIGNATURES = {
     "tg_guidance_ratio": (i32, [vp, i32, i32, i32, i32, vp, f32, vp, vp, vp]),
     "tg_guidance_ref": (i32, [vp, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
     "tg_guidance_batch": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "tg_guidance_plan_run": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),
     "tg_groupnorm_bwd": (i32, [i32, vp, vp, i32, i64, i32, i32, f32, vp, vp, i32, vp, vp]),
     "tg_layernorm_bwd": (i32, [i32, vp, vp, i64, i32, f32, vp, vp, vp]),
     "tg_geglu_bwd": (i32, [i32, vp, vp, i64, i64, vp, vp]),

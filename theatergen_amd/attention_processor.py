@@ -132,6 +132,14 @@ class Attention(nn.Module):
         ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight]
         return self._cached("qkv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
 
+    def ln_weight(self, name, norm):
+        """(W', u, v) of ``pack_ln_linear`` for the projection that consumes ``norm`` (a ``nn.LayerNorm``): ``name`` = "qkv" (self-
+        attention: to_q ; to_k ; to_v rows) or "q" (cross-attention query)."""
+        from .weights_pack import pack_ln_linear
+        ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight] if name == "qkv" else [self.to_q.weight]
+        return self._cached("ln_" + name, ws + [norm.weight, norm.bias],
+                            lambda: pack_ln_linear(torch.cat([w.detach() for w in ws], dim=0), None, norm.weight, norm.bias))
+
     def kv_weight(self):
         ws = [self.to_k.weight, self.to_v.weight]
         return self._cached("kv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
@@ -210,23 +218,30 @@ class AttnProcessor(nn.Module):
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
                  return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
-                 enable_flash_attn=True, _fused_residual=None):
+                 enable_flash_attn=True, _fused_residual=None, _fused_ln=None):
+        """``_fused_ln`` (internal, ``BasicTransformerBlock``): ``hidden_states`` is the block's UN-normalised stream and the
+        ``nn.LayerNorm`` given here is folded into the first projection (tg_gemm ``ln_u`` / ``ln_v``)."""
         _check_common(attn, hidden_states, attention_mask, attn_process_fn)
         x, B, N, C, shape4 = _to_tokens(hidden_states)
         inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
+        lnq = None
+        if _fused_ln is not None:
+            wl, ul, vl = attn.ln_weight("qkv" if encoder_hidden_states is None else "q", _fused_ln)
+            lnq = (ul, vl, _fused_ln.eps)
         if encoder_hidden_states is None:
             # one GEMM: [Q | K] token-major + V^T per batch item
             ldt = _round8(N)
             qk = torch.empty((B * N, 2 * inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
-            ops.gemm(x, attn.qkv_weight(), B * N, 3 * inner, C, rows_per_batch=N, out=qk, n_split=2 * inner, out_t=vt, ldt=ldt)
+            ops.gemm(x, wl if lnq else attn.qkv_weight(), B * N, 3 * inner, C, rows_per_batch=N, out=qk, n_split=2 * inner, out_t=vt, ldt=ldt,
+                     ln=lnq)
             ops.attention(qk, 2 * inner, N * 2 * inner, qk[:, inner:], 2 * inner, N * 2 * inner, vt, ldt, inner * ldt, N,
                           B, heads, d, N, attn.scale, o, inner, N * inner)
         else:
             enc, L, enc_bs = _enc_rows(encoder_hidden_states)
             ctx = enc.shape[2]
-            q = ops.linear(x, attn.to_q.weight)
+            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight)
             ldt = _round8(L)
             k = torch.empty((B * L, inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
@@ -346,7 +361,7 @@ class IPAttnProcessor(nn.Module):
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
                  return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
-                 enable_flash_attn=True, _fused_residual=None):
+                 enable_flash_attn=True, _fused_residual=None, _fused_ln=None):
         _check_common(attn, hidden_states, attention_mask, attn_process_fn)
         if encoder_hidden_states is None:
             raise RuntimeError("IPAttnProcessor is a cross-attention processor: encoder_hidden_states is required")
@@ -354,7 +369,11 @@ class IPAttnProcessor(nn.Module):
         inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
         enc = encoder_hidden_states.contiguous()
         k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
-        q = ops.linear(x, attn.to_q.weight)
+        if _fused_ln is not None:
+            wl, ul, vl = attn.ln_weight("q", _fused_ln)
+            q = ops.linear(x, wl, ln=(ul, vl, _fused_ln.eps))
+        else:
+            q = ops.linear(x, attn.to_q.weight)
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
         ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
                       o, inner, N * inner, k1=kip, k1_ld=inner, k1_bs=T * inner, vt1=vtip, vt1_ld=ldi, vt1_bs=inner * ldi,
@@ -375,12 +394,13 @@ class CNAttnProcessor:
         self.num_tokens = num_tokens
         self._plain = AttnProcessor()
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, _fused_residual=None):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, _fused_residual=None,
+                 _fused_ln=None):
         if encoder_hidden_states is not None:
             end_pos = encoder_hidden_states.shape[1] - self.num_tokens
             encoder_hidden_states = encoder_hidden_states[:, :end_pos]
         return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask,
-                           temb=temb, _fused_residual=_fused_residual)
+                           temb=temb, _fused_residual=_fused_residual, _fused_ln=_fused_ln)
 
 
 # the reference's torch-2 aliases (ip_adapter/ip_adapter.py:13-24 selects these names)

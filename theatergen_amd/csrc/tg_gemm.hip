@@ -18,6 +18,7 @@
 // nearest-x2 upsampled input (Upsample2D) and a two-source channel concat (skip connection) are folded
 // into the gather.
 #include "tg_gemm_common.h"
+#include "tg_gemm_glds.h"
 
 namespace {
 
@@ -36,472 +37,6 @@ struct Plan { int tile; bool halo; int full, tail, s, kps; long tiles_m, tiles_n
 
 
 
-// ------------------------------------------------------------------------------------------------------------
-// Operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
-// ds_write pass).  (A first, register-staged generation of this kernel spent 32 KB of ds_write_b128 per 128x128x64 tile,
-// ~415 LDS cycles next to 256 cycles of fragment reads and 512 MFMA cycles: the LDS pipe was its bound; it is gone.)  LDS image: unpadded 128-byte rows (the DMA destination is lane-linear), XOR-swizzled in 16-byte slots
-// with key = (row >> 1) & 7; the swizzle is applied on the per-lane SOURCE address and again on the fragment read
-// (cdna guide rule 21), which makes the 16-lane ds_read_b128 groups conflict-free.  Out-of-range rows / conv padding
-// read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
-
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_glds_kernel(GemmParams p) {
-  constexpr int NW = WAVES_M * WAVES_N;
-  constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
-  constexpr int CH = BKT / 8;                 // 16-byte chunks per LDS row (8 at BK = 64, 4 at BK = 32)
-  constexpr int RPI = 64 / CH;                // tile rows covered by one 1-KiB DMA instruction (8 or 16)
-  constexpr int KSH = CH == 8 ? 1 : 2;        // swizzle key = (row >> KSH) & (CH - 1): conflict-free ds_read_b128 groups
-  constexpr int NDMA = BM / (RPI * NW) + BN / (RPI * NW);   // LDS-DMA instructions per wave per K-tile (constant: invalid rows fetch the zero page)
-  constexpr int TM = BM / (WAVES_M * 32);
-  constexpr int TN = BN / (WAVES_N * 32);
-  constexpr int XJ = BM / (RPI * NW);   // DMA instructions per wave per K-tile for the activation tile
-  constexpr int WJ = BN / (RPI * NW);
-  static_assert(BKT == 64 || BKT == 32, "BK");
-  static_assert((size_t)NW * 32 * (TN * 32 + 4) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "epilogue scratch must fit the operand stages");
-  typedef typename Vec<T>::v8 V8;
-  static_assert(NW % 2 == 0 && XJ >= 1 && WJ >= 1, "tile / wave layout");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sX = reinterpret_cast<T*>(smem);                 // [2][BM][64]
-  T* sW = sX + STAGES * BM * BKT;                     // [STAGES][BN][BKT]
-  stagger_first_round(p.flags, smem);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave / WAVES_N;
-  const int wave_n = wave % WAVES_N;
-  // work item -> (tile, K range): the first full_tiles blocks compute whole tiles (XCD-chunked order); the tail tiles
-  // are cut tail_s ways along K so that the last, partially filled round of the grid is spread over all CUs
-  int lbid, split = 0, part = -1;
-  if ((int)blockIdx.x < p.full_tiles) {
-    lbid = xcd_chunked_block_id(blockIdx.x, p.full_tiles);
-  } else {
-    const int j = (int)blockIdx.x - p.full_tiles;
-    lbid = p.full_tiles + j / p.tail_s;
-    split = j - (j / p.tail_s) * p.tail_s;
-    part = j;
-  }
-  const int tile_n = lbid % p.tiles_n;
-  const int tile_m = lbid / p.tiles_n;
-  const long m0 = (long)tile_m * BM;
-  const long n0 = (long)tile_n * BN;
-  const int nkt_total = (int)((p.K + BKT - 1) / BKT);
-  const int kt_begin = part >= 0 ? split * p.kt_per_split : 0;
-  int kt_end = part >= 0 ? kt_begin + p.kt_per_split : nkt_total;
-  if (kt_end > nkt_total) kt_end = nkt_total;
-  const int nkt = kt_end - kt_begin;
-
-  // DMA lane geometry: instruction q covers tile rows [RPI*q, RPI*q + RPI); lane -> (row RPI*q + lane/CH, slot lane%CH)
-  const int lrow = lane / CH;
-  const int slot = lane & (CH - 1);
-  // key of row RPI*q + lrow, q = j*NW + wave: BK=64: ((8q + lrow) >> 1) & 7 = (4(wave&1) + lane/16) & 7;  BK=32: (lane/16) & 3
-  const int wkey = CH == 8 ? ((4 * (wave & 1) + (lane >> 4)) & 7) : ((lane >> 4) & 3);
-  const int chunk = slot ^ wkey;                          // global 16-byte chunk this lane fetches into its slot
-
-  const T* A0 = reinterpret_cast<const T*>(p.a0);
-  const T* A1 = reinterpret_cast<const T*>(p.a1);
-  const T* Wp = reinterpret_cast<const T*>(p.w);
-  const T* zero = reinterpret_cast<const T*>(tg_zero_page);
-  const int ctot = p.c0 + p.c1;
-
-  long xbase[XJ], xrow[XJ];
-  int x_oy[XJ], x_ox[XJ], x_ob[XJ];
-  bool x_ok[XJ];
-#pragma unroll
-  for (int j = 0; j < XJ; ++j) {
-    const long m = m0 + (j * NW + wave) * RPI + lrow;
-    x_ok[j] = m < p.M;
-    xbase[j] = m * p.c0;
-    xrow[j] = m;
-    if (!CONV && p.a_rpb > 0) { const long bb = m / p.a_rpb; xbase[j] = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
-    if (CONV) {
-      const long mm = x_ok[j] ? m : 0;
-      const int hw = p.out_h * p.out_w;
-      x_ob[j] = (int)(mm / hw);
-      const int r = (int)(mm - (long)x_ob[j] * hw);
-      x_oy[j] = r / p.out_w;
-      x_ox[j] = r - x_oy[j] * p.out_w;
-    }
-  }
-  const T* wrow[WJ];
-#pragma unroll
-  for (int j = 0; j < WJ; ++j) {
-    const long n = n0 + (j * NW + wave) * RPI + lrow;
-    wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
-  }
-
-  auto dma = [&](const T* src, T* lds_row_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
-  };
-
-  auto issue_tile = [&](int kt, int buf) {
-    const long k0 = (long)kt * BKT;
-    const long kc = k0 + chunk * 8;
-    const bool kok = kc < p.K;
-    T* dx = sX + buf * BM * BKT;
-    T* dw = sW + buf * BN * BKT;
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const T* src = (kok && wrow[j] != nullptr) ? wrow[j] + kc : zero;
-      dma(src, dw + (j * NW + wave) * RPI * BKT);
-    }
-    if (!CONV) {
-      const T* base = A0;
-      long pitch = p.c0;
-      long kk = kc;
-      const bool second = A1 != nullptr && k0 >= p.c0;
-      if (second) { base = A1; pitch = p.c1; kk = kc - p.c0; }
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        const long off = second ? xrow[j] * pitch : xbase[j];
-        const T* src = (kok && x_ok[j]) ? base + off + kk : zero;
-        dma(src, dx + (j * NW + wave) * RPI * BKT);
-      }
-    } else {
-      const int tap = (int)(k0 / ctot);
-      int cc = (int)(k0 - (long)tap * ctot);
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const T* base = A0;
-      int pitch = p.c0;
-      if (cc >= p.c0) { base = A1; pitch = p.c1; cc -= p.c0; }
-      cc += chunk * 8;
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        int iy, ix;
-        bool ok = x_ok[j];
-        if (!p.upsample) {
-          iy = x_oy[j] * p.stride + ky - p.pad_lo;
-          ix = x_ox[j] * p.stride + kx - p.pad_lo;
-          ok = ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        } else {
-          const int uy = x_oy[j] + ky - 1, ux = x_ox[j] + kx - 1;
-          ok = ok && uy >= 0 && uy < 2 * p.in_h && ux >= 0 && ux < 2 * p.in_w;
-          iy = uy >> 1;
-          ix = ux >> 1;
-        }
-        const T* src = ok ? base + ((long)(x_ob[j] * p.in_h + iy) * p.in_w + ix) * pitch + cc : zero;
-        dma(src, dx + (j * NW + wave) * RPI * BKT);
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  constexpr bool BIGW = TM * TN > 4;            // big wave tiles: fragments are read per k-step (register budget)
-  // EARLY REFILL (2 stages, all fragments of a K-tile read into registers up front): a stage is dead as soon as every wave
-  // has its 16 fragments, i.e. half a K-tile before the next one starts — it is refilled right then with the tile AFTER
-  // next.  Two K-tiles are in flight with two 32 KB stages; the K-tile period was one DMA round trip (~1800 cycles against
-  // 1024 of MFMA work for the two resident blocks) and a third stage does not fit next to a second block.
-  constexpr bool ER = STAGES == 2 && !BIGW;
-  if (nkt > 0) {
-    // counted waits: a wave only waits until the NEXT tile's DMA has landed (vmcnt(NDMA) = one younger tile may stay in
-    // flight; LDS-DMA completes in issue order); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
-    if constexpr (ER) {
-      issue_tile(kt_begin, 0);
-      if (nkt > 1) issue_tile(kt_begin + 1, 1);
-      if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (s < nkt) issue_tile(kt_begin + s, s);
-      if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
-    const int rkey = (l31 >> KSH) & (CH - 1);
-    int buf = 0;
-    for (int it = 0; it < nkt; ++it) {
-      const T* bx = sX + buf * BM * BKT + (wave_m * TM * 32 + l31) * BKT;
-      const T* bw = sW + buf * BN * BKT + (wave_n * TN * 32 + l31) * BKT;
-      // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
-      // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
-      // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
-      V8 xf[BKT / 16][TM], wf[BKT / 16][TN];
-      if constexpr (!BIGW) {
-#pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
-          const int so = ((2 * ks + hi) ^ rkey) * 8;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!ER) {
-        // the next tile's DMA addresses are computed / issued while the fragment reads are in flight
-        if (it + PF < nkt) {
-          int nb = buf + PF;
-          if (nb >= STAGES) nb -= STAGES;
-          issue_tile(kt_begin + it + PF, nb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (p.flags & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < BKT / 16; ++ks) {
-        if constexpr (BIGW) {
-          const int so = ((2 * ks + hi) ^ rkey) * 8;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
-        }
-        if constexpr (ER) {
-          if (ks == BKT / 32) {
-            // half of the chain is issued: by now every fragment has landed in registers -> the stage is free
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (it + 2 < nkt) issue_tile(kt_begin + it + 2, buf);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
-      }
-      if (p.flags & 2) __builtin_amdgcn_s_setprio(0);
-      // keep the MFMA chain ABOVE the wait: an asm "memory" clobber does not order register-only MFMAs, and hipcc
-      // otherwise hoists `s_waitcnt vmcnt(0); s_barrier` in front of them, exposing the whole DMA latency per tile
-      __builtin_amdgcn_sched_barrier(0);
-      // tile it+1 must have landed; a younger tile (if issued) may stay in flight
-      if ((ER || PF >= 2) && it + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      buf = buf + 1 == STAGES ? 0 : buf + 1;
-    }
-  }
-
-  epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                   reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// conv3x3 with an LDS-STAGED HALO WINDOW (stride 1, pad 1, image width 16 / 32 / 64).
-// The implicit-GEMM kernel above fetches every activation row 9 times (once per tap) through L2; the GEMM family is
-// bound by L2 -> LDS operand delivery (profiles/r1_gemm_findings.md), so here a block = 128 output pixels = TH full
-// image rows stages the (TH+2) x (W+2) input halo of ONE 64-channel chunk in LDS once and serves all 9 taps from
-// it: the MFMA B-operand (lane = pixel) is read at slab row (py+ky)*(W+2) + px+kx.  K runs chunk-major / tap-minor;
-// only the 128x64 weight tile streams per K-step (double-buffered).  Activation L2 traffic drops 9x, total operand
-// traffic per FLOP by ~1.7x.  Same swizzle, same accumulator layout and the same epilogue as the GEMM kernel
-// (full-width rows make the block's pixels contiguous in the token-major tensor).
-// UPS = true: the same for Upsample2D (nearest x2 then conv3x3): WI is the OUTPUT width, the slab holds the
-// (TH/2 + 2) x (WI/2 + 2) INPUT pixels the block's upsampled window maps to (input pixel = upsampled coordinate >> 1).
-template <typename T, int WI, bool UPS>
-__global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
-  constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, WAVES_N = 2;
-  // WI = 8 (the 8x8 level): a block's 128 pixels are TWO whole 8x8 images; their two 10x10 padded windows are stacked
-  // in the slab (20 slab rows of width 10), everything else is unchanged
-  constexpr bool MULTI = WI == 8;
-  static_assert(!(MULTI && UPS), "no upsample variant at width 8");
-  constexpr int TH = BM / WI, WIN = UPS ? WI / 2 : WI, SW = WIN + 2, SROWS = MULTI ? 20 : (UPS ? TH / 2 + 2 : TH + 2);
-  constexpr int SLAB = SROWS * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
-  constexpr int WJ = BN / (8 * NW);
-  typedef typename Vec<T>::v8 V8;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sS = reinterpret_cast<T*>(smem);                 // [NI*8][64]   halo slab of the current channel chunk
-  stagger_first_round(p.flags, smem);
-  // weight-tile ring: 3 stages (2 tiles in flight) wherever slab + 3 x 16 KB still lets two blocks share a CU (every
-  // variant but the 64-wide one): a K-step's period was one DMA round trip of the next W tile, not its 16 MFMAs
-  constexpr int WST = ((size_t)NI * 8 * BK + 3 * BN * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
-  constexpr int WD = WST - 1;                          // W tiles issued ahead of the one being multiplied
-  T* sW = sS + NI * 8 * BK;                           // [WST][BN][64]  weight tiles
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave / WAVES_N;
-  const int wave_n = wave % WAVES_N;
-  int lbid, split = 0, part = -1;     // same work-item scheme as gemm_glds_kernel; the K split runs over channel chunks
-  if ((int)blockIdx.x < p.full_tiles) {
-    lbid = xcd_chunked_block_id(blockIdx.x, p.full_tiles);
-  } else {
-    const int j = (int)blockIdx.x - p.full_tiles;
-    lbid = p.full_tiles + j / p.tail_s;
-    split = j - (j / p.tail_s) * p.tail_s;
-    part = j;
-  }
-  const int tile_n = lbid % p.tiles_n;
-  const int tile_m = lbid / p.tiles_n;
-  const long m0 = (long)tile_m * BM;
-  const long n0 = (long)tile_n * BN;
-  const int H = p.in_h;                               // INPUT height (output height = 2H when UPS)
-  const int HO = UPS ? 2 * H : H;
-  const int img = (int)(m0 / ((long)HO * WI));
-  const int y0 = (int)((m0 - (long)img * HO * WI) / WI);
-  const int iy0 = UPS ? y0 / 2 - 1 : y0 - 1;          // input row held by slab row 0
-
-  const int lrow = lane >> 3;
-  const int slot = lane & 7;
-  const int wkey = (4 * (wave & 1) + (lane >> 4)) & 7;
-  const int chunk = slot ^ wkey;
-
-  const T* A0 = reinterpret_cast<const T*>(p.a0);
-  const T* A1 = reinterpret_cast<const T*>(p.a1);
-  const T* Wp = reinterpret_cast<const T*>(p.w);
-  const T* zero = reinterpret_cast<const T*>(tg_zero_page);
-  const int ctot = p.c0 + p.c1;
-  const int nchunks = ctot / BK;
-
-  int spix[SJ];                                       // input pixel feeding this lane's slab row (-1: zero padding)
-#pragma unroll
-  for (int j = 0; j < SJ; ++j) {
-    const int sr = (j * NW + wave) * 8 + lrow;
-    const int sy = sr / SW, sx = sr - sy * SW;
-    int iy = iy0 + sy, im = img;
-    if (MULTI) { im = img + sy / 10; iy = sy % 10 - 1; }       // slab rows [10 i, 10 i + 10) = padded window of image img + i
-    const int ix = sx - 1;
-    const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WIN && (m0 < p.M);
-    spix[j] = ok ? (im * H + iy) * WIN + ix : -1;
-  }
-  const T* wrow[WJ];
-#pragma unroll
-  for (int j = 0; j < WJ; ++j) {
-    const long n = n0 + (j * NW + wave) * 8 + lrow;
-    wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
-  }
-
-  auto dma = [&](const T* src, T* lds_row_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
-  };
-  auto issue_slab = [&](int cc) {
-    int c = cc * BK;
-    const T* base = A0;
-    int pitch = p.c0;
-    if (c >= p.c0) { base = A1; pitch = p.c1; c -= p.c0; }
-    c += chunk * 8;
-#pragma unroll
-    for (int j = 0; j < SJ; ++j) {
-      if (j * NW + wave < NI) {
-        const T* src = spix[j] >= 0 ? base + (long)spix[j] * pitch + c : zero;
-        dma(src, sS + (j * NW + wave) * 8 * BK);
-      }
-    }
-  };
-  auto issue_w = [&](int cc, int tap, int buf) {
-    const long kc = (long)tap * ctot + cc * BK + chunk * 8;
-    T* dw = sW + buf * BN * BK;
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const T* src = wrow[j] != nullptr ? wrow[j] + kc : zero;
-      dma(src, dw + (j * NW + wave) * 8 * BK);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31;
-  const int hi = lane >> 5;
-  const int rkey = (l31 >> 1) & 7;
-  int ppy[TM], ppx[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int pm = wave_m * TM * 32 + i * 32 + l31;
-    ppy[i] = MULTI ? (pm >> 6) * 10 + ((pm & 63) >> 3) : pm / WI;
-    ppx[i] = pm % WI;
-  }
-
-  // channel chunks of this work item (kt_per_split counts chunks here)
-  const int c_begin = part >= 0 ? split * p.kt_per_split : 0;
-  int c_end = part >= 0 ? c_begin + p.kt_per_split : nchunks;
-  if (c_end > nchunks) c_end = nchunks;
-
-  const int nkt = (c_end - c_begin) * 9;
-  int icc = c_begin, itap = 0;                         // (chunk, tap) of the next W tile to request
-  issue_slab(c_begin);
-#pragma unroll
-  for (int s_ = 0; s_ < WD; ++s_) {
-    if (s_ < nkt) {
-      issue_w(icc, itap, s_);
-      if (++itap == 9) { itap = 0; ++icc; }
-    }
-  }
-  if (WD == 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int cc = c_begin, tap = 0;
-  int buf = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
-    V8 xf[BK / 16][TM], wf[BK / 16][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int sr = UPS ? (((ppy[i] + ky - 1) >> 1) + 1) * SW + ((ppx[i] + kx - 1) >> 1) + 1
-                         : (ppy[i] + ky) * SW + ppx[i] + kx;
-      const int key = (sr >> 1) & 7;
-      const T* bx = sS + sr * BK;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) xf[ks][i] = *reinterpret_cast<const V8*>(bx + ((2 * ks + hi) ^ key) * 8);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int so = ((2 * ks + hi) ^ rkey) * 8;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BK + so);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int ncc = cc, ntap = tap + 1;
-    if (ntap == 9) { ntap = 0; ncc = cc + 1; }
-    if (kt + 1 < nkt) {
-      if (ntap == 0) {
-        // the next K-step starts a new channel chunk: every wave must have its tap-8 fragments in registers before
-        // the slab is overwritten; the slab DMA then overlaps this step's 16 MFMAs
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_slab(ncc);
-      }
-    }
-    if (kt + WD < nkt) {
-      int nb = buf + WD;
-      if (nb >= WST) nb -= WST;
-      issue_w(icc, itap, nb);
-      if (++itap == 9) { itap = 0; ++icc; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);
-    // the W tile of step kt+1 (and a slab requested in this step, which is older than this step's W request) must have
-    // landed; the W tile requested in this step may stay in flight
-    if (WD == 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    cc = ncc;
-    tap = ntap;
-    buf = buf + 1 == WST ? 0 : buf + 1;
-  }
-
-  epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                 reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
-}
-
 template <typename T>
 __global__ void splitk_reduce_kernel(GemmParams p);
 
@@ -516,19 +51,6 @@ int launch_reduce(const GemmParams& p, const Plan& pl, hipStream_t st) {
     TG_LAUNCH_CHECK();
   }
   return TG_OK;
-}
-
-template <typename T, int WI, bool UPS>
-int launch_halo(const GemmParams& p, const Plan& pl, hipStream_t st) {
-  constexpr int TH = 128 / WI, SLAB = WI == 8 ? 200 : (UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2)), NI = (SLAB + 7) / 8;
-  const int wst = ((size_t)NI * 8 * BK + 3 * 128 * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
-  const size_t lds = ((size_t)NI * 8 * BK + wst * 128 * BK) * sizeof(T);
-  auto k = conv_halo_kernel<T, WI, UPS>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)attr;
-  hipLaunchKernelGGL(k, dim3((unsigned)(pl.full + pl.tail * pl.s)), dim3(256), lds, st, p);
-  TG_LAUNCH_CHECK();
-  return launch_reduce<T>(p, pl, st);
 }
 
 inline bool halo_eligible(const tg_gemm_desc* d) {
@@ -667,6 +189,10 @@ int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, vo
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 // loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles for long-K plain GEMMs
 int tg_gemm_lc_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
+// LayerNorm-fused projections (tg_gemm_ln.hip): 128 x 128 tiles, no K split
+int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, int grid, void* stream);
+// LDS-halo conv (tg_conv_halo.hip): grid = full tiles + tail tiles * K splits
+int tg_conv_halo_launch(const tg_gemm_desc* d, const void* params, int grid, void* stream);
 namespace {
 
 // Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 16 / 32 / 64-wide maps, 128-pixel x 320-channel
@@ -774,11 +300,19 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
   }
   p.a_coef = d->a_coef; p.a_silu = d->a_silu;
+  p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
                 (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
                 (d->n_split == 0 || d->n_split % 64 == 0);
+  }
+  if (d->ln_u != nullptr) {
+    // LayerNorm-fused projection: whole rows per workgroup (no K split), 128 x 128 tiles in XCD-chunked order
+    const long tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128);
+    p.full_tiles = (int)tiles; p.tail_s = 1; p.tiles_n = (int)((d->N + 127) / 128); p.tile_bm = 128; p.tile_bn = 128;
+    p.kt_per_split = 0;
+    return tg_gemm_ln_launch(d, &p, d->K <= 640 ? 1 : 0, (int)tiles, st);
   }
   if (const int sp = slab_splits_of(d); sp > 0) {
     const long tiles = (d->M / 128) * (d->N / 320);
@@ -820,15 +354,9 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     return tg_gemm_bt_launch(d, &p, bt, st);
   }
   if (pl.halo) {
-    if (d->upsample) {
-      if (d->out_w == 64) return launch_halo<T, 64, true>(p, pl, st);
-      if (d->out_w == 32) return launch_halo<T, 32, true>(p, pl, st);
-      return launch_halo<T, 16, true>(p, pl, st);
-    }
-    if (d->out_w == 64) return launch_halo<T, 64, false>(p, pl, st);
-    if (d->out_w == 32) return launch_halo<T, 32, false>(p, pl, st);
-    if (d->out_w == 8) return launch_halo<T, 8, false>(p, pl, st);
-    return launch_halo<T, 16, false>(p, pl, st);
+    const int rc = tg_conv_halo_launch(d, &p, pl.full + pl.tail * pl.s, st);
+    if (rc != TG_OK) return rc;
+    return launch_reduce<T>(p, pl, st);
   }
   switch (pl.tile) {
     case 0: return launch_cfg2<T, 128, 128, 2, 2, 2>(d, p, pl, st);
@@ -882,6 +410,13 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->out_t && d->n_split % 4 == 0 && d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bad transposed-output args");
   }
   if (d->bvec) TG_CHECK(d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bvec needs rows_per_batch");
+  if (d->ln_u != nullptr || d->ln_v != nullptr) {
+    TG_CHECK(d->ln_u && d->ln_v, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs both ln_u and ln_v");
+    TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && d->force_tile == 0,
+             TG_ERR_ARG, "tg_gemm: the LayerNorm fold takes a plain single-source GEMM with a linear or GEGLU epilogue (no residual / per-batch vector / split)");
+    TG_CHECK(d->K % 32 == 0 && d->N % 8 == 0 && d->ln_eps > 0.f, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs K %% 32 == 0, N %% 8 == 0, eps > 0");
+    TG_CHECK((reinterpret_cast<uintptr_t>(d->ln_u) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_v) & 15) == 0, TG_ERR_ARG, "tg_gemm: ln_u / ln_v must be 16-byte aligned");
+  }
   return TG_OK;
 }
 
@@ -890,6 +425,13 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
+  if (d->ln_u != nullptr) {
+    if (tile_m) *tile_m = 128;
+    if (tile_n) *tile_n = 128;
+    if (splits) *splits = 1;
+    if (kernel_kind) *kernel_kind = 6;
+    return TG_OK;
+  }
   if (const int sp = slab_splits_of(d); sp > 0) {
     if (tile_m) *tile_m = 128;
     if (tile_n) *tile_n = 320;
@@ -921,6 +463,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
+  if (d->ln_u != nullptr) return 0;
   if (const int sp = slab_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (const int sp = lc_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (bt_tile_of(d) >= 0) return 0;

@@ -40,6 +40,9 @@ struct GemmParams {
   int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
   const void* a_coef;   // conv slab kernel: GroupNorm coefficients [batch][2][c0 + c1] fp32 (a, d): A' = act(A * a + d) while staging, or NULL
   int a_silu;           // ... with SiLU
+  const float* ln_u;    // LayerNorm folded into the GEMM (gemm_glds_kernel<..., LN = true>): W is pre-multiplied by gamma, the kernel takes the
+  const float* ln_v;    // row statistics from its own A tiles and the epilogue forms rstd * (acc - mean * u[n]) + v[n]; u, v fp32 [N]
+  float ln_eps;
   int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
                     // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
 };
@@ -131,10 +134,27 @@ __device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
 // kernel's instructions; leaving it out of the kernels that never run it is worth ~6 % at K = 320 (code size).
 // J0 / JN: the window [J0, J0 + JN) of the wave tile's TN 32-column tiles this call handles (big wave tiles run the
 // epilogue in column chunks so that the LDS bounce stays small); n_base is the column of tile 0, lane offset included.
-template <typename T, int TM, int TN, int EPI, int J0 = 0, int JN = TN>
+// LN: LayerNorm-folded projection (gemm_glds_kernel<..., LN>): the kernel has already turned every accumulator into
+// rstd * (acc - mean * u[n]); the epilogue adds the fp32 vector v[n] = sum_k beta[k] W[n, k] + bias[n] where the bias would go.
+template <typename T, int TM, int TN, int EPI, int J0 = 0, int JN = TN, bool LN = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int part,
                                               long pm0, long pn0) {
   typedef typename Vec<T>::v4 V4;
+  if constexpr (LN) {
+    // (the caller already formed rstd * (acc - mean * u) in place) + v[n]; the direct path is the cold one: V^T columns
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = J0; j < J0 + JN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long n4 = n_base + 32 * j + 8 * g;
+          f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+          if (n4 < p.N) v4 = *reinterpret_cast<const f32x4*>(p.ln_v + n4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += v4[e];
+        }
+  }
   if (part >= 0) {
     // K-split tail tile: fp32 partial in tile-local layout ws[part][tile_bm][tile_bn]; the reduce kernel sums the
     // tail_s partials of the tile in a fixed order and applies the epilogue
@@ -272,7 +292,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // per-batch-vector loads, then the 8 LDS writes, then ALL LDS reads of the half, then the arithmetic and the stores
 // (only the store is predicated on the row bound).  fp32: ((acc + bias) + bvec) + res, activation, * scale, one rounding;
 // x + 0 and x * 1 are exact, so this rounds the same value as the direct epilogue.
-template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES, int J0 = 0, int JN = TN>
+template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES, int J0 = 0, int JN = TN, bool LN = false>
 __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
                                                   float* scr) {
   typedef typename Vec<T>::v8 V8;
@@ -293,6 +313,11 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&
     const V8 b8 = *reinterpret_cast<const V8*>(biasp + nc);
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
+  }
+  if constexpr (LN) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.ln_v + nc), v1 = *reinterpret_cast<const f32x4*>(p.ln_v + nc + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias_f[e] += v0[e]; bias_f[4 + e] += v1[e]; }
   }
   const float scale = p.out_scale;
 #pragma unroll
@@ -513,14 +538,14 @@ __device__ __forceinline__ void epilogue_tile_reg16(const GemmParams& p, f32x16 
 }
 
 // one column chunk [J0, J0 + JN) of the wave tile through the LDS bounce (or the direct path where the bounce does not apply)
-template <typename T, int TM, int TN, int EPI, int J0, int JN>
+template <typename T, int TM, int TN, int EPI, int J0, int JN, bool LN = false>
 __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
                                                    float* scr, int part, long pm0, long pn0) {
   typedef typename Vec<T>::v4 V4;
   typedef typename Vec<T>::v8 V8;
   const int l31 = lane & 31, hi = lane >> 5;
   if (part >= 0 || !p.epi_lds || (p.n_split > 0 && n_wave + J0 * 32 >= p.n_split)) {
-    epilogue_tile<T, TM, TN, EPI, J0, JN>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0);
+    epilogue_tile<T, TM, TN, EPI, J0, JN, LN>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0);
     return;
   }
   T* outp = reinterpret_cast<T*>(p.out);
@@ -549,6 +574,15 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) { baf[g][e] = to_f32<T>(ba[e]); bgf[g][e] = to_f32<T>(bg[e]); }
+        }
+        if constexpr (LN) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const long na = gok[g] ? nq + 4 * hi + 8 * g : 0;
+            const f32x4 va = *reinterpret_cast<const f32x4*>(p.ln_v + na), vg = *reinterpret_cast<const f32x4*>(p.ln_v + na + 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { baf[g][e] += va[e]; bgf[g][e] += vg[e]; }
+          }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -589,7 +623,10 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
   // one straight-line instance of the row loop per (per-batch vector?, residual?) combination: with the wave-uniform
   // branches inside the loop every pass was its own basic block and the compiler exposed one LDS / load latency per
   // pass (in-kernel s_memtime: ~7200 cycles per 128x128 tile against ~1800 per K-tile)
-  if (bvecp != nullptr) {
+  if constexpr (LN) {
+    // the LayerNorm-fused projections carry no per-batch vector and no residual (QKV, to_q, FF1)
+    epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN, true>(p, acc, m_wave, n_wave, lane, scr);
+  } else if (bvecp != nullptr) {
     if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
     else epilogue_rows_lds<T, TM, TN, EPI, true, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
   } else {
@@ -601,12 +638,13 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
 // Whole wave tile.  Up to two 32-column tiles go through the bounce in one piece (the 128x128 / 64x64 kernels: unchanged);
 // wider wave tiles (the big-tile kernels: 5 or 4 tiles) run in 64-column chunks (+ one 32-column rest), so the per-wave
 // scratch stays 32 x 68 floats and every store instruction still covers whole 128-byte rows.
-template <typename T, int TM, int TN, int EPI>
+template <typename T, int TM, int TN, int EPI, bool LN = false>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
                                                   float* scr, int part, long pm0, long pn0) {
   if constexpr (TN <= 2) {
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
   } else {
+    static_assert(!LN, "the LayerNorm fold is instantiated for the 64-column wave tiles only");
     epilogue_chunk_lds<T, TM, TN, EPI, 0, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
     if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
     if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);

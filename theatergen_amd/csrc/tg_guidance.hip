@@ -37,12 +37,14 @@ __device__ void wave_topk_select(const float* x, int n, int k, int lane, float& 
 // each *_block function is executed by a whole 256-thread block and returns (in thread 0) the term the reference adds to
 // the loss for ONE (attention map, object, token position); `grad` (optional) is accumulated in place
 __device__ float guidance_topk_block(float* sh, const float* attn, int heads, int hw, int n_tok, int token, const float* mask,
-                                     int k_fg, int k_bg, float fg_w, float bg_w, float scale, float* grad) {
+                                     int k_fg, int k_bg, float fg_w, float bg_w, float scale, float* grad, int h0 = 0, int hcnt = 1 << 30, float* head_out = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* xf = sh + (size_t)wave * 2 * hw;   // A * M
   float* xb = xf + hw;                      // A * (1 - M)
   float* head_loss = sh + (size_t)G_WAVES * 2 * hw;  // [heads]
-  for (int h = wave; h < heads; h += G_WAVES) {
+  const int h_end = heads < h0 + hcnt ? heads : h0 + hcnt;
+  if (head_out != nullptr) head_loss = head_out;      // per-head terms go to the caller's array (folded later, in the same order)
+  for (int h = h0 + wave; h < h_end; h += G_WAVES) {
     const float* col = attn + (long)h * hw * n_tok + token;
     for (int i = lane; i < hw; i += 64) {
       const float a = col[(long)i * n_tok], m = mask[i];
@@ -83,7 +85,7 @@ __device__ float guidance_topk_block(float* sh, const float* attn, int heads, in
   }
   __syncthreads();
   float term = 0.f;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && head_out == nullptr) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
     term = scale * s;
@@ -92,9 +94,11 @@ __device__ float guidance_topk_block(float* sh, const float* attn, int heads, in
 }
 
 __device__ float guidance_ratio_block(float* head_loss, const float* attn, int heads, int hw, int n_tok, int token,
-                                      const float* mask, float scale, float* grad) {
+                                      const float* mask, float scale, float* grad, int h0 = 0, int hcnt = 1 << 30, float* head_out = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int h = wave; h < heads; h += G_WAVES) {
+  const int h_end = heads < h0 + hcnt ? heads : h0 + hcnt;
+  if (head_out != nullptr) head_loss = head_out;      // per-head terms go to the caller's array (folded later, in the same order)
+  for (int h = h0 + wave; h < h_end; h += G_WAVES) {
     const float* col = attn + (long)h * hw * n_tok + token;
     float sm = 0.f, sa = 0.f;
     for (int i = lane; i < hw; i += 64) {
@@ -114,7 +118,7 @@ __device__ float guidance_ratio_block(float* head_loss, const float* attn, int h
   }
   __syncthreads();
   float term = 0.f;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && head_out == nullptr) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
     term = scale * s / (float)heads;
@@ -125,9 +129,11 @@ __device__ float guidance_ratio_block(float* head_loss, const float* attn, int h
 // attention-transfer term (utils/guidance.py:223-233): per head, the masked current column and the masked reference
 // column are each normalised by (their sum + eps); loss = mean over heads of the L1 distance.  ref: [heads, hw].
 __device__ float guidance_ref_block(float* head_loss, const float* attn, int heads, int hw, int n_tok, int token, const float* ref,
-                                    const float* mask, float eps, float scale, float* grad) {
+                                    const float* mask, float eps, float scale, float* grad, int h0 = 0, int hcnt = 1 << 30, float* head_out = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int h = wave; h < heads; h += G_WAVES) {
+  const int h_end = heads < h0 + hcnt ? heads : h0 + hcnt;
+  if (head_out != nullptr) head_loss = head_out;      // per-head terms go to the caller's array (folded later, in the same order)
+  for (int h = h0 + wave; h < h_end; h += G_WAVES) {
     const float* col = attn + (long)h * hw * n_tok + token;
     const float* rcol = ref + (long)h * hw;
     float cs = 0.f, rs = 0.f;
@@ -162,7 +168,7 @@ __device__ float guidance_ref_block(float* head_loss, const float* attn, int hea
   }
   __syncthreads();
   float term = 0.f;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && head_out == nullptr) {
     float s = 0.f;
     for (int h = 0; h < heads; ++h) s += head_loss[h];
     term = scale * s / (float)heads;
@@ -212,7 +218,75 @@ __global__ void guidance_fold_kernel(const float* partials, int n, float* out) {
   }
 }
 
+// ---- plan form of the same launch (round 3): the item table holds SLOT INDICES instead of pointers, the pointers of the call (the
+// saved maps, their gradients, the box masks, reference columns) travel by value in the kernel arguments.  A table therefore depends
+// only on (boxes, token positions, keys, map shapes, loss options): the host builds it once, keeps it on the device and every later
+// call is two launches with no host -> device copy — and can be captured in the hipGraph of the denoising step.  Work split: one
+// block per (item, group of G_WAVES heads), one head per wave: 4 keys x 4 boxes x 20 heads = 560 waves in flight instead of 28 blocks
+// walking 5 heads each.  The fold adds the per-head terms of an item in head order and the items in item order: the sequence of
+// additions of the per-item launches, i.e. the same bits.
+struct GuidanceSlots { const void* p[TG_GUIDANCE_MAX_SLOTS]; };
+
+__global__ __launch_bounds__(64 * G_WAVES) void guidance_plan_kernel(const tg_guidance_pitem* items, GuidanceSlots slots, int hgroups,
+                                                                     int max_heads, float* head_terms) {
+  extern __shared__ float sh[];
+  const int item = blockIdx.x / hgroups, h0 = (blockIdx.x - item * hgroups) * G_WAVES;
+  const tg_guidance_pitem it = items[item];
+  if (h0 >= it.heads) return;
+  const float* attn = reinterpret_cast<const float*>(slots.p[it.attn_slot]);
+  float* grad = it.grad_slot >= 0 ? reinterpret_cast<float*>(const_cast<void*>(slots.p[it.grad_slot])) : nullptr;
+  const float* mask = reinterpret_cast<const float*>(slots.p[it.mask_slot]);
+  const float* ref = it.ref_slot >= 0 ? reinterpret_cast<const float*>(slots.p[it.ref_slot]) : nullptr;
+  float* out = head_terms + (long)item * max_heads;
+  if (it.kind == 0) guidance_topk_block(sh, attn, it.heads, it.hw, it.n_tok, it.token, mask, it.k_fg, it.k_bg, it.fg_w, it.bg_w, it.scale, grad, h0, G_WAVES, out);
+  else if (it.kind == 1) guidance_ratio_block(sh, attn, it.heads, it.hw, it.n_tok, it.token, mask, it.scale, grad, h0, G_WAVES, out);
+  else guidance_ref_block(sh, attn, it.heads, it.hw, it.n_tok, it.token, ref, mask, it.eps, it.scale, grad, h0, G_WAVES, out);
+}
+// items [begin, end) of one launch group; terms are added to out[0] in item order (thread 0), after every thread folded one item's heads
+__global__ __launch_bounds__(256) void guidance_plan_fold_kernel(const tg_guidance_pitem* items, int n_items, int max_heads,
+                                                                 const float* head_terms, float* out) {
+  __shared__ float terms[256];
+  for (int base = 0; base < n_items; base += 256) {
+    const int i = base + threadIdx.x;
+    if (i < n_items) {
+      const tg_guidance_pitem it = items[i];
+      float sacc = 0.f;
+      for (int h = 0; h < it.heads; ++h) sacc += head_terms[(long)i * max_heads + h];
+      terms[threadIdx.x] = it.kind == 0 ? it.scale * sacc : it.scale * sacc / (float)it.heads;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = out[0];
+      const int n = n_items - base < 256 ? n_items - base : 256;
+      for (int j = 0; j < n; ++j) t += terms[j];
+      out[0] = t;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int tg_guidance_plan_run(const tg_guidance_pitem* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
+                                    const void* const* slots_host, int32_t n_slots, float* head_terms, float* out, void* stream) {
+  TG_CHECK(items_device && head_terms && out && slots_host && n_items > 0 && max_heads > 0 && max_hw_topk >= 0, TG_ERR_ARG, "tg_guidance_plan_run: bad args");
+  TG_CHECK(n_slots > 0 && n_slots <= TG_GUIDANCE_MAX_SLOTS, TG_ERR_ARG, "tg_guidance_plan_run: %d pointer slots (1..%d)", n_slots, TG_GUIDANCE_MAX_SLOTS);
+  const size_t lds = ((size_t)G_WAVES * 2 * max_hw_topk + max_heads) * sizeof(float);
+  TG_CHECK(lds <= 160 * 1024, TG_ERR_ARG, "tg_guidance_plan_run: attention map too large for the top-k select (hw = %d needs %zu bytes of LDS, "
+           "160 KB available)", max_hw_topk, lds);
+  GuidanceSlots sl;
+  for (int i = 0; i < TG_GUIDANCE_MAX_SLOTS; ++i) sl.p[i] = i < n_slots ? slots_host[i] : nullptr;
+  for (int i = 0; i < n_slots; ++i) TG_CHECK(sl.p[i] != nullptr, TG_ERR_ARG, "tg_guidance_plan_run: slot %d is NULL", i);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(guidance_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int hgroups = (max_heads + G_WAVES - 1) / G_WAVES;
+  hipLaunchKernelGGL(guidance_plan_kernel, dim3((unsigned)(n_items * hgroups)), dim3(64 * G_WAVES), lds, st, items_device, sl, hgroups, max_heads, head_terms);
+  TG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(guidance_plan_fold_kernel, dim3(1), dim3(256), 0, st, items_device, n_items, max_heads, head_terms, out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
 
 extern "C" int tg_guidance_batch(const tg_guidance_item* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
                                  float* partials, float* out, void* stream) {

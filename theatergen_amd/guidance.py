@@ -16,14 +16,24 @@ from . import ops
 from .utils import scale_proportion
 
 
+_mask_cache = {}           # (boxes, H, W, device) -> (host mask, device mask): box masks are step-invariant, uploaded once
+_MASK_CACHE_MAX = 256
+
+
 def _box_mask(obj_boxes, H, W, device):
     if not isinstance(obj_boxes[0], Iterable):
         obj_boxes = [obj_boxes]
-    m = torch.zeros(H, W)
-    for bx in obj_boxes:
-        x0, y0, x1, y1 = scale_proportion(bx, H=H, W=W)
-        m[y0:y1, x0:x1] = 1
-    return m, m.to(device)
+    key = (tuple(tuple(float(v) for v in bx) for bx in obj_boxes), int(H), int(W), str(device))
+    hit = _mask_cache.get(key)
+    if hit is None:
+        m = torch.zeros(H, W)
+        for bx in obj_boxes:
+            x0, y0, x1, y1 = scale_proportion(bx, H=H, W=W)
+            m[y0:y1, x0:x1] = 1
+        if len(_mask_cache) >= _MASK_CACHE_MAX:
+            _mask_cache.pop(next(iter(_mask_cache)))
+        hit = _mask_cache[key] = (m, m.to(device))
+    return hit
 
 
 def add_ca_loss_per_attn_map_to_loss(loss, attn_map, object_number, bboxes, object_positions, use_ratio_based_loss=True,

@@ -68,7 +68,7 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False, ln=None):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -106,6 +106,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.pad_mode = int(pad_mode)
     d.a_coef = _ptr(a_coef)
     d.a_silu = 1 if a_silu else 0
+    if ln is not None:                  # (u fp32 [N], v fp32 [N], eps): LayerNorm of the A rows folded into this GEMM (``pack_ln_linear``)
+        d.ln_u, d.ln_v, d.ln_eps = _ptr(ln[0]), _ptr(ln[1]), float(ln[2])
     if plan_only:
         tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)))
@@ -135,6 +137,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         kname = f"lc_gemm_kernel<{tm.value}x{tn.value}>"
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
+    elif kk.value == 6:
+        kname = f"gemm_glds_kernel<plain+ln,{tm.value}x{tn.value}>"
     else:
         kname = f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
     _gemm_profile.append(dict(kernel=kname, splits=sp.value,
@@ -489,20 +493,29 @@ def sumpool2x2(du, batch, h, w):
 
 class GuidanceBatch:
     """Collects the terms of one ``compute_ca_lossv3`` call (one per attention map x object x token position) and evaluates
-    them with ONE ``tg_guidance_batch`` launch + an in-order fold instead of one dependent launch each.  Terms whose
-    gradient columns would collide (same grad tensor and token in one call: two objects sharing a token position, or a
+    them with ONE ``tg_guidance_plan_run`` launch pair (+ an in-order fold) instead of one dependent launch each.
+
+    Round 3: the device-side item table holds SLOT indices, not pointers; the call's tensors (maps, gradients, masks, reference
+    columns) are passed as kernel arguments.  The table therefore only depends on (kinds, shapes, token positions, top-k sizes,
+    weights, which tensor goes with which) and is cached on the device, keyed by exactly that — a steady-state call makes NO host ->
+    device copy (the round-2 path built and uploaded a pointer table per call: most of its 1.3 ms at BASELINE configs[3]) and can
+    be captured in a hipGraph.
+
+    Terms whose gradient columns would collide (same grad tensor and token in one call: two objects sharing a token position, or a
     reference-attention term next to the box term of the same key and token) are deferred to a following launch, so the
     order of additions into the loss is LAUNCH-MAJOR, item order within each launch — fixed and deterministic for a given
     call, identical to the per-term launches whenever no column collides (the shipped flow), one fp32 re-association otherwise."""
     KIND_TOPK, KIND_RATIO, KIND_REF = 0, 1, 2
+    _tables = {}            # (device index, item signature) -> (device table tensor, n_items, max_hw_topk, max_heads)
+    _TABLES_MAX = 128
 
     def __init__(self, device):
         self.device = device
-        self.items, self.keep = [], []
+        self.items = []
 
     def add(self, kind, attn, token, mask, scale, grad=None, ref=None, k_fg=0, k_bg=0, fg_w=0.0, bg_w=0.0, eps=0.0):
         heads, hw, n_tok = attn.shape
-        for t in (attn, grad, mask, ref):             # raw device pointers go into the item table: a host tensor would fault the GPU
+        for t in (attn, grad, mask, ref):             # raw device pointers go to the kernel: a host tensor would fault the GPU
             if t is not None:
                 _need_cuda(t)
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -511,35 +524,65 @@ class GuidanceBatch:
             raise RuntimeError(f"guidance: token position {token} outside the {n_tok} text tokens")
         if kind == self.KIND_TOPK and not (1 <= k_fg <= hw and 1 <= k_bg <= hw):
             raise RuntimeError("guidance: top-k size out of range")
-        it = _lib.GuidanceItem()
-        it.attn, it.grad, it.mask, it.ref = _ptr(attn), _ptr(grad), _ptr(mask), _ptr(ref)
-        it.heads, it.hw, it.n_tok, it.token = int(heads), int(hw), int(n_tok), int(token)
-        it.kind, it.k_fg, it.k_bg = int(kind), int(k_fg), int(k_bg)
-        it.fg_w, it.bg_w, it.scale, it.eps = float(fg_w), float(bg_w), float(scale), float(eps)
-        self.items.append(it)
-        self.keep += [attn, grad, mask, ref]
+        if mask.numel() != hw or (ref is not None and ref.numel() != heads * hw) or (grad is not None and grad.numel() != attn.numel()):
+            raise RuntimeError("guidance: mask / reference / gradient shape does not match the attention map")
+        self.items.append(dict(kind=int(kind), attn=attn, grad=grad, mask=mask, ref=ref, heads=int(heads), hw=int(hw), n_tok=int(n_tok),
+                               token=int(token), k_fg=int(k_fg), k_bg=int(k_bg), fg_w=float(fg_w), bg_w=float(bg_w), scale=float(scale),
+                               eps=float(eps)))
+
+    def _launch(self, now, loss):
+        slots, index = [], {}
+
+        def slot(t):
+            if t is None:
+                return -1
+            key = t.data_ptr()
+            if key not in index:
+                index[key] = len(slots)
+                slots.append(t)
+            return index[key]
+        rows = []
+        for it in now:
+            rows.append((slot(it["attn"]), slot(it["grad"]), slot(it["mask"]), slot(it["ref"]), it["heads"], it["hw"], it["n_tok"], it["token"],
+                         it["kind"], it["k_fg"], it["k_bg"], it["fg_w"], it["bg_w"], it["scale"], it["eps"]))
+        if len(slots) > _lib.GUIDANCE_MAX_SLOTS:
+            half = len(now) // 2                      # more distinct tensors than argument slots: two launches (item order is kept)
+            self._launch(now[:half], loss)
+            self._launch(now[half:], loss)
+            return
+        key = (self.device.index, tuple(rows))
+        hit = GuidanceBatch._tables.get(key)
+        if hit is None:
+            arr = (_lib.GuidancePItem * len(rows))()
+            for a, r in zip(arr, rows):
+                (a.attn_slot, a.grad_slot, a.mask_slot, a.ref_slot, a.heads, a.hw, a.n_tok, a.token, a.kind, a.k_fg, a.k_bg,
+                 a.fg_w, a.bg_w, a.scale, a.eps) = r
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)     # once per signature
+            hit = (table, len(rows), max([r[5] for r in rows if r[8] == self.KIND_TOPK] + [0]), max(r[4] for r in rows))
+            if len(GuidanceBatch._tables) >= GuidanceBatch._TABLES_MAX:
+                GuidanceBatch._tables.pop(next(iter(GuidanceBatch._tables)))
+            GuidanceBatch._tables[key] = hit
+        table, n, max_hw, max_heads = hit
+        ptrs = (C.c_void_p * len(slots))(*[t.data_ptr() for t in slots])
+        head_terms = torch.empty(n * max_heads, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().tg_guidance_plan_run(table.data_ptr(), n, max_hw, max_heads, ptrs, len(slots), head_terms.data_ptr(), _ptr(loss),
+                                                   _stream()))
 
     def flush(self, loss):
-        """loss: fp32 device tensor [1], accumulated in place in item order"""
+        """loss: fp32 device tensor [1], accumulated in place (launch-major, item order within a launch)"""
         items, self.items = self.items, []
         while items:
             seen, now, later = set(), [], []
             for it in items:
-                col = (it.grad, it.token) if it.grad else None
+                col = (it["grad"].data_ptr(), it["token"]) if it["grad"] is not None else None
                 if col is not None and col in seen:
                     later.append(it)              # keeps item order within each launch; collisions go to the next one
                 else:
                     if col is not None:
                         seen.add(col)
                     now.append(it)
-            arr = (_lib.GuidanceItem * len(now))(*now)
-            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            partials = torch.empty(len(now), dtype=torch.float32, device=self.device)
-            max_hw = max([it.hw for it in now if it.kind == self.KIND_TOPK] + [0])
-            _lib.check(_lib.lib().tg_guidance_batch(table.data_ptr(), len(now), max_hw, max(it.heads for it in now),
-                                                    partials.data_ptr(), _ptr(loss), _stream()))
+            self._launch(now, loss)
             items = later
-        # nothing is pinned beyond the last launch: every tensor above is used on the current stream only, and the caching
-        # allocator hands a freed block back to that same stream (stream-ordered reuse), so dropping the references is safe
-        self.keep = []
+        # nothing is pinned beyond the last launch: every tensor is used on the current stream only, and the caching allocator
+        # hands a freed block back to that same stream (stream-ordered reuse)
         return loss

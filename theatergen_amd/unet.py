@@ -29,7 +29,7 @@ import torch.nn as nn
 from . import ops
 from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor
 from .config import UNetConfig
-from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu
+from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear
 
 
 class DeviceSchedule:
@@ -70,6 +70,9 @@ class _Packed:
 
 # dev switch: TG_NO_GN_FUSE=1 keeps GroupNorm and conv two ops everywhere (A/B of the fused window staging)
 _FUSE_GN = not os.environ.get("TG_NO_GN_FUSE")
+# dev switch: TG_NO_LN_FUSE=1 keeps LayerNorm a launch of its own in front of the q|k|v / to_q / GEGLU projections
+_FUSE_LN = not os.environ.get("TG_NO_LN_FUSE")
+_FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
 
 class ResnetBlock2D(nn.Module):
@@ -169,10 +172,17 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
         self._p = _Packed()
 
-    def run(self, x2d, residual):
+    def run(self, x2d, residual, ln=None):
+        """``ln`` (a ``nn.LayerNorm``): ``x2d`` is the un-normalised stream and the norm is folded into the GEGLU GEMM"""
         proj = self.net[0].proj
         M, K = x2d.shape
-        if M > 64 and (proj.weight.shape[0] // 2) % 32 == 0:
+        if ln is not None:
+            def build():
+                wp, bp = pack_geglu(proj.weight.detach(), proj.bias.detach())
+                return pack_ln_linear(wp, bp, ln.weight, ln.bias)
+            wl, ul, vl = self._p.get("geglu_ln", [proj.weight, proj.bias, ln.weight, ln.bias], build)
+            g = ops.gemm(x2d, wl, M, wl.shape[0], K, geglu=True, ln=(ul, vl, ln.eps))
+        elif M > 64 and (proj.weight.shape[0] // 2) % 32 == 0:
             # GEGLU fused into the C -> 8C GEMM epilogue: the [M, 8C] pre-activation is never written
             wp, bp = self._p.get("geglu", [proj.weight, proj.bias], lambda: pack_geglu(proj.weight.detach(), proj.bias.detach()))
             g = ops.gemm(x2d, wp, M, wp.shape[0], K, bias=bp, geglu=True)
@@ -194,14 +204,21 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     @staticmethod
-    def _call(attn, x2d, b, n, enc, residual, kwargs):
+    def _call(attn, x2d, b, n, enc, residual, kwargs, ln=None):
+        """``ln`` None: ``x2d`` is the normalised input.  ``ln`` = the block's ``nn.LayerNorm``: ``x2d`` is the un-normalised
+        stream; our own processors fold the norm into their first projection, any other processor gets ``tg_layernorm`` first."""
         proc = attn.processor
+        ours = isinstance(proc, (AttnProcessor, IPAttnProcessor, CNAttnProcessor))
+        if ln is not None and not ours:
+            x2d, ln = ops.layernorm(x2d, ln.weight, ln.bias, ln.eps), None
         x3 = x2d.reshape(b, n, -1)
         if isinstance(proc, (AttnProcessor, IPAttnProcessor)) and attn.rescale_output_factor == 1.0 \
                 and not attn.residual_connection and not kwargs.get("return_attntion_probs"):
-            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual, **kwargs).reshape(b * n, -1)
+            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual, _fused_ln=ln, **kwargs).reshape(b * n, -1)
         if isinstance(proc, CNAttnProcessor):
-            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual).reshape(b * n, -1)
+            return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual, _fused_ln=ln).reshape(b * n, -1)
+        if ln is not None:
+            x3 = ops.layernorm(x2d, ln.weight, ln.bias, ln.eps).reshape(b, n, -1)
         # foreign processor: plain diffusers protocol, residual added afterwards
         out = attn(x3, encoder_hidden_states=enc, **kwargs)
         if isinstance(out, tuple):
@@ -209,6 +226,12 @@ class BasicTransformerBlock(nn.Module):
         return ops.add(out.reshape(b * n, -1).contiguous(), residual)
 
     def run(self, x2d, b, n, enc, ca_kwargs):
+        M, C = x2d.shape
+        if _FUSE_LN and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
+            # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor, no layernorm launch
+            x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=self.norm1)
+            x2d = self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=self.norm2)
+            return self.ff.run(x2d, x2d, ln=self.norm3)
         h = ops.layernorm(x2d, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
         h = ops.layernorm(x2d, self.norm2.weight, self.norm2.bias, self.norm2.eps)

@@ -96,7 +96,10 @@ def shift_tensor(tensor, x_offset, y_offset, base_w=8, base_h=8, offset_normaliz
     """Zero-filled shift of the last two dims.  fp32 CUDA tensors go through ``tg_shift``; small host masks
     (bool / int, 64x64) are index-copied on the host like the reference does."""
     if ignore_last_dim:
-        raise NotImplementedError("ignore_last_dim (attention-map shifting) is not on the hot path")
+        # cross-attention maps [..., H, W, tokens] (reference utils/utils.py:146-147, 174-176): the two dims in front of the last one
+        # are the image; pure data movement: shift a view with the token dim moved to the front, hand back the original layout
+        moved = shift_tensor(tensor.movedim(-1, 0), x_offset, y_offset, base_w, base_h, offset_normalized, False)
+        return moved.movedim(0, -1).contiguous()
     h, w = tensor.shape[-2:]
     if offset_normalized:
         x_offset, y_offset = quantize_offset(x_offset, y_offset, h, w, base_w, base_h)
