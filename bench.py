@@ -338,6 +338,10 @@ def bench_sd21_editing(args):
             with torch.cuda.graph(gr):
                 full_step()                                   # round 3: the WHOLE step (UNet + capture, guidance losses + d loss / d A, epilogue)
             graph = gr
+            gr2 = torch.cuda.CUDAGraph()                      # the guidance call alone, captured: its device-side cost without the host's Python
+            with torch.cuda.graph(gr2):
+                guid_call()
+            out["guid_graph_ms"] = _ev_ms(gr2.replay, iters=20)
         except Exception as e:                                # noqa: BLE001 - any capture failure means eager launches
             sys.stderr.write(f"[bench sd21] hipGraph capture of the UNet call refused ({type(e).__name__}: {e}); eager launches\n")
             torch.cuda.synchronize()
@@ -424,7 +428,10 @@ def bench_sd21_editing(args):
                      "by_kernel": by_kernel},
         "guidance": {"bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 5),
                      "bytes_per_step": map_bytes, "ms": round(parts["guidance"] / 5, 3),
-                     "note": "4 maps x 20 heads x (144 | 576) x 77 fp32 read + gradients written; latency-bound (1.5 MB per step)"},
+                     "ms_in_graph": round(out["guid_graph_ms"], 4) if "guid_graph_ms" in out else None,
+                     "note": "4 maps x 20 heads x (144 | 576) x 77 fp32 read + gradients written (1.5 MB per step); `ms` = eager call incl. the host's Python "
+                             "(loop over keys / boxes / positions), `ms_in_graph` = the same call replayed from a hipGraph: what it costs inside the captured step; "
+                             "achieved / frac use `ms`"},
     }
     return result
 
@@ -469,7 +476,10 @@ def bench_sdxl(args):
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(hist[-1]).all()
     s_step = elapsed / (args.steps * steps)
-    by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(eng._step)
+    def one_eager_step():
+        eng._reset(lat)                                   # step counter back to 0: the epilogue indexes its tables with it
+        eng._step()
+    by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(one_eager_step)
     ach = PLAN_FLOP_PER_CFG_CALL["sdxl"] / s_step / 1e12
     result = {
         "metric": "SDXL 1024px IP-Adapter-Plus: seconds per DDIM step (CFG batch 2)", "value": round(s_step, 5), "unit": "s/step",

@@ -131,6 +131,7 @@ typedef struct {
   const float* ln_u;
   const float* ln_v;
   float ln_eps;
+  const float* ln_rows;  /* optional with ln_u: precomputed row statistics (tg_layernorm_stats, fp32 [M][2]); NULL = taken inside the kernel */
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
@@ -198,6 +199,9 @@ int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32_t c0, int3
                  void* partials, void* stream);
 int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, const void* gamma,
                  const void* beta, void* out, int64_t ldo, void* stream);
+/* Row statistics of tg_layernorm only: stats[m] = (rstd, -rstd * mean) fp32 [rows][2] (two-pass mean / centred biased variance over the
+ * stored values) — the `ln_rows` input of the LayerNorm-folded projections (tg_gemm_desc.ln_u): half the traffic of the normalising pass. */
+int tg_layernorm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream);
 /* GroupNorm statistics only: coef[b][0][c] = rstd(b, group(c)) * gamma[c], coef[b][1][c] = beta[c] - mean(b, group(c)) * coef[b][0][c]
  * (fp32 [batch][2][c0 + c1]; the same reductions, in the same order, as tg_groupnorm) for tg_gemm_desc.a_coef: the apply pass
  * (normalise + SiLU, one HBM write + read of the activation per conv) moves into the consumer conv's window staging. */

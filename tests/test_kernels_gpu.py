@@ -684,6 +684,14 @@ SLAB_CASES = [
     (3, 32, 32, 1280, 640, 640, 11),    # SD-1.5 up block 2, 30 chunks
     (2, 64, 32, 128, 0, 320, 11),       # two chunks: the look-ahead request never fires
     (34, 32, 32, 320, 0, 320, 11),      # 272 tiles on 256 persistent workgroups: second, partial round
+    # round 3, PATCH tiles: the image is wider than the tile (128-wide maps as 2 x 64 patches, 96-wide maps as 4 x 32 patches): halo
+    # columns are real neighbour pixels, a wave's pixels are not one contiguous token range
+    (1, 8, 128, 128, 0, 320, 11),       # SDXL level-0 width, 8 tiles in 4 patch rows x 2 patch columns
+    (2, 4, 128, 320, 64, 640, 11),      # two images, two sources, two N tiles
+    (1, 8, 96, 192, 0, 320, 11),        # SD-2.1 level-0 width: 3 patch columns x 2 patch rows of 4 x 32
+    (2, 12, 96, 320, 320, 320, 11),     # two images x (3 x 3) patches, two sources
+    (2, 128, 128, 320, 0, 320, 0),      # BASELINE configs[4] level 0 at batch 2: 256 tiles, taken by the heuristic
+    (2, 96, 96, 320, 0, 320, 0),        # BASELINE configs[3] level 0 at batch 2: 144 tiles, taken by the heuristic (no 128-pixel halo fallback)
 ]
 
 
@@ -732,7 +740,8 @@ def test_conv_slab_kernel(dtype, case):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 64, 64, 320, 0, 320, 11), (2, 64, 64, 640, 320, 320, 11), (3, 32, 32, 960, 320, 640, 11),
                                   (1, 64, 64, 64, 0, 320, 11), (2, 32, 32, 128, 0, 320, 11), (16, 32, 32, 640, 0, 640, 0),
-                                  (16, 16, 16, 1280, 1280, 1280, 0), (3, 16, 16, 640, 0, 1280, 12)])
+                                  (16, 16, 16, 1280, 1280, 1280, 0), (3, 16, 16, 640, 0, 1280, 12),
+                                  (2, 8, 128, 320, 0, 320, 11), (2, 12, 96, 640, 320, 320, 11), (2, 96, 96, 320, 0, 320, 0)])
 def test_conv_slab_groupnorm_prologue(dtype, case):
     """GroupNorm + SiLU applied while the window is staged == tg_groupnorm followed by the plain conv, bit for bit; the
     coefficients against an fp32 reference; the heuristic (force_tile 0) takes a layer that fills the chip."""
@@ -843,6 +852,13 @@ def test_gemm_layernorm_folded(dtype, case):
     check(got, xn @ w.float().t(), dtype, f"ln-folded to_q {case}", scale=1.5)
     two = ops.linear(ops.layernorm(xd, gamma.to(dev), beta.to(dev), eps), w.to(dev))
     check(got, two.float(), dtype, f"ln-folded vs two-launch {case}", scale=2.0)
+    # the same fold with the row statistics precomputed (tg_layernorm_stats -> ln_rows)
+    rows_st = ops.layernorm_stats(xd, eps)
+    mu, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    assert torch.allclose(rows_st[:, 0].cpu(), rstd, rtol=2e-5, atol=0) and torch.allclose(rows_st[:, 1].cpu(), -rstd * mu, rtol=2e-5, atol=1e-6)
+    got2 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps, rows_st))
+    check(got2, xn @ w.float().t(), dtype, f"ln-folded (precomputed statistics) to_q {case}", scale=1.5)
     # (b) q | k | v^T split (rows_per_batch divides M)
     B = 2 if M % 2 == 0 else 1
     rows = M // B
@@ -864,6 +880,13 @@ def test_gemm_layernorm_folded(dtype, case):
     gg = ops.gemm(xd, wlg, M, N, C, geglu=True, ln=(ug, vg, eps))
     assert gg.shape == (M, N // 2)
     check(gg, y[:, :N // 2] * F.gelu(y[:, N // 2:]), dtype, f"ln-folded geglu {case}", scale=1.5)
+    gg2 = ops.gemm(xd, wlg, M, N, C, geglu=True, ln=(ug, vg, eps, rows_st))
+    check(gg2, y[:, :N // 2] * F.gelu(y[:, N // 2:]), dtype, f"ln-folded geglu (precomputed statistics) {case}", scale=1.5)
+    qk2 = torch.zeros((M, 2 * C), dtype=dtype, device=dev)
+    vt2 = torch.zeros((B, C, ldt), dtype=dtype, device=dev)
+    ops.gemm(xd, wl3, M, 3 * C, C, rows_per_batch=rows, out=qk2, n_split=2 * C, out_t=vt2, ldt=ldt, ln=(u3, v3, eps, rows_st))
+    check(qk2, ref3[:, :2 * C], dtype, f"ln-folded q|k (precomputed statistics) {case}", scale=1.5)
+    check(vt2[:, :, :rows], ref3[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, f"ln-folded v^T (precomputed statistics) {case}", scale=1.5)
 
 
 def test_gemm_layernorm_fold_argument_errors():

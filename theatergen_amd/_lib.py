@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("act", i32), ("geglu", i32), ("out_scale", f32), ("out", vp), ("ldc", i64), ("n_split", i64),
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
         ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
-        ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32),
+        ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32), ("ln_rows", vp),
     ]
 
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),
     "tg_groupnorm": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, i32, vp, vp, vp]),
     "tg_layernorm": (i32, [i32, vp, i64, i32, i64, f32, vp, vp, vp, i64, vp]),
+    "tg_layernorm_stats": (i32, [i32, vp, i64, i32, i64, f32, vp, vp]),
     "tg_groupnorm_coef": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, vp, vp]),
     "tg_geglu": (i32, [i32, vp, i64, i64, vp, vp]),
     "tg_act": (i32, [i32, vp, i64, i32, vp, vp]),

@@ -219,16 +219,17 @@ class AttnProcessor(nn.Module):
                  return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
                  return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
                  enable_flash_attn=True, _fused_residual=None, _fused_ln=None):
-        """``_fused_ln`` (internal, ``BasicTransformerBlock``): ``hidden_states`` is the block's UN-normalised stream and the
-        ``nn.LayerNorm`` given here is folded into the first projection (tg_gemm ``ln_u`` / ``ln_v``)."""
+        """``_fused_ln`` = (nn.LayerNorm, row statistics or None) (internal, ``BasicTransformerBlock``): ``hidden_states`` is the block's
+        UN-normalised stream and the norm is folded into the first projection (tg_gemm ``ln_u`` / ``ln_v`` / ``ln_rows``)."""
         _check_common(attn, hidden_states, attention_mask, attn_process_fn)
         x, B, N, C, shape4 = _to_tokens(hidden_states)
         inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
         lnq = None
         if _fused_ln is not None:
-            wl, ul, vl = attn.ln_weight("qkv" if encoder_hidden_states is None else "q", _fused_ln)
-            lnq = (ul, vl, _fused_ln.eps)
+            norm, rows = _fused_ln                           # (nn.LayerNorm, layernorm_stats tensor or None = statistics inside the kernel)
+            wl, ul, vl = attn.ln_weight("qkv" if encoder_hidden_states is None else "q", norm)
+            lnq = (ul, vl, norm.eps, rows)
         if encoder_hidden_states is None:
             # one GEMM: [Q | K] token-major + V^T per batch item
             ldt = _round8(N)
@@ -370,8 +371,9 @@ class IPAttnProcessor(nn.Module):
         enc = encoder_hidden_states.contiguous()
         k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
         if _fused_ln is not None:
-            wl, ul, vl = attn.ln_weight("q", _fused_ln)
-            q = ops.linear(x, wl, ln=(ul, vl, _fused_ln.eps))
+            norm, rows = _fused_ln
+            wl, ul, vl = attn.ln_weight("q", norm)
+            q = ops.linear(x, wl, ln=(ul, vl, norm.eps, rows))
         else:
             q = ops.linear(x, attn.to_q.weight)
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)

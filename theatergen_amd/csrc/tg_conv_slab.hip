@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // write it between the last K-step of a chunk and the first of the next (one extra barrier per 9 K-steps).
   constexpr unsigned SLAB_PAD = SLAB_BYTES > SCRATCH_BYTES ? SLAB_BYTES : SCRATCH_BYTES, W_BASE = SLAB_PAD;
   constexpr int WJ = BN / 32;                      // LDS-DMA instructions per loader wave per weight tile (8 rows x 128 B each)
-  static_assert(BM % WI == 0, "whole image rows per tile");
+  static_assert(BM % WI == 0, "whole image (or patch) rows per tile");
   static_assert(SJ <= 9, "two slab rows per thread in taps 3..5, one in taps 6..8");
   typedef typename Vec<T>::v8 V8;
 
@@ -154,15 +154,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       cfirst = sp * cps;
       nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
       nkt = nchunks * 9;
-      img = (int)(m0 / ((long)H * WI));
-      const int y0 = (int)((m0 - (long)img * H * WI) / WI);
+      // PATCH TILES (round 3): a tile is TH rows x WI columns of an image that may be WIDER than WI (p.in_w = 128 with WI = 64: SDXL's
+      // 128 x 128 level; p.in_w = 96 with WI = 32: SD-2.1's 96 x 96 level): tile_m -> (image, patch row ty, patch column tx); the
+      // window's halo columns then hold real neighbour pixels instead of padding.  p.in_w == WI is the whole-rows case of round 2.
+      const int tpr = p.in_w / WI, tpi = (H / TH) * tpr;       // patches per image row / per image
+      img = tile_m / tpi;
+      const int rem = tile_m - img * tpi;
+      const int y0 = (rem / tpr) * TH, x0 = (rem % tpr) * WI;
 #pragma unroll
       for (int j = 0; j < SJ; ++j) {
         const int sr = (tid >> 3) + 32 * j;
         const int sy = sr / SW, sx = sr - sy * SW;
-        const int iy = y0 - 1 + sy, ix = sx - 1;
-        const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI;
-        spix[j] = ok ? (img * H + iy) * WI + ix : -1;
+        const int iy = y0 - 1 + sy, ix = x0 - 1 + sx;
+        const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < p.in_w;
+        spix[j] = ok ? (img * H + iy) * p.in_w + ix : -1;
       }
       wlane = Wp + (n0 + wave * 8 + (lane >> 3)) * p.K + wchunk * 8;
     };
@@ -340,8 +345,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // every wave is past the last barrier with all its fragment reads done; the next tile's prologue leaves the slab region alone
     // (measured and dropped, scripts/dev_slab_exp.py same-process A/B: the loaders touching the tile's residual lines a few
     // K-steps ahead so that the epilogue's loads hit L2: 2 % slower; s_setprio on either role: no gain)
-    epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                   reinterpret_cast<float*>(smem) + wave * (32 * 68), S > 1 ? lbid : -1, m0, n0);
+    // token index of the wave's first pixel and the distance between its two 32-row blocks.  Whole-row tiles: m0 + 64 wave_m, 32.
+    // Patch tile (p.in_w > WI, never split): the wave's 64 pixels are 64 / WI patch rows of WI contiguous tokens each; the two blocks
+    // are 32 tokens apart inside one patch row (WI = 64) or one image row apart (WI = 32).
+    long mw = m0 + wave_m * TM * 32, mbase = m0, mstride = 32;
+    if (p.in_w != WI) {
+      const int tpr = p.in_w / WI, tpi = (H / TH) * tpr;
+      const int im = tile_m / tpi, rem = tile_m - im * tpi;
+      mw = ((long)im * H + (rem / tpr) * TH + (wave_m * 64) / WI) * p.in_w + (rem % tpr) * WI;
+      mbase = mw;
+      if (WI != 64) mstride = p.in_w;
+    }
+    epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, n0 + wave_n * TN * 32, lane, reinterpret_cast<float*>(smem) + wave * (32 * 68),
+                                   S > 1 ? lbid : -1, mbase, n0, mstride);
   }
 }
 
@@ -374,6 +390,9 @@ int launch_slab_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hi
   if (w == 64) return pro ? launch_slab<T, 64, true>(d, p, splits, st) : launch_slab<T, 64, false>(d, p, splits, st);
   if (w == 32) return pro ? launch_slab<T, 32, true>(d, p, splits, st) : launch_slab<T, 32, false>(d, p, splits, st);
   if (w == 16) return pro ? launch_slab<T, 16, true>(d, p, splits, st) : launch_slab<T, 16, false>(d, p, splits, st);
+  // patch tiles: 128-wide maps as 2 x 64 patches, 96-wide maps as 4 x 32 patches (same staging geometry as the 64 / 32-wide instances)
+  if (w == 128 && splits == 1) return pro ? launch_slab<T, 64, true>(d, p, splits, st) : launch_slab<T, 64, false>(d, p, splits, st);
+  if (w == 96 && splits == 1) return pro ? launch_slab<T, 32, true>(d, p, splits, st) : launch_slab<T, 32, false>(d, p, splits, st);
   tg_set_error("tg_gemm conv: no slab kernel for width %d", w);
   return TG_ERR_UNSUPPORTED;
 }

@@ -205,15 +205,20 @@ inline int slab_splits_of(const tg_gemm_desc* d) {
   if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return 0;
   if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
   const int w = d->out_w;
-  if (w != 16 && w != 32 && w != 64) return 0;
+  // patch tiles (round 3): 128-wide maps (SDXL level 0) as 2-row x 64-column patches, 96-wide maps (SD-2.1 level 0) as 4 x 32; never split
+  const bool patch = (w == 128 && d->out_h % 2 == 0) || (w == 96 && d->out_h % 4 == 0);
+  if (w != 16 && w != 32 && w != 64 && !patch) return 0;
   if (((long)d->out_h * w) % 128 != 0 || d->M % 128 != 0) return 0;
   const int chunks = (d->c0 + (d->a1 ? d->c1 : 0)) / BK;
   if (d->force_tile == 11) return 1;
-  if (d->force_tile == 12) return chunks >= 2 ? 2 : 0;
+  if (d->force_tile == 12) return (chunks >= 2 && !patch) ? 2 : 0;
   if (d->force_tile != 0) return 0;
-  { const char* e = getenv("TG_GEMM_FLAGS"); if (e && (strtol(e, nullptr, 0) & 128)) return 0; }
+  { const char* e = getenv("TG_GEMM_FLAGS"); const long f = e ? strtol(e, nullptr, 0) : 0; if ((f & 128) || (patch && (f & 1024))) return 0; }   // dev A/B: bit 7 no slab kernel, bit 10 no patch tiles
   const long t = (d->M / 128) * (d->N / 320);
   auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
+  // a patch-tile layer has no 128-pixel halo kernel to fall back to (the implicit-GEMM conv re-fetches every window 9 times): half a
+  // chip of slab tiles already beats it (BASELINE configs[3]: 96 x 96 x batch 2 = 144 tiles)
+  if (patch) return t >= 128 ? 1 : 0;
   if (full(t)) return 1;
   if (chunks >= 10 && full(2 * t)) return 2;
   return 0;
@@ -300,7 +305,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
   }
   p.a_coef = d->a_coef; p.a_silu = d->a_silu;
-  p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps;
+  p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps; p.ln_rows = d->ln_rows;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
@@ -410,12 +415,13 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->out_t && d->n_split % 4 == 0 && d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bad transposed-output args");
   }
   if (d->bvec) TG_CHECK(d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bvec needs rows_per_batch");
-  if (d->ln_u != nullptr || d->ln_v != nullptr) {
+  if (d->ln_u != nullptr || d->ln_v != nullptr || d->ln_rows != nullptr) {
     TG_CHECK(d->ln_u && d->ln_v, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs both ln_u and ln_v");
     TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && d->force_tile == 0,
              TG_ERR_ARG, "tg_gemm: the LayerNorm fold takes a plain single-source GEMM with a linear or GEGLU epilogue (no residual / per-batch vector / split)");
     TG_CHECK(d->K % 32 == 0 && d->N % 8 == 0 && d->ln_eps > 0.f, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs K %% 32 == 0, N %% 8 == 0, eps > 0");
-    TG_CHECK((reinterpret_cast<uintptr_t>(d->ln_u) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_v) & 15) == 0, TG_ERR_ARG, "tg_gemm: ln_u / ln_v must be 16-byte aligned");
+    TG_CHECK((reinterpret_cast<uintptr_t>(d->ln_u) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_v) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(d->ln_rows) & 7) == 0, TG_ERR_ARG, "tg_gemm: ln_u / ln_v must be 16-byte, ln_rows 8-byte aligned");
   }
   return TG_OK;
 }

@@ -43,6 +43,7 @@ struct GemmParams {
   const float* ln_u;    // LayerNorm folded into the GEMM (gemm_glds_kernel<..., LN = true>): W is pre-multiplied by gamma, the kernel takes the
   const float* ln_v;    // row statistics from its own A tiles and the epilogue forms rstd * (acc - mean * u[n]) + v[n]; u, v fp32 [N]
   float ln_eps;
+  const float* ln_rows; // LN = 2: precomputed (rstd, -rstd * mean) per row, fp32 [M][2] (tg_layernorm_stats)
   int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
                     // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
 };
@@ -138,7 +139,7 @@ __device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
 // rstd * (acc - mean * u[n]); the epilogue adds the fp32 vector v[n] = sum_k beta[k] W[n, k] + bias[n] where the bias would go.
 template <typename T, int TM, int TN, int EPI, int J0 = 0, int JN = TN, bool LN = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int part,
-                                              long pm0, long pn0) {
+                                              long pm0, long pn0, long mstride = 32) {
   typedef typename Vec<T>::v4 V4;
   if constexpr (LN) {
     // (the caller already formed rstd * (acc - mean * u) in place) + v[n]; the direct path is the cold one: V^T columns
@@ -186,7 +187,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
         const long nA = n_base - hi4 + 32 * jq;     // first packed column of the a-block (multiple of 64)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const long m = m_base + 32 * i;
+          const long m = m_base + mstride * i;
           if (m >= p.M) continue;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
     }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const long m = m_base + 32 * i;
+    const long m = m_base + mstride * i;
     const bool m_ok = m < p.M;
     long b = 0;
     if (bvecp != nullptr || p.n_split > 0) b = (m_ok ? m : 0) / p.rows_per_batch;
@@ -294,7 +295,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // x + 0 and x * 1 are exact, so this rounds the same value as the direct epilogue.
 template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES, int J0 = 0, int JN = TN, bool LN = false>
 __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr) {
+                                                  float* scr, long mstride = 32) {
   typedef typename Vec<T>::v8 V8;
   constexpr int W = JN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -322,8 +323,8 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&
   const float scale = p.out_scale;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const long m_first = m_wave + 32 * i + r0;
-    V8 add8[NPASS], res8[NPASS];
+    const long m_first = m_wave + mstride * i + r0;      // mstride: token distance between the wave tile's 32-row blocks (32 = contiguous rows;
+    V8 add8[NPASS], res8[NPASS];                         // the image width for the slab conv's 32-pixel patch rows)
     if constexpr (HAS_ADD) {
 #pragma unroll
       for (int it = 0; it < NPASS; ++it) {
@@ -540,12 +541,12 @@ __device__ __forceinline__ void epilogue_tile_reg16(const GemmParams& p, f32x16 
 // one column chunk [J0, J0 + JN) of the wave tile through the LDS bounce (or the direct path where the bounce does not apply)
 template <typename T, int TM, int TN, int EPI, int J0, int JN, bool LN = false>
 __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                   float* scr, int part, long pm0, long pn0) {
+                                                   float* scr, int part, long pm0, long pn0, long mstride = 32) {
   typedef typename Vec<T>::v4 V4;
   typedef typename Vec<T>::v8 V8;
   const int l31 = lane & 31, hi = lane >> 5;
   if (part >= 0 || !p.epi_lds || (p.n_split > 0 && n_wave + J0 * 32 >= p.n_split)) {
-    epilogue_tile<T, TM, TN, EPI, J0, JN, LN>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0);
+    epilogue_tile<T, TM, TN, EPI, J0, JN, LN>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0, mstride);
     return;
   }
   T* outp = reinterpret_cast<T*>(p.out);
@@ -607,7 +608,7 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
-            const long m = m_wave + 32 * i + it * 16 + r0;
+            const long m = m_wave + mstride * i + it * 16 + r0;
             V8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] = from_f32<T>(lo[it][e]); o[4 + e] = from_f32<T>(hi4[it][e]); }
@@ -625,13 +626,13 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
   // pass (in-kernel s_memtime: ~7200 cycles per 128x128 tile against ~1800 per K-tile)
   if constexpr (LN) {
     // the LayerNorm-fused projections carry no per-batch vector and no residual (QKV, to_q, FF1)
-    epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN, true>(p, acc, m_wave, n_wave, lane, scr);
+    epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN, true>(p, acc, m_wave, n_wave, lane, scr, mstride);
   } else if (bvecp != nullptr) {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
-    else epilogue_rows_lds<T, TM, TN, EPI, true, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
+    else epilogue_rows_lds<T, TM, TN, EPI, true, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
   } else {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
-    else epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr);
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
+    else epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
   }
 }
 
@@ -640,15 +641,15 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
 // scratch stays 32 x 68 floats and every store instruction still covers whole 128-byte rows.
 template <typename T, int TM, int TN, int EPI, bool LN = false>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr, int part, long pm0, long pn0) {
+                                                  float* scr, int part, long pm0, long pn0, long mstride = 32) {
   if constexpr (TN <= 2) {
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
   } else {
     static_assert(!LN, "the LayerNorm fold is instantiated for the 64-column wave tiles only");
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
-    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
-    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
-    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0);
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
+    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
+    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
+    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
     static_assert(TN <= 5, "wave tiles wider than 160 columns are not instantiated");
   }
 }

@@ -13,7 +13,9 @@ namespace {
 // (cdna guide rule 21), which makes the 16-lane ds_read_b128 groups conflict-free.  Out-of-range rows / conv padding
 // read from a zero page.  Double-buffered: the DMA of tile t+1 is in flight while tile t is multiplied.
 
-// LN = true (tg_gemm_ln.hip: the projections that follow a LayerNorm — attn1 QKV, attn2 to_q, FeedForward GEGLU; K = C, never
+// LN = 1 / 2 (tg_gemm_ln.hip; 1: row statistics taken inside the kernel as described below, 2: precomputed by tg_layernorm_stats and read
+// from p.ln_rows — no extra work in the K loop; which one pays is a measurement, see profiles/r3_ln_findings.md):
+// LN != 0 (tg_gemm_ln.hip: the projections that follow a LayerNorm — attn1 QKV, attn2 to_q, FeedForward GEGLU; K = C, never
 // split): LayerNorm is folded into the GEMM so that the normalised tensor and the layernorm launch do not exist.
 //   LN(x) W^T = rstd * (x (W * gamma)^T - mean * u) + v,   u[n] = sum_k (W * gamma)[n, k],  v[n] = sum_k beta[k] W[n, k] (+ bias[n])
 // W * gamma is packed once in the storage dtype and u is summed from THOSE rounded values, so acc - mean * u is exactly
@@ -43,8 +45,8 @@ template <> __device__ __forceinline__ void ln_row_sums<f16_t>(f16x8 x, float& s
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, bool LN = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu((LN && STAGES == 3 && BKT == 32) ? 3 : 2)))
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, int LN = 0>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu((LN != 0 && STAGES == 3 && BKT == 32) ? 3 : 2)))
 void gemm_glds_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
@@ -197,7 +199,7 @@ void gemm_glds_kernel(GemmParams p) {
 
   // LN: thread -> (tile row tid / 2, half tid & 1 of the row's K-tile); SCH 16-byte slots per thread and K-tile.  The slot order is
   // rotated by the row so that the 16 lanes of one ds_read_b128 phase hit 16 different 4-bank groups.
-  static_assert(!LN || (BM * 2 == NW * 64 && !CONV && TN <= 2), "LN: two threads per tile row, plain GEMM, 64-column wave tiles");
+  static_assert(LN == 0 || (BM * 2 == NW * 64 && !CONV && TN <= 2), "LN: two threads per tile row, plain GEMM, 64-column wave tiles");
   constexpr int SCH = CH / 2;
   const int srow = tid >> 1, shalf = tid & 1;
   const int srot = CH == 8 ? (srow >> 1) : (srow >> 2);
@@ -251,7 +253,7 @@ void gemm_glds_kernel(GemmParams p) {
       // the three-workgroups-per-CU variant has 168 registers per lane and not one to spare
       V8 sx[SCH];
       const T* srp = sX + buf * BM * BKT + srow * BKT + shalf * (SCH * 8);
-      if constexpr (LN && ER) {
+      if constexpr (LN == 1 && ER) {
 #pragma unroll
         for (int c = 0; c < SCH; ++c) sx[c] = *reinterpret_cast<const V8*>(srp + (((c + srot) & (SCH - 1)) << 3));
       }
@@ -291,7 +293,7 @@ void gemm_glds_kernel(GemmParams p) {
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(wf[ks][j], xf[ks][i], acc[i][j]);
       }
       if (p.flags & 2) __builtin_amdgcn_s_setprio(0);
-      if constexpr (LN) {
+      if constexpr (LN == 1) {
         if constexpr (!ER) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -311,21 +313,30 @@ void gemm_glds_kernel(GemmParams p) {
     }
   }
 
-  if constexpr (LN) {
+  if constexpr (LN != 0) {
     // row statistics -> (a, b) = (rstd, -rstd * mean) and this tile's u[n] into LDS behind the epilogue scratch (the operand stages
     // are dead); then, still in accumulator layout (lane & 31 = row: a, b are per-lane scalars; a register quad = 4 consecutive
     // columns: one broadcast ds_read_b128 of u), acc <- a * acc + b * u = rstd * (acc - mean * u), in place
     static_assert((size_t)(NW * 32 * (TN * 32 + 4) + 2 * BM + BN) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "LN: row statistics must fit the operand stages");
     float* lnrow = reinterpret_cast<float*>(smem) + NW * 32 * (TN * 32 + 4);
     float* lnu = lnrow + 2 * BM;
-    const float s_all = ln_s + __shfl_xor(ln_s, 1, 64), q_all = ln_q + __shfl_xor(ln_q, 1, 64);
-    const float inv_k = 1.0f / (float)p.K;
-    const float mean = s_all * inv_k;
-    const float var = fmaxf(__builtin_fmaf(-mean, mean, q_all * inv_k), 0.f);
-    const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
-    if (shalf == 0) {
-      lnrow[2 * srow] = rstd;
-      lnrow[2 * srow + 1] = -rstd * mean;
+    if constexpr (LN == 1) {
+      const float s_all = ln_s + __shfl_xor(ln_s, 1, 64), q_all = ln_q + __shfl_xor(ln_q, 1, 64);
+      const float inv_k = 1.0f / (float)p.K;
+      const float mean = s_all * inv_k;
+      const float var = fmaxf(__builtin_fmaf(-mean, mean, q_all * inv_k), 0.f);
+      const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+      if (shalf == 0) {
+        lnrow[2 * srow] = rstd;
+        lnrow[2 * srow + 1] = -rstd * mean;
+      }
+    } else {
+      if (tid < BM) {
+        const long m = m0 + tid;
+        float2 ab = make_float2(1.f, 0.f);
+        if (m < p.M) ab = *reinterpret_cast<const float2*>(p.ln_rows + 2 * m);
+        *reinterpret_cast<float2*>(lnrow + 2 * tid) = ab;
+      }
     }
     if (tid < BN / 4) {
       const long n4 = n0 + 4 * tid;

@@ -6,16 +6,22 @@
 
 namespace {
 
-template <typename T, int STAGES, int BKT, int EPI>
-int launch_ln(const GemmParams& p, int grid, hipStream_t st) {
+template <typename T, int STAGES, int BKT, int EPI, int MODE>
+int launch_ln_mode(const GemmParams& p, int grid, hipStream_t st) {
   constexpr int BM = 128, BN = 128;
   const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(T);
-  auto k = gemm_glds_kernel<T, BM, BN, 2, 2, false, STAGES, BKT, EPI, true>;
+  auto k = gemm_glds_kernel<T, BM, BN, 2, 2, false, STAGES, BKT, EPI, MODE>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();
   return TG_OK;
+}
+
+template <typename T, int STAGES, int BKT, int EPI>
+int launch_ln(const GemmParams& p, int grid, hipStream_t st) {
+  // statistics precomputed by tg_layernorm_stats (ln_rows) or taken from the staged A tiles inside the kernel
+  return p.ln_rows != nullptr ? launch_ln_mode<T, STAGES, BKT, EPI, 2>(p, grid, st) : launch_ln_mode<T, STAGES, BKT, EPI, 1>(p, grid, st);
 }
 
 template <typename T>

@@ -402,9 +402,11 @@ int gn_nblk(int batch, long hw) {
 // (MAXC of them) of its row: at C = 320 a row is 40 chunks, so one-row-per-wave left 24 of 64 lanes idle; with LPR = 8
 // every lane carries 5 chunks.  Two-pass (mean, then centred sum of squares) in registers, reductions by xor-shuffles
 // inside the LPR-lane group.
+// stats != NULL: statistics only — (rstd, -rstd * mean) per row, fp32 [rows][2], for the LayerNorm-folded projections (tg_gemm ln_rows):
+// the same two-pass mean / centred variance as the normalising kernel, half its traffic (no output tensor).
 template <typename T, int LPR, int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, int C, long ldx, float eps, const T* gamma,
-                                                        const T* beta, T* out, long ldo) {
+                                                        const T* beta, T* out, long ldo, float* stats = nullptr) {
   typedef typename Vec<T>::v8 V8;
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -439,6 +441,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, i
   for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q / (float)C + eps);
   if (!row_ok) return;
+  if (stats != nullptr) {
+    if (l == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -rstd * mean);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = l + LPR * i;
@@ -461,11 +467,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long rows, i
 
 template <typename T>
 int launch_ln(const void* x, long rows, int C, long ldx, float eps, const void* gamma, const void* beta, void* out,
-              long ldo, hipStream_t st) {
+              long ldo, hipStream_t st, float* stats = nullptr) {
   const int cpr = C / 8;
 #define LN_CASE(LPR, MAXC)                                                                                              \
   hipLaunchKernelGGL((layernorm_kernel<T, LPR, MAXC>), dim3((unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
-                     dim3(256), 0, st, (const T*)x, rows, C, ldx, eps, (const T*)gamma, (const T*)beta, (T*)out, ldo)
+                     dim3(256), 0, st, (const T*)x, rows, C, ldx, eps, (const T*)gamma, (const T*)beta, (T*)out, ldo, stats)
   if (cpr <= 8) LN_CASE(8, 1);
   else if (cpr <= 40) LN_CASE(8, 5);          // C <= 320
   else if (cpr <= 80) LN_CASE(16, 5);         // C <= 640
@@ -566,4 +572,13 @@ extern "C" int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == TG_BF16) return launch_ln<bf16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
   return launch_ln<f16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
+}
+
+extern "C" int tg_layernorm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_layernorm_stats: bad dtype");
+  TG_CHECK(x && stats && rows > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * 8 && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, TG_ERR_ARG,
+           "tg_layernorm_stats: bad args rows=%lld C=%d", (long long)rows, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == TG_BF16) return launch_ln<bf16_t>(x, rows, C, ldx, eps, nullptr, nullptr, nullptr, 0, st, stats);
+  return launch_ln<f16_t>(x, rows, C, ldx, eps, nullptr, nullptr, nullptr, 0, st, stats);
 }

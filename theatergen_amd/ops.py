@@ -106,8 +106,12 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.pad_mode = int(pad_mode)
     d.a_coef = _ptr(a_coef)
     d.a_silu = 1 if a_silu else 0
-    if ln is not None:                  # (u fp32 [N], v fp32 [N], eps): LayerNorm of the A rows folded into this GEMM (``pack_ln_linear``)
-        d.ln_u, d.ln_v, d.ln_eps = _ptr(ln[0]), _ptr(ln[1]), float(ln[2])
+    if ln is not None:                  # (u fp32 [N], v fp32 [N], eps[, rows]): LayerNorm of the A rows folded into this GEMM (``pack_ln_linear``);
+        d.ln_u, d.ln_v, d.ln_eps = _ptr(ln[0]), _ptr(ln[1]), float(ln[2])     # rows = ``layernorm_stats`` output, None: taken inside the kernel
+        if len(ln) > 3 and ln[3] is not None:
+            if ln[3].dtype != torch.float32 or ln[3].numel() != 2 * M or not ln[3].is_contiguous():
+                raise RuntimeError("gemm: ln rows must be the contiguous fp32 [M, 2] tensor of layernorm_stats")
+            d.ln_rows = _ptr(ln[3])
     if plan_only:
         tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)))
@@ -280,6 +284,15 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
         out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
     _lib.check(_lib.lib().tg_layernorm(_dt(x), _ptr(x), rows, Cc, x.stride(0), float(eps), _ptr(gamma), _ptr(beta), _ptr(out),
                                        out.stride(0), _stream()))
+    return out
+
+
+def layernorm_stats(x, eps=1e-5):
+    """fp32 [rows, 2] = (rstd, -rstd * mean) per row: the statistics half of ``layernorm`` (no normalised tensor), input of ``gemm(ln=...)``"""
+    _need_cuda(x)
+    rows, Cc = x.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tg_layernorm_stats(_dt(x), _ptr(x), rows, Cc, x.stride(0), float(eps), _ptr(out), _stream()))
     return out
 
 

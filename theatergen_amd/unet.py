@@ -71,7 +71,12 @@ class _Packed:
 # dev switch: TG_NO_GN_FUSE=1 keeps GroupNorm and conv two ops everywhere (A/B of the fused window staging)
 _FUSE_GN = not os.environ.get("TG_NO_GN_FUSE")
 # dev switch: TG_NO_LN_FUSE=1 keeps LayerNorm a launch of its own in front of the q|k|v / to_q / GEGLU projections
-_FUSE_LN = not os.environ.get("TG_NO_LN_FUSE")
+# TG_LN_MODE bits: 1 = fold norm1 / norm2 into attn1 q|k|v / attn2.to_q, 2 = fold norm3 into the GEGLU GEMM, 4 = row statistics from a
+# statistics-only pass (tg_layernorm_stats) instead of inside the GEMM.  0 = LayerNorm launches (round 2).
+# Default 1, by same-box graph-replay A/B (profiles/r3_ln_findings.md): attention-only fold with in-kernel statistics +1.06 % images/s;
+# folding norm3 too costs the FeedForward its 256 x 256 big-tile GEGLU kernel (-0.4 % overall); a separate statistics pass is slower
+# than taking them from the staged tiles (+0.75 % instead of +1.06 %).
+_LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_MODE", "1"))
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
 
@@ -173,15 +178,17 @@ class FeedForward(nn.Module):
         self._p = _Packed()
 
     def run(self, x2d, residual, ln=None):
-        """``ln`` (a ``nn.LayerNorm``): ``x2d`` is the un-normalised stream and the norm is folded into the GEGLU GEMM"""
+        """``ln`` = (nn.LayerNorm, row statistics or None): ``x2d`` is the un-normalised stream and the norm is folded into the GEGLU GEMM"""
         proj = self.net[0].proj
         M, K = x2d.shape
         if ln is not None:
+            norm, rows = ln
+
             def build():
                 wp, bp = pack_geglu(proj.weight.detach(), proj.bias.detach())
-                return pack_ln_linear(wp, bp, ln.weight, ln.bias)
-            wl, ul, vl = self._p.get("geglu_ln", [proj.weight, proj.bias, ln.weight, ln.bias], build)
-            g = ops.gemm(x2d, wl, M, wl.shape[0], K, geglu=True, ln=(ul, vl, ln.eps))
+                return pack_ln_linear(wp, bp, norm.weight, norm.bias)
+            wl, ul, vl = self._p.get("geglu_ln", [proj.weight, proj.bias, norm.weight, norm.bias], build)
+            g = ops.gemm(x2d, wl, M, wl.shape[0], K, geglu=True, ln=(ul, vl, norm.eps, rows))
         elif M > 64 and (proj.weight.shape[0] // 2) % 32 == 0:
             # GEGLU fused into the C -> 8C GEMM epilogue: the [M, 8C] pre-activation is never written
             wp, bp = self._p.get("geglu", [proj.weight, proj.bias], lambda: pack_geglu(proj.weight.detach(), proj.bias.detach()))
@@ -205,12 +212,12 @@ class BasicTransformerBlock(nn.Module):
 
     @staticmethod
     def _call(attn, x2d, b, n, enc, residual, kwargs, ln=None):
-        """``ln`` None: ``x2d`` is the normalised input.  ``ln`` = the block's ``nn.LayerNorm``: ``x2d`` is the un-normalised
-        stream; our own processors fold the norm into their first projection, any other processor gets ``tg_layernorm`` first."""
+        """``ln`` None: ``x2d`` is the normalised input.  ``ln`` = (the block's ``nn.LayerNorm``, row statistics or None): ``x2d`` is the
+        un-normalised stream; our own processors fold the norm into their first projection, any other processor gets ``tg_layernorm`` first."""
         proc = attn.processor
         ours = isinstance(proc, (AttnProcessor, IPAttnProcessor, CNAttnProcessor))
         if ln is not None and not ours:
-            x2d, ln = ops.layernorm(x2d, ln.weight, ln.bias, ln.eps), None
+            x2d, ln = ops.layernorm(x2d, ln[0].weight, ln[0].bias, ln[0].eps), None
         x3 = x2d.reshape(b, n, -1)
         if isinstance(proc, (AttnProcessor, IPAttnProcessor)) and attn.rescale_output_factor == 1.0 \
                 and not attn.residual_connection and not kwargs.get("return_attntion_probs"):
@@ -218,7 +225,7 @@ class BasicTransformerBlock(nn.Module):
         if isinstance(proc, CNAttnProcessor):
             return proc(attn, x3, encoder_hidden_states=enc, _fused_residual=residual, _fused_ln=ln).reshape(b * n, -1)
         if ln is not None:
-            x3 = ops.layernorm(x2d, ln.weight, ln.bias, ln.eps).reshape(b, n, -1)
+            x3 = ops.layernorm(x2d, ln[0].weight, ln[0].bias, ln[0].eps).reshape(b, n, -1)
         # foreign processor: plain diffusers protocol, residual added afterwards
         out = attn(x3, encoder_hidden_states=enc, **kwargs)
         if isinstance(out, tuple):
@@ -227,11 +234,23 @@ class BasicTransformerBlock(nn.Module):
 
     def run(self, x2d, b, n, enc, ca_kwargs):
         M, C = x2d.shape
-        if _FUSE_LN and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
-            # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor, no layernorm launch
-            x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=self.norm1)
-            x2d = self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=self.norm2)
-            return self.ff.run(x2d, x2d, ln=self.norm3)
+        if _LN_MODE and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
+            # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor.  Row statistics: a
+            # statistics-only pass (half the layernorm kernel's traffic) or taken inside the GEMM from its own A tiles
+            def folded(norm, t):
+                return (norm, ops.layernorm_stats(t, norm.eps) if _LN_MODE & 4 else None)
+            if _LN_MODE & 1:
+                x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d))
+                x2d = self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=folded(self.norm2, x2d))
+            else:
+                h = ops.layernorm(x2d, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+                x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
+                h = ops.layernorm(x2d, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                x2d = self._call(self.attn2, h, b, n, enc, x2d, ca_kwargs)
+            if _LN_MODE & 2:
+                return self.ff.run(x2d, x2d, ln=folded(self.norm3, x2d))
+            h = ops.layernorm(x2d, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            return self.ff.run(h, x2d)
         h = ops.layernorm(x2d, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
         h = ops.layernorm(x2d, self.norm2.weight, self.norm2.bias, self.norm2.eps)
