@@ -459,6 +459,8 @@ def bench_sdxl(args):
         for _ in range(3):
             tok = rs(clip_hidden)
         res_ms = _ev_ms(lambda: rs(clip_hidden), iters=20)
+        rs.graphed(clip_hidden)                               # capture
+        res_graph_ms = _ev_ms(lambda: rs.graphed(clip_hidden), iters=20)
     text = (torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.5).to(device, dtype)
     enc = torch.cat([text, torch.stack([tok[1], tok[0]])], dim=1).contiguous()    # negatives first: uncond tokens on row 0
     added = {"text_embeds": torch.randn(2, 1280, generator=g).to(device, dtype),
@@ -491,6 +493,7 @@ def bench_sdxl(args):
                    "plan": "sdxl", "ddim_steps": steps},
         "images_per_s": round(1.0 / (s_step * steps), 4),
         "resampler_us_per_character": round(res_ms * 1e3, 1),
+        "resampler_us_per_character_graph_replay": round(res_graph_ms * 1e3, 1),
         "resampler_note": "SDXL-Plus Resampler (depth 4, 20 heads x 64, 16 queries, 257 CLIP tokens), batch 2 = cond + zero-image uncond "
                           "(ip_adapter.py:347-359): 2 x 5.13 GMAC",
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
@@ -679,7 +682,7 @@ def other_configs_leg(args):
         try:
             r = fn(a)
             keep = ("metric", "value", "unit", "dtype", "images_per_s", "per_step_ms", "latent_backward_guidance_iteration_ms",
-                    "resampler_us_per_character", "guidance")
+                    "resampler_us_per_character", "resampler_us_per_character_graph_replay", "guidance")
             c = {k: r[k] for k in keep if k in r}
             c["workload"] = r["config"]["workload"]
             c["roofline"] = r["roofline"]

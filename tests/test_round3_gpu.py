@@ -353,3 +353,22 @@ def test_guidance_plan_cached_on_device_and_graph_capturable():
     assert lg.item() == le.item(), (lg.item(), le.item())
     for k in keys:
         assert torch.equal(gg[k], ge[k])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resampler_graph_replay_equals_eager(dtype):
+    """the Resampler (``IPAdapterPlus.get_image_embeds``' image_proj_model, ~40 launch-bound kernels) replayed from
+    a hipGraph gives the bits of the eager launches, for new inputs of the captured shape and for a second shape."""
+    from theatergen_amd import weights as W
+    from theatergen_amd.resampler import Resampler
+    kw = dict(dim=256, depth=2, dim_head=64, heads=4, num_queries=16, embedding_dim=320, output_dim=512, ff_mult=4)
+    rs = Resampler(**kw)
+    rs.load_state_dict(W.random_resampler_state_dict(seed=7, **kw))
+    rs = rs.to(DEV, dtype)
+    g = torch.Generator().manual_seed(3)
+    for shape in ((2, 257, 320), (2, 257, 320), (1, 50, 320), (2, 257, 320)):
+        x = torch.randn(*shape, generator=g).to(DEV, dtype)
+        want = rs(x)
+        got = rs.graphed(x)
+        assert got.shape == want.shape and torch.equal(got, want), shape
+    assert len(rs._graphed._graphs) == 2

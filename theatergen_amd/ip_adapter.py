@@ -165,8 +165,11 @@ class IPAdapterPlus(IPAdapter):
             uncond_clip_image_embeds = self.image_encoder(torch.zeros_like(clip_image), output_hidden_states=True).hidden_states[-2]
         if uncond_clip_image_embeds is None:
             raise RuntimeError("IPAdapterPlus.get_image_embeds needs uncond_clip_image_embeds (CLIP hidden states of a zero image)")
-        image_prompt_embeds = self.image_proj_model(clip_image_embeds.to(self.device, dtype=self.dtype))
-        uncond_image_prompt_embeds = self.image_proj_model(uncond_clip_image_embeds.to(self.device, dtype=self.dtype))
+        # the Resampler is ~40 launch-bound kernels per call: replayed from a hipGraph when it has one to offer (Resampler.graphed)
+        proj = getattr(self.image_proj_model, "graphed", None) if getattr(self, "use_graph", True) else None
+        proj = proj if proj is not None else self.image_proj_model
+        image_prompt_embeds = proj(clip_image_embeds.to(self.device, dtype=self.dtype))
+        uncond_image_prompt_embeds = proj(uncond_clip_image_embeds.to(self.device, dtype=self.dtype))
         return image_prompt_embeds, uncond_image_prompt_embeds
 
 
