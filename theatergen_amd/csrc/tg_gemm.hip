@@ -106,6 +106,14 @@ Plan make_plan(const tg_gemm_desc* d) {
       const char* mk = getenv("TG_T7_MAXK");           // dev knob
       const long maxk = mk ? strtol(mk, nullptr, 0) : 640;
       if (t == 0 && d->mode == 0 && !d->geglu && K <= maxk && K % 32 == 0) t = 6;
+      // round 3 (dev switch TG_T7_FIT=1, A/B in profiles/r3_gemm_findings.md): longer-K plain GEMMs whose 128x128 tile count fits ONE
+      // round of the three-workgroup variant (768 slots) but not one round of the two-workgroup one (512): 16384 x 640 x 2560
+      // (FeedForward net.2 of the 32 x 32 level) is 640 tiles = a full round + a quarter-filled one on 512 slots
+      {
+        const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+        const char* fit = getenv("TG_T7_FIT");
+        if (fit && fit[0] == '1' && t == 0 && d->mode == 0 && !d->geglu && K % 32 == 0 && t128 > 512 && t128 <= 768) t = 6;
+      }
     }
     if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
