@@ -151,9 +151,28 @@ def roofline_leg(unet, engine):
             break
         except (OSError, KeyError, ValueError):
             continue
-    alg = sum(2.0 * (r["M"] * r["K"] + r["N"] * r["K"] + r["M"] * r["N"]) for r in recs if r["kernel"] == name) / top["launches"]
+    # algorithmic bytes per launch: operands once + result once (+ the residual where the layer has one is NOT counted); a 3x3 conv reads
+    # its input ONCE (M x C, not the M x 9C of the implicit GEMM)
+    def alg_bytes(r):
+        a_elems = r["M"] * (r["K"] // 9 if "conv" in r["kernel"] else r["K"])
+        return 2.0 * (a_elems + r["N"] * r["K"] + r["M"] * r["N"])
+    alg = sum(alg_bytes(r) for r in recs if r["kernel"] == name) / top["launches"]
+    avg_s = top["ms"] / top["launches"] * 1e-3
+    # the other roof: HBM-side rate of the same launches, from the counters (traffic) and from the algorithmic bytes
+    hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic": round(alg / avg_s / 1e9, 1), "algorithmic_frac": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+           "measured": round(traffic / avg_s / 1e9, 1) if traffic else None,
+           "measured_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "traffic_over_algorithmic": round(traffic / alg, 3) if traffic else None}
+    # the 128x128 LDS-DMA GEMM is two kernel symbols since round 3 (plain, and the LayerNorm-folded instances): their sum, so that the
+    # family that was round 2's dominant kernel stays comparable
+    fam = [v for k, v in by.items() if k.startswith("gemm_glds_kernel<plain")]
+    fam_ms, fam_fl, fam_n = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam), sum(v["launches"] for v in fam)
+    family = {"kernels": "gemm_glds_kernel<plain,*> + gemm_glds_kernel<plain+ln,*>", "launches": fam_n, "ms": round(fam_ms, 3),
+              "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms else None,
+              "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if fam_ms else None}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg),
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg), "hbm": hbm,
+            "gemm_glds_family": family,
             "kernel": name, "launches_per_cfg_call": top["launches"], "cfg_batch_of_measured_call": 2 * engine.n_img,
             "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
             "flop_per_launch_avg": top["flops"] / top["launches"],

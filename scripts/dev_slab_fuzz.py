@@ -9,15 +9,15 @@ random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_ok = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     dt = random.choice([torch.bfloat16, torch.float16])
-    w = random.choice([16, 32, 64])
-    rows_per_tile = 128 // w
-    h = rows_per_tile * random.randint(1, max(1, 64 // rows_per_tile // 2))
+    w = random.choice([16, 32, 64, 96, 128, 96, 128])     # 96 / 128: patch tiles (round 3): 4 x 32 and 2 x 64 patches
+    rows_per_tile = {96: 4, 128: 2}.get(w, 128 // w)
+    h = rows_per_tile * random.randint(1, max(1, (64 if w <= 64 else 24) // rows_per_tile // 2))
     B = random.randint(1, 5)
     cin = 64 * random.randint(1, 6)
     c1 = 64 * random.randint(0, 3) if random.random() < 0.4 else 0
     cout = 320 * random.randint(1, 3)
     ft = random.choice([11, 12])
-    if ft == 12 and (cin + c1) // 64 < 2:
+    if ft == 12 and ((cin + c1) // 64 < 2 or w > 64):      # patch tiles are never split
         ft = 11
     g = torch.Generator().manual_seed(it)
     M = B * h * w

@@ -26,8 +26,8 @@ def _glds128(n):
 
 FAMILIES = [
     # labels = the kernel labels of bench.py's roofline leg (ops.gemm profiling mode), so that `roofline.traffic` finds its kernel
-    ("gemm_glds_kernel<plain,128x128>", lambda n: _glds128(n) and "Li0EEvNS" in n),
-    ("gemm_glds_kernel<plain+ln,128x128>", lambda n: _glds128(n) and ("Li1EEvNS" in n or "Li2EEvNS" in n)),
+    ("gemm_glds_kernel<plain,128x128>", lambda n: _glds128(n) and "ELi0EEEvNS_10GemmParamsE" in n),
+    ("gemm_glds_kernel<plain+ln,128x128>", lambda n: _glds128(n) and ("ELi1EEEvNS_10GemmParamsE" in n or "ELi2EEEvNS_10GemmParamsE" in n)),
     ("bt_gemm_kernel<256x256>", lambda n: "bt_gemm_kernel" in n and "Li256ELi256E" in n),
     ("gemm_glds_kernel<conv,128x128>", lambda n: "gemm_glds_kernel" in n and "Li128ELi128ELi2ELi2ELb1E" in n),
     ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n),

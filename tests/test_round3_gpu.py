@@ -372,3 +372,45 @@ def test_resampler_graph_replay_equals_eager(dtype):
         got = rs.graphed(x)
         assert got.shape == want.shape and torch.equal(got, want), shape
     assert len(rs._graphed._graphs) == 2
+
+
+def test_sdxl_custom_pipeline_loop_with_gated_ip_scale_vs_oracle():
+    """ip_adapter/custom_pipelines.py:308-367 on the tiny SDXL-shaped plan (text_time conditioning, 3 levels): embeddings in, latents out,
+    ``control_guidance_start / end`` gating the IP scale per step, against the oracle loop; the final scale is the gated one, as in
+    the reference (its loop leaves the last ``set_scale`` in place)."""
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from theatergen_amd import config
+    from theatergen_amd.custom_pipelines import StableDiffusionXLCustomPipeline
+    dtype = torch.float16
+    cfg = config.tiny(xl=True)
+    unet, sd_r = _build(cfg, dtype)
+    g = torch.Generator().manual_seed(61)
+    n, steps, T, gs = 1, 5, 4, 5.0
+    ctx = cfg.cross_attention_dim
+    pos, neg = torch.randn(n, 77 + T, ctx, generator=g) * 0.5, torch.randn(n, 77 + T, ctx, generator=g) * 0.5
+    pooled, npooled = torch.randn(n, 64, generator=g), torch.randn(n, 64, generator=g)
+    lat = torch.randn(n, 4, 16, 16, generator=g)
+    pipe = StableDiffusionXLCustomPipeline(unet)
+    pipe.set_scale(0.6)
+    seen = []
+    out = pipe(prompt_embeds=pos.to(DEV, dtype), negative_prompt_embeds=neg.to(DEV, dtype), pooled_prompt_embeds=pooled.to(DEV, dtype),
+               negative_pooled_prompt_embeds=npooled.to(DEV, dtype), height=128, width=128, num_inference_steps=steps, guidance_scale=gs,
+               latents=lat, control_guidance_start=0.2, control_guidance_end=0.8, callback=lambda i, t, x: seen.append((i, t)),
+               original_size=(128, 128), target_size=(128, 128)).images
+    assert [i for i, _ in seen] == list(range(steps))
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(steps)
+    assert [t for _, t in seen] == osch.timesteps.tolist()
+    enc = torch.cat([neg, pos]).to(dtype).float()
+    added = {"text_embeds": torch.cat([npooled, pooled]).to(dtype).float(), "time_ids": torch.tensor([[128., 128., 0., 0., 128., 128.]] * 2)}
+    ref = lat.clone()
+    for i, t in enumerate(osch.timesteps.tolist()):
+        s = 0.0 if (i / steps < 0.2 or (i + 1) / steps > 0.8) else 0.6
+        npred = ou.unet_forward(cfg, sd_r, torch.cat([ref] * 2).to(dtype).float(), t, enc, ip_scale=s, num_tokens=T, added_cond_kwargs=added)
+        ref = oddim.step_epilogue(osch, npred, t, ref, gs)
+    pm.check(out, ref, "SDXL custom pipeline loop, gated IP scale, fp16 tiny plan", 7.5e-3, 1.5e-2)
+    with pytest.raises(NotImplementedError):
+        pipe(prompt="a cat")
+    with pytest.raises(NotImplementedError):
+        pipe(prompt_embeds=pos, negative_prompt_embeds=neg, pooled_prompt_embeds=pooled, negative_pooled_prompt_embeds=npooled, guidance_rescale=0.7)
