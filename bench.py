@@ -151,11 +151,12 @@ def roofline_leg(unet, engine):
             break
         except (OSError, KeyError, ValueError):
             continue
-    # algorithmic bytes per launch: operands once + result once (+ the residual where the layer has one is NOT counted); a 3x3 conv reads
-    # its input ONCE (M x C, not the M x 9C of the implicit GEMM)
+    # algorithmic bytes per launch: operands once + result once + the residual tensor where the layer adds one; a 3x3 conv reads its
+    # input ONCE (M x C, not the M x 9C of the implicit GEMM); the fused GEGLU writes N / 2 columns
     def alg_bytes(r):
         a_elems = r["M"] * (r["K"] // 9 if "conv" in r["kernel"] else r["K"])
-        return 2.0 * (a_elems + r["N"] * r["K"] + r["M"] * r["N"])
+        n_out = r.get("n_out", r["N"])
+        return 2.0 * (a_elems + r["N"] * r["K"] + r["M"] * n_out + (r["M"] * n_out if r.get("has_res") else 0))
     alg = sum(alg_bytes(r) for r in recs if r["kernel"] == name) / top["launches"]
     avg_s = top["ms"] / top["launches"] * 1e-3
     # the other roof: HBM-side rate of the same launches, from the counters (traffic) and from the algorithmic bytes

@@ -146,7 +146,8 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     else:
         kname = f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
     _gemm_profile.append(dict(kernel=kname, splits=sp.value,
-                              M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1)))
+                              M=int(M), N=int(N), K=int(K), flops=2.0 * M * N * K, events=(e0, e1),
+                              has_res=res is not None, n_out=int(n_main if n_split <= 0 else N)))
     return out
 
 
