@@ -1,4 +1,4 @@
-"""gpurun_out/parity_metrics.jsonl (written by tests/parity_metrics.py during `pytest -m gpu`) -> profiles/r2_parity_metrics.json:
+"""gpurun_out/parity_metrics.jsonl (written by tests/parity_metrics.py during `pytest -m gpu`) -> profiles/r3_parity_metrics.json (argv[3] = another name):
 single-kernel checks condensed to the worst case per dtype, every multi-kernel comparison listed with its tolerance."""
 import json
 import os
@@ -19,5 +19,6 @@ for key, tag in (("single_kernel_bf16", ".bfloat16"), ("single_kernel_fp16", ".f
         out[key] = {"n": len(ks), "worst_rel_l2": max(r["rel_l2"] for r in ks), "worst_max_rel": max(r["max_rel"] for r in ks)}
 out["comparisons"] = [{k: r[k] for k in ("what", "rel_l2", "max_rel", "l2_tol", "max_tol") if k in r}
                       for r in recs if not r["what"].startswith("kernel:")]
-json.dump(out, open(os.path.join(R, "profiles", "r2_parity_metrics.json"), "w"), indent=1)
+name = sys.argv[3] if len(sys.argv) > 3 else "r3_parity_metrics.json"
+json.dump(out, open(os.path.join(R, "profiles", name), "w"), indent=1)
 print(out.get("single_kernel_bf16"), out.get("single_kernel_fp16"), len(out["comparisons"]))
