@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 
 inline bool halo_eligible(const tg_gemm_desc* d);
 
+// 128x128 tile counts up to this take the 64x64 tile (4x the blocks, three per CU).  128 was fitted on the SD-1.5 bench (CFG batch 16);
+// dev knob TG_T64_MAX for the batch-2 plans (BASELINE configs[3] / [4]: 2048 x 1280 x 1280 is 160 tiles = a third of the chip)
+inline long t64_max_tiles() {
+  const char* e = getenv("TG_T64_MAX");
+  return e ? strtol(e, nullptr, 0) : 128;
+}
+
 Plan make_plan(const tg_gemm_desc* d) {
   // Tile: measured on MI355X over the UNet's shapes (scripts/dev_gemm_bench.py) the 128x128 tile with 2 blocks per CU is
   // the best or within a few % of the best everywhere; skinny problems (one dimension <= 64) take the matching tile.
@@ -96,7 +103,7 @@ Plan make_plan(const tg_gemm_desc* d) {
     else if (M <= 64 && N <= 64) t = 1;  // 64 x 64
     // few 128x128 tiles (the 8x8 level, M = 1024): 64x64 tiles put 4x as many blocks on the chip (3 per CU):
     // 1024x1280x1280 22 -> 13 us, K = 5120 69 -> 39 us (scripts/dev_tile_sweep.py)
-    else if (d->mode == 0 && !d->geglu && ((M + 127) / 128) * ((N + 127) / 128) <= 128) t = 1;
+    else if (d->mode == 0 && !d->geglu && ((M + 127) / 128) * ((N + 127) / 128) <= t64_max_tiles()) t = 1;
     // dev A/B (TG_GEMM_FLAGS bit 14): short-K plain GEMMs on the 32-wide K stages (three co-resident workgroups per CU)
     // short-K plain GEMMs (K <= 640: the 64x64 / 32x32 levels' attention and proj_in / proj_out projections) take the 128x128 tile
     // on three 32-wide K stages: 48 KB of LDS = THREE co-resident workgroups per CU instead of two, more prologue / epilogue
