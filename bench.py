@@ -98,6 +98,9 @@ def gemm_by_kernel(step_fn):
         step_fn()
         torch.cuda.synchronize()
         recs = ops.gemm_profile_stop()
+    if os.environ.get("TG_DUMP_RECS"):                   # dev: per-launch records (shape, kernel, ms) of this plan's step
+        with open(os.environ["TG_DUMP_RECS"], "w") as f:
+            json.dump(recs, f)
     by = {}
     for r in recs:
         k = by.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0))

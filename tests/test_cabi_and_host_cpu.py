@@ -347,6 +347,20 @@ def test_gemm_planner_kernel_choice(monkeypatch):
     assert plan(conv(16, 64, 64, 320, 320, stride=2))[3] == 1
     assert plan(conv(16, 64, 64, 128, 128))[3] != 4
     assert plan(conv(2, 64, 64, 320, 320, force_tile=11)) == (128, 320, 1, 4)
+    # round 3, second pass: the small-M levels of the batch-2 plans that used to fall to the implicit-GEMM conv take the slab kernel on
+    # generic patch tiles with a K split over the channel chunks (one round of work items on the 256 CUs); halo-eligible layers stay
+    assert plan(conv(2, 48, 48, 640, 640)) == (128, 320, 3, 4)               # SD-2.1 level 1: 72 tiles x 3
+    assert plan(conv(2, 48, 48, 640, 640, c1=640)) == (128, 320, 3, 4)
+    assert plan(conv(2, 24, 24, 1280, 1280))[2:] == (5, 4)                   # SD-2.1 level 2: two 8 x 8 patches per tile, 36 tiles x 5
+    assert plan(conv(2, 32, 32, 1280, 1280)) == (128, 320, 4, 4)             # SDXL level 2 at batch 2: 64 tiles x 4
+    d = conv(2, 32, 32, 1280, 1280)
+    assert h.tg_gemm_workspace_bytes(C.byref(d)) == 16 * 4 * 4 * 128 * 320 * 4
+    assert plan(conv(2, 12, 12, 1280, 1280))[3] == 1                         # 12 x 12: no patch geometry, weight-streaming bound anyway
+    assert plan(conv(16, 8, 8, 1280, 1280))[3] == 2                          # the 8 x 8 level keeps the halo kernel (measured)
+    assert plan(conv(2, 8, 8, 1280, 1280))[3] == 1                           # 4 tiles: never enough work items
+    monkeypatch.setenv("TG_GEMM_FLAGS", "2048")                               # dev switch: the round-3 first-pass rules only
+    assert plan(conv(2, 48, 48, 640, 640))[3] == 1
+    monkeypatch.delenv("TG_GEMM_FLAGS")
     # the dev switch turns the slab kernel off
     monkeypatch.setenv("TG_GEMM_FLAGS", "128")
     assert plan(conv(16, 64, 64, 320, 320))[3] == 2

@@ -692,6 +692,20 @@ SLAB_CASES = [
     (2, 12, 96, 320, 320, 320, 11),     # two images x (3 x 3) patches, two sources
     (2, 128, 128, 320, 0, 320, 0),      # BASELINE configs[4] level 0 at batch 2: 256 tiles, taken by the heuristic
     (2, 96, 96, 320, 0, 320, 0),        # BASELINE configs[3] level 0 at batch 2: 144 tiles, taken by the heuristic (no 128-pixel halo fallback)
+    # round 3, second pass: generic patches (8th entry = K splits over the channel chunks: force_split_k with force_tile 11, or the
+    # heuristic's expected choice with force_tile 0).  16-pixel patch rows (48 = 3 x 16, 80 = 5 x 16): a 32-row MFMA block is two patch rows;
+    # two 8 x 8 patches per tile (24 = 3 x 8, the 8 x 8 level): a tile may straddle two images; split tiles: fp32 partials in tile-local
+    # row order, the reduce kernel maps rows to tokens
+    (2, 48, 48, 128, 0, 320, 11),       # SD-2.1 level-1 width: 3 patch columns x 6 patch rows per image
+    (2, 48, 48, 640, 320, 640, 11, 3),  # two sources, two N tiles, 15 chunks in 5 + 5 + 5
+    (1, 16, 80, 64, 0, 320, 11),        # 5 patch columns, one chunk
+    (2, 24, 24, 128, 0, 320, 11),       # SD-2.1 level-2 width: 9 patches per image, tile 4 holds the last patch of image 0 and the first of image 1
+    (2, 24, 24, 1280, 0, 1280, 11, 5),  # 20 chunks in 5 x 4
+    (4, 8, 8, 192, 64, 320, 11),        # the 8 x 8 level: two whole images per tile, two sources
+    (16, 8, 8, 1280, 0, 1280, 11, 7),   # SD-1.5 8 x 8 level at CFG batch 16, 20 chunks in 6 x 3 + 2
+    (2, 8, 128, 128, 0, 320, 11, 2),    # 64-pixel patch rows, split
+    (2, 16, 96, 192, 0, 320, 11, 3),    # 32-pixel patch rows, split 1 + 1 + 1
+    (6, 16, 16, 320, 0, 640, 11, 5),    # whole-row tiles with more than two splits
 ]
 
 
@@ -704,7 +718,8 @@ def test_conv_slab_kernel(dtype, case):
     from theatergen_amd import ops
     from theatergen_amd.weights_pack import pack_conv3x3
     dev = _dev()
-    B, h, w, cin, c1, cout, ft = case
+    B, h, w, cin, c1, cout, ft = case[:7]
+    fs = case[7] if len(case) > 7 else 0
     g = torch.Generator().manual_seed(sum(case))
     ctot = cin + c1
     x = rnd((B, ctot, h, w), dtype, g)
@@ -717,9 +732,10 @@ def test_conv_slab_kernel(dtype, case):
     kw = dict(x1=x1, c1=c1, bias=bias.to(dev), bvec=bvec.to(dev), rows_per_batch=h * w,
               res=res.permute(0, 2, 3, 1).reshape(B * h * w, cout).contiguous().to(dev), out_scale=0.5)
     wp = pack_conv3x3(wt).to(dev)
-    plan = ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, plan_only=True, **kw)
-    assert plan[3] == 4 and plan[2] == (2 if ft == 12 or case[0] == 16 else 1)
-    out = ops.conv3x3(x0, wp, B, h, w, cin, force_tile=ft, **kw)
+    fkw = dict(force_tile=ft, force_split_k=fs if ft == 11 else 0)
+    plan = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **fkw, **kw)
+    assert plan[3] == 4 and plan[2] == (fs if fs else (2 if ft == 12 or case[0] == 16 else 1))
+    out = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
     got = out.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     check(got, ref, dtype, f"slab conv {case}")
     old = os.environ.get("TG_GEMM_FLAGS")
@@ -741,14 +757,19 @@ def test_conv_slab_kernel(dtype, case):
 @pytest.mark.parametrize("case", [(2, 64, 64, 320, 0, 320, 11), (2, 64, 64, 640, 320, 320, 11), (3, 32, 32, 960, 320, 640, 11),
                                   (1, 64, 64, 64, 0, 320, 11), (2, 32, 32, 128, 0, 320, 11), (16, 32, 32, 640, 0, 640, 0),
                                   (16, 16, 16, 1280, 1280, 1280, 0), (3, 16, 16, 640, 0, 1280, 12),
-                                  (2, 8, 128, 320, 0, 320, 11), (2, 12, 96, 640, 320, 320, 11), (2, 96, 96, 320, 0, 320, 0)])
+                                  (2, 8, 128, 320, 0, 320, 11), (2, 12, 96, 640, 320, 320, 11), (2, 96, 96, 320, 0, 320, 0),
+                                  # generic patches: 3 x 16 patch columns; two 8 x 8 patches per tile of DIFFERENT images (two coefficient
+                                  # sets per tile); the 8 x 8 level; split tiles
+                                  (2, 48, 48, 320, 0, 640, 11), (2, 24, 24, 640, 640, 1280, 11), (4, 8, 8, 128, 0, 320, 11),
+                                  (2, 24, 24, 1280, 0, 1280, 11, 5), (2, 48, 48, 640, 0, 640, 11, 3)])
 def test_conv_slab_groupnorm_prologue(dtype, case):
     """GroupNorm + SiLU applied while the window is staged == tg_groupnorm followed by the plain conv, bit for bit; the
     coefficients against an fp32 reference; the heuristic (force_tile 0) takes a layer that fills the chip."""
     from theatergen_amd import ops
     from theatergen_amd.weights_pack import pack_conv3x3
     dev = _dev()
-    B, h, w, cin, c1, cout, ft = case
+    B, h, w, cin, c1, cout, ft = case[:7]
+    fs = case[7] if len(case) > 7 else 0
     g = torch.Generator().manual_seed(sum(case) + 1)
     ctot = cin + c1
     x = rnd((B, ctot, h, w), dtype, g) * 1.5 + 0.3
@@ -769,9 +790,9 @@ def test_conv_slab_groupnorm_prologue(dtype, case):
     d_ref = beta.float()[None] - mean.repeat_interleave(ctot // 32, dim=1) * a_ref
     cf = coef.cpu()
     assert torch.allclose(cf[:, 0], a_ref, rtol=2e-4, atol=1e-5) and torch.allclose(cf[:, 1], d_ref, rtol=2e-4, atol=2e-4)
-    fused = ops.conv3x3(x0, wp, B, h, w, cin, x1=x1, c1=c1, bias=bias.to(dev), a_coef=coef, a_silu=True, force_tile=ft)
+    fused = ops.conv3x3(x0, wp, B, h, w, cin, x1=x1, c1=c1, bias=bias.to(dev), a_coef=coef, a_silu=True, force_tile=ft, force_split_k=fs)
     hn = ops.groupnorm(x0, B, h * w, 32, 1e-5, gamma.to(dev), beta.to(dev), silu=True, x1=x1)
-    plain = ops.conv3x3(hn, wp, B, h, w, ctot, bias=bias.to(dev), force_tile=ft)
+    plain = ops.conv3x3(hn, wp, B, h, w, ctot, bias=bias.to(dev), force_tile=ft, force_split_k=fs)
     assert torch.equal(fused, plain), f"fused GroupNorm prologue differs from norm -> conv: {(fused.float() - plain.float()).abs().max().item()}"
     ref = F.conv2d(F.silu(F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-5)), wt.float(), bias.float(), padding=1)
     got = fused.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)

@@ -31,17 +31,23 @@
 
 namespace {
 
-template <typename T, int WI, bool PRO>
+// WI = patch (or image) width, NP = patches per tile: NP = 1: one TH x WI patch, TH = 128 / WI rows (whole image rows when in_w == WI);
+// NP = 2 (WI = 8): two 8 x 8 patches, their 10 x 10 windows stacked in the slab — the 8 x 8 level (two whole images per tile) and
+// the 24- / 40-wide maps; one compute-wave row (64 pixels) is one patch.
+// PATCH = false: whole-row tiles (in_w == WI, NP = 1): the instances of the SD-1.5 bench, kept free of the patch code paths.
+template <typename T, int WI, int NP, bool PRO, bool PATCH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slab_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 320, TM = 2, TN = 5, NF = TM + TN;
-  constexpr int TH = BM / WI, SW = WI + 2, SROWS = TH + 2, SLAB = SROWS * SW, SJ = (SLAB + 31) / 32;
+  constexpr int PP = BM / NP, TH = PP / WI, SW = WI + 2, SROWS = TH + 2, WIN = SROWS * SW, SLAB = NP * WIN, SJ = (SLAB + 31) / 32;
+  static_assert(NP == 1 || (NP == 2 && PP == 64), "two patches per tile = one per compute-wave row");
+  static_assert(PATCH || NP == 1, "two-patch tiles are patch tiles");
   constexpr unsigned SLAB_BYTES = SJ * 32 * 128, WST_BYTES = BN * 128, SCRATCH_BYTES = 4 * 32 * 68 * 4;
   // LDS: slab (ONE buffer; the epilogue bounce lives here too) | weight stages 0, 1, 2.  Three 40 KB weight stages leave room for
   // one slab only: the loaders hold the NEXT chunk's window in registers (loaded and normalised under the current chunk) and
   // write it between the last K-step of a chunk and the first of the next (one extra barrier per 9 K-steps).
   constexpr unsigned SLAB_PAD = SLAB_BYTES > SCRATCH_BYTES ? SLAB_BYTES : SCRATCH_BYTES, W_BASE = SLAB_PAD;
   constexpr int WJ = BN / 32;                      // LDS-DMA instructions per loader wave per weight tile (8 rows x 128 B each)
-  static_assert(BM % WI == 0, "whole image (or patch) rows per tile");
+  static_assert(PP % WI == 0, "whole image (or patch) rows per tile");
   static_assert(SJ <= 9, "two slab rows per thread in taps 3..5, one in taps 6..8");
   typedef typename Vec<T>::v8 V8;
 
@@ -95,8 +101,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned sdst = (unsigned)tid * 16u;     // byte offset of (row tid / 8, slot tid % 8) inside a slab buffer
     int spix[SJ];                                   // input pixel of this thread's slab row j (-1: zero padding / beyond the slab)
     u32x4 sreg[SJ];                                 // the chunk being staged
-    f32x4 ca0, ca1, cd0, cd1;                       // its GroupNorm coefficients a[8], d[8]
-    int img = 0;
+    f32x4 ca0, ca1, cd0, cd1;                       // its GroupNorm coefficients a[8], d[8] (of the image of patch 0)
+    f32x4 cb0, cb1, ce0, ce1;                       // NP = 2: the same for the image of patch 1 (slab rows >= WIN)
+    int img = 0, img1 = 0;
     auto load_slab = [&](int cc) {                  // request chunk cc of the window (asm: the compiler's waitcnt pass must not see these)
       int c = cc * BK;
       const T* base = A0;
@@ -115,20 +122,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(ca1) : "v"(ca) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cd0) : "v"(cd) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(cd1) : "v"(cd) : "memory");
+        if constexpr (NP == 2) {
+          const float* cb = coef + (long)img1 * 2 * ctot + cc * BK + schunk * 8;
+          const float* ce = cb + ctot;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cb0) : "v"(cb) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(cb1) : "v"(cb) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ce0) : "v"(ce) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(ce1) : "v"(ce) : "memory");
+        }
       }
     };
+    constexpr int NCOEF = PRO ? 4 * NP : 0;        // coefficient loads per chunk (vmcnt accounting)
     // after a `s_waitcnt vmcnt` that covers the loads above: ties every later use of the staged registers to this point
     auto slab_landed = [&]() {
 #pragma unroll
       for (int j = 0; j < SJ; ++j) asm volatile("" : "+v"(sreg[j]));
       if constexpr (PRO) asm volatile("" : "+v"(ca0), "+v"(ca1), "+v"(cd0), "+v"(cd1));
+      if constexpr (PRO && NP == 2) asm volatile("" : "+v"(cb0), "+v"(cb1), "+v"(ce0), "+v"(ce1));
     };
     const bool silu = p.a_silu != 0;
     auto xform_piece = [&](int j) {                 // normalise (+SiLU) slab row j in its registers (zero padding stays zero)
       if constexpr (PRO) {
         V8 v = __builtin_bit_cast(V8, sreg[j]);
-        const float a[8] = {ca0[0], ca0[1], ca0[2], ca0[3], ca1[0], ca1[1], ca1[2], ca1[3]};
-        const float d[8] = {cd0[0], cd0[1], cd0[2], cd0[3], cd1[0], cd1[1], cd1[2], cd1[3]};
+        float a[8] = {ca0[0], ca0[1], ca0[2], ca0[3], ca1[0], ca1[1], ca1[2], ca1[3]};
+        float d[8] = {cd0[0], cd0[1], cd0[2], cd0[3], cd1[0], cd1[1], cd1[2], cd1[3]};
+        if constexpr (NP == 2) {                    // slab rows >= WIN belong to patch 1 (possibly another image)
+          const bool second = (tid >> 3) + 32 * j >= WIN;
+          const float b[8] = {cb0[0], cb0[1], cb0[2], cb0[3], cb1[0], cb1[1], cb1[2], cb1[3]};
+          const float f[8] = {ce0[0], ce0[1], ce0[2], ce0[3], ce1[0], ce1[1], ce1[2], ce1[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a[e] = second ? b[e] : a[e]; d[e] = second ? f[e] : d[e]; }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = to_f32<T>(v[e]) * a[e] + d[e];   // tg_norm.hip gn_apply_kernel / gn_small_kernel: the same expression
@@ -157,17 +181,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // PATCH TILES (round 3): a tile is TH rows x WI columns of an image that may be WIDER than WI (p.in_w = 128 with WI = 64: SDXL's
       // 128 x 128 level; p.in_w = 96 with WI = 32: SD-2.1's 96 x 96 level): tile_m -> (image, patch row ty, patch column tx); the
       // window's halo columns then hold real neighbour pixels instead of padding.  p.in_w == WI is the whole-rows case of round 2.
+      // generic patches (round 3, second pass): any in_w that is a multiple of WI (48 = 3 x 16, 24 = 3 x 8), NP patches per tile.
       const int tpr = p.in_w / WI, tpi = (H / TH) * tpr;       // patches per image row / per image
-      img = tile_m / tpi;
-      const int rem = tile_m - img * tpi;
+      const int g0 = tile_m * NP;
+      img = g0 / tpi;
+      const int rem = g0 - img * tpi;
       const int y0 = (rem / tpr) * TH, x0 = (rem % tpr) * WI;
+      int y1 = 0, x1 = 0;
+      if constexpr (NP == 2) {
+        img1 = (g0 + 1) / tpi;
+        const int rem1 = g0 + 1 - img1 * tpi;
+        y1 = (rem1 / tpr) * TH; x1 = (rem1 % tpr) * WI;
+      }
 #pragma unroll
       for (int j = 0; j < SJ; ++j) {
         const int sr = (tid >> 3) + 32 * j;
-        const int sy = sr / SW, sx = sr - sy * SW;
-        const int iy = y0 - 1 + sy, ix = x0 - 1 + sx;
+        const bool second = NP == 2 && sr >= WIN;
+        const int r = second ? sr - WIN : sr;
+        const int sy = r / SW, sx = r - sy * SW;
+        const int iy = (second ? y1 : y0) - 1 + sy, ix = (second ? x1 : x0) - 1 + sx;
         const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < p.in_w;
-        spix[j] = ok ? (img * H + iy) * p.in_w + ix : -1;
+        spix[j] = ok ? ((second ? img1 : img) * H + iy) * p.in_w + ix : -1;
       }
       wlane = Wp + (n0 + wave * 8 + (lane >> 3)) * p.K + wchunk * 8;
     };
@@ -208,7 +242,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           // seam of K-step kt: weight tile kt + 1 (requested TWO K-steps ago) has landed; tile kt + 2 and, in taps 0 and 1, the
           // window loads (younger than tile kt + 2 in tap 0, than tile kt + 1 in neither) may stay in flight
           if (kt + 2 < nkt) {
-            if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + SJ + (PRO ? 4 : 0)) : "memory");
+            if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + SJ + NCOEF) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
           } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (tap == 2 && more) slab_landed();
@@ -239,7 +273,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pm = wave_m * TM * 32 + i * 32 + l31;
-    srow[i] = (pm / WI) * SW + pm % WI;
+    const int pk = pm / PP, pq = pm - pk * PP;      // patch of the tile, pixel inside it
+    srow[i] = pk * WIN + (pq / WI) * SW + pq % WI;
   }
   unsigned ax[TM], aw;                              // k-step 0 addresses of the current K-step
   auto set_addr = [&](int tap) {                    // K-step (any chunk, tap): slab rows of the tap, weight stage tap % 3 (9 taps per chunk)
@@ -348,22 +383,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // token index of the wave's first pixel and the distance between its two 32-row blocks.  Whole-row tiles: m0 + 64 wave_m, 32.
     // Patch tile (p.in_w > WI, never split): the wave's 64 pixels are 64 / WI patch rows of WI contiguous tokens each; the two blocks
     // are 32 tokens apart inside one patch row (WI = 64) or one image row apart (WI = 32).
-    long mw = m0 + wave_m * TM * 32, mbase = m0, mstride = 32;
-    if (p.in_w != WI) {
-      const int tpr = p.in_w / WI, tpi = (H / TH) * tpr;
-      const int im = tile_m / tpi, rem = tile_m - im * tpi;
-      mw = ((long)im * H + (rem / tpr) * TH + (wave_m * 64) / WI) * p.in_w + (rem % tpr) * WI;
+    // Patch tiles (p.patch_pwl > 0): the wave's first pixel is patch_token(tile, 64 wave_m); 64-pixel patch rows: blocks 32 tokens apart;
+    // 32-pixel patch rows: one image row apart; 16- / 8-pixel patch rows: per-row mapping (wave_row_token's pwl form).  A SPLIT work
+    // item writes its fp32 partial in tile-local row order (the reduce kernel maps rows to tokens with the same patch_token).
+    long mw = m0 + wave_m * TM * 32, mbase = m0;
+    const bool patch = PATCH && S == 1;
+    if (patch) {
+      mw = patch_token(p, tile_m, wave_m * 64);
       mbase = mw;
-      if (WI != 64) mstride = p.in_w;
     }
-    epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, n0 + wave_n * TN * 32, lane, reinterpret_cast<float*>(smem) + wave * (32 * 68),
-                                   S > 1 ? lbid : -1, mbase, n0, mstride);
+    float* scr = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    const long nw = n0 + wave_n * TN * 32;
+    const int part = S > 1 ? lbid : -1;
+    // one call per row mapping, so that the whole-row tiles keep a compile-time block distance (the row loop's address arithmetic)
+    if constexpr (WI == 64 || !PATCH) {
+      epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, nw, lane, scr, part, mbase, n0);
+    } else if constexpr (WI == 32) {
+      if (patch) epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, nw, lane, scr, -1, mbase, n0, (long)p.in_w);
+      else epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, nw, lane, scr, part, mbase, n0);
+    } else {
+      if (patch) epilogue_tile_lds<T, TM, TN, 0, false, true>(p, acc, mw, nw, lane, scr, -1, mbase, n0, 32, p.patch_pwl);
+      else epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, nw, lane, scr, part, mbase, n0);
+    }
   }
 }
 
-template <typename T, int WI, bool PRO>
+template <typename T, int WI, int NP, bool PRO, bool PATCH>
 int launch_slab(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st) {
-  constexpr int BM = 128, TH = BM / WI, SLAB = (TH + 2) * (WI + 2), SJ = (SLAB + 31) / 32;
+  constexpr int BM = 128, TH = BM / NP / WI, SLAB = NP * (TH + 2) * (WI + 2), SJ = (SLAB + 31) / 32;
   constexpr size_t slab = (size_t)SJ * 32 * 128, scratch = 4 * 32 * 68 * 4;
   const size_t lds = (slab > scratch ? slab : scratch) + 3 * (size_t)320 * 128;
   const long tiles_m = d->M / BM, tiles_n = d->N / 320;
@@ -375,7 +422,7 @@ int launch_slab(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st)
   p.tile_bm = BM; p.tile_bn = 320;
   long grid = tiles_m * tiles_n * splits;
   if (grid > 256) grid = 256;                     // one persistent workgroup per CU
-  auto k = conv_slab_kernel<T, WI, PRO>;
+  auto k = conv_slab_kernel<T, WI, NP, PRO, PATCH>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, st, p);
@@ -385,15 +432,23 @@ int launch_slab(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st)
 
 template <typename T>
 int launch_slab_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hipStream_t st) {
-  const int w = d->out_w;
+  // the planner (tg_gemm.hip: slab_geometry) chose the patch width / patches per tile: whole rows of 64 / 32 / 16-wide maps, patches of
+  // wider maps (128 = 2 x 64, 96 = 3 x 32, 48 = 3 x 16, ...), two 8 x 8 patches for the 8- / 24- / 40-wide maps
+  const bool patch = p.patch_pwl > 0;
+  const int pw = patch ? (1 << p.patch_pwl) : d->out_w;
   const bool pro = d->a_coef != nullptr;
-  if (w == 64) return pro ? launch_slab<T, 64, true>(d, p, splits, st) : launch_slab<T, 64, false>(d, p, splits, st);
-  if (w == 32) return pro ? launch_slab<T, 32, true>(d, p, splits, st) : launch_slab<T, 32, false>(d, p, splits, st);
-  if (w == 16) return pro ? launch_slab<T, 16, true>(d, p, splits, st) : launch_slab<T, 16, false>(d, p, splits, st);
-  // patch tiles: 128-wide maps as 2 x 64 patches, 96-wide maps as 4 x 32 patches (same staging geometry as the 64 / 32-wide instances)
-  if (w == 128 && splits == 1) return pro ? launch_slab<T, 64, true>(d, p, splits, st) : launch_slab<T, 64, false>(d, p, splits, st);
-  if (w == 96 && splits == 1) return pro ? launch_slab<T, 32, true>(d, p, splits, st) : launch_slab<T, 32, false>(d, p, splits, st);
-  tg_set_error("tg_gemm conv: no slab kernel for width %d", w);
+#define TG_SLAB_CASE(W, N, PT)                                                                                         \
+  if (pw == W && p.patch_np == N && patch == PT)                                                                         \
+    return pro ? launch_slab<T, W, N, true, PT>(d, p, splits, st) : launch_slab<T, W, N, false, PT>(d, p, splits, st);
+  TG_SLAB_CASE(64, 1, false)
+  TG_SLAB_CASE(32, 1, false)
+  TG_SLAB_CASE(16, 1, false)
+  TG_SLAB_CASE(64, 1, true)
+  TG_SLAB_CASE(32, 1, true)
+  TG_SLAB_CASE(16, 1, true)
+  TG_SLAB_CASE(8, 2, true)
+#undef TG_SLAB_CASE
+  tg_set_error("tg_gemm conv: no slab kernel for width %d (patch %d x %d)", d->out_w, pw, p.patch_np);
   return TG_ERR_UNSUPPORTED;
 }
 

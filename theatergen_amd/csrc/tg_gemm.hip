@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const int lr = slice * rows + q / q4, lc = (q % q4) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < p.tail_s; ++z) s += *reinterpret_cast<const f32x4*>(base + z * tile_elems + (long)lr * p.tile_bn + lc);
-    epilogue_store4<T>(p, m0 + lr, n0 + lc, s[0], s[1], s[2], s[3]);
+    // slab conv patch tiles: partial rows are in tile-local order, the token comes from the patch geometry
+    const long m = p.patch_pwl > 0 ? patch_token(p, lbid / p.tiles_n, lr) : m0 + lr;
+    epilogue_store4<T>(p, m, n0 + lc, s[0], s[1], s[2], s[3]);
   }
 }
 
@@ -216,27 +218,80 @@ namespace {
 // the channel chunks in 2 if that is what it takes (the 16-wide maps: 128 tiles; every split keeps >= 5 chunks = 45 K-steps).
 // TG_GEMM_FLAGS bit 7 (dev) turns it off.  (A 64 x 320 tile for the 16-wide maps was built, measured and dropped: 40 KB of weights
 // per 640 matrix-pipe cycles = 64 B/clk per CU is the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.)
+// Tile geometry of the slab kernel for an out_h x out_w map: patch width *pw and patches per 128-pixel tile *np (tg_conv_slab.hip).
+// Whole image rows for the 64 / 32 / 16-wide maps (*patch = false); wider or odd maps are cut into patches: multiples of 64 -> 2 x 64,
+// of 32 -> 4 x 32 (SD-2.1's 96), of 16 -> 8 x 16 (48, 80), of 8 -> two 8 x 8 patches per tile (the 8 x 8 level, 24, 40).
+inline bool slab_geometry(const tg_gemm_desc* d, int* pw, int* np, bool* patch) {
+  const int w = d->out_w, h = d->out_h;
+  int P = 0, NPv = 1;
+  if (w == 64 || w == 32 || w == 16) P = w;
+  else if (w % 64 == 0) P = 64;
+  else if (w % 32 == 0) P = 32;
+  else if (w % 16 == 0) P = 16;
+  else if (w % 8 == 0) { P = 8; NPv = 2; }
+  else return false;
+  const int th = 128 / (P * NPv);
+  if (h % th != 0 || d->M % 128 != 0) return false;
+  *pw = P; *np = NPv; *patch = (P != w) || NPv > 1;
+  return true;
+}
+
 inline int slab_splits_of(const tg_gemm_desc* d) {
-  if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->force_split_k > 1 || d->act != TG_ACT_NONE || d->geglu) return 0;
+  if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->act != TG_ACT_NONE || d->geglu) return 0;
   if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
-  const int w = d->out_w;
-  // patch tiles (round 3): 128-wide maps (SDXL level 0) as 2-row x 64-column patches, 96-wide maps (SD-2.1 level 0) as 4 x 32; never split
-  const bool patch = (w == 128 && d->out_h % 2 == 0) || (w == 96 && d->out_h % 4 == 0);
-  if (w != 16 && w != 32 && w != 64 && !patch) return 0;
-  if (((long)d->out_h * w) % 128 != 0 || d->M % 128 != 0) return 0;
+  int pw, np;
+  bool patch;
+  if (!slab_geometry(d, &pw, &np, &patch)) return 0;
   const int chunks = (d->c0 + (d->a1 ? d->c1 : 0)) / BK;
-  if (d->force_tile == 11) return 1;
-  if (d->force_tile == 12) return (chunks >= 2 && !patch) ? 2 : 0;
+  // force_tile 11: the slab kernel with force_split_k (default 1) splits, 12: two splits (tests / dev sweeps)
+  if (d->force_tile == 11) {
+    if (d->force_split_k <= 1) return 1;
+    if (d->force_split_k > chunks) return 0;
+    const int cps = (chunks + d->force_split_k - 1) / d->force_split_k;
+    return (chunks + cps - 1) / cps;                                // every split keeps at least one chunk
+  }
+  if (d->force_split_k > 1) return 0;
+  if (d->force_tile == 12) return chunks >= 2 ? 2 : 0;
   if (d->force_tile != 0) return 0;
-  { const char* e = getenv("TG_GEMM_FLAGS"); const long f = e ? strtol(e, nullptr, 0) : 0; if ((f & 128) || (patch && (f & 1024))) return 0; }   // dev A/B: bit 7 no slab kernel, bit 10 no patch tiles
+  long flags = 0;
+  { const char* e = getenv("TG_GEMM_FLAGS"); flags = e ? strtol(e, nullptr, 0) : 0; }
+  const bool old_patch = (d->out_w == 128 || d->out_w == 96);     // round-3 first pass: 2 x 64 / 4 x 32 patches, never split
+  if ((flags & 128) || (old_patch && (flags & 1024))) return 0;    // dev A/B: bit 7 no slab kernel, bit 10 no patch tiles
   const long t = (d->M / 128) * (d->N / 320);
   auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
-  // a patch-tile layer has no 128-pixel halo kernel to fall back to (the implicit-GEMM conv re-fetches every window 9 times): half a
-  // chip of slab tiles already beats it (BASELINE configs[3]: 96 x 96 x batch 2 = 144 tiles)
-  if (patch) return t >= 128 ? 1 : 0;
-  if (full(t)) return 1;
-  if (chunks >= 10 && full(2 * t)) return 2;
-  return 0;
+  if (!patch || old_patch) {
+    // a patch-tile layer has no 128-pixel halo kernel to fall back to (the implicit-GEMM conv re-fetches every window 9 times): half a
+    // chip of slab tiles already beats it (BASELINE configs[3]: 96 x 96 x batch 2 = 144 tiles)
+    if (old_patch && t >= 128) return 1;
+    if (!old_patch && full(t)) return 1;
+    if (!old_patch && chunks >= 10 && full(2 * t)) return 2;
+  }
+  // Round 3, second pass: what the rules above used to leave to the IMPLICIT-GEMM conv (which re-fetches every window 9 times) — the
+  // small-M levels of the batch-2 plans: SD-2.1 48 x 48 (3 x 16 patches) and 24 x 24 (two 8 x 8 patches per tile), SDXL 32 x 32 at
+  // batch 2, SD-1.5 32 x 32 / 16 x 16 at batch 2 — with a K split over the channel chunks that puts enough work items on the chip.
+  // Layers the LDS-halo kernel takes (power-of-two widths with M >= 4096, the 8 x 8 level at M >= 1024) stay there: measured
+  // (scripts/dev_slab_split_sweep.py, profiles/r3_slab_split_sweep.txt) 51 vs 55 us on SDXL's 64 x 64 320 -> 640 and 57 vs 62 us on
+  // the 8 x 8 level at CFG batch 16.  Cost of S splits, one work item per CU and round (us; fitted on the same sweep, only ratios matter):
+  //   rounds(t S / 256) x 9 x chunks-per-split x t_k + [S > 1] (t_red + t_part x t S),  t_k = max(0.9, min(t S, 256) / 210)
+  // — a K-step takes 0.8 .. 0.9 us on a part-filled chip and the whole chip completes ~210 K-steps per us (72 / 144 / 216 / 252 work
+  // items: 0.80 / 0.90 / 1.03 / 1.27 us), so filling the last 20 % of the CUs buys nothing; the fp32 partials are nearly free.
+  if (flags & 2048) return 0;                                      // dev A/B: bit 11 = the rules above only
+  if (halo_eligible(d) && !(flags & 4096)) return 0;               // dev A/B: bit 12 = this rule for halo-eligible layers too
+  const double t_red = 8.0, t_part = 0.02;
+  double best = 1e30;
+  int best_s = 0;
+  for (int c = 1; c <= 8; ++c) {
+    const int cps = (chunks + c - 1) / c;
+    if (c > 1 && (cps < 2 || (chunks + cps - 1) / cps != c)) continue;
+    const long items = t * c;
+    const long rounds = (items + 255) / 256;
+    const double per_round = (double)(items < 256 ? items : 256);
+    const double t_k = per_round / 210.0 > 0.9 ? per_round / 210.0 : 0.9;
+    const double cost = rounds * 9.0 * cps * t_k + (c > 1 ? t_red + t_part * (double)items : 0.0);
+    if (cost < best) { best = cost; best_s = c; }
+  }
+  if (t * best_s < 96) return 0;                                   // under ~a third of the chip even when split: not this kernel's case
+  return best_s;
 }
 
 // Loader / compute GEMM (tg_gemm_lc.hip): plain GEMM, one A source, N a multiple of 320, K a multiple of 64 and >= 1024, linear
@@ -320,6 +375,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
   }
   p.a_coef = d->a_coef; p.a_silu = d->a_silu;
+  p.patch_pwl = 0; p.patch_np = 1;
   p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps; p.ln_rows = d->ln_rows;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -340,6 +396,13 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
       const int64_t need = tiles * sp * 128 * 320 * 4;
       TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= need, TG_ERR_ARG, "tg_gemm conv: the K split needs %lld workspace bytes, got %lld",
                (long long)need, (long long)d->workspace_bytes);
+    }
+    {
+      int pw = 0, np = 1;
+      bool patch = false;
+      slab_geometry(d, &pw, &np, &patch);
+      p.patch_np = np;
+      if (patch) { int l = 0; while ((1 << l) < pw) ++l; p.patch_pwl = l; }
     }
     int rc = tg_conv_slab_launch(d, &p, sp, st);
     if (rc != TG_OK || sp == 1) return rc;

@@ -46,7 +46,21 @@ struct GemmParams {
   const float* ln_rows; // LN = 2: precomputed (rstd, -rstd * mean) per row, fp32 [M][2] (tg_layernorm_stats)
   int flags;        // dev experiments (env TG_GEMM_FLAGS): bit 0 = stagger the two co-resident blocks of a CU (low 8 bits = mode,
                     // bits 8.. = delay in ~1 us units), bit 1 = s_setprio(1) around the MFMA chain
+  // slab conv PATCH tiles (tg_conv_slab.hip): a 128-pixel tile = patch_np patches of (128 / patch_np >> patch_pwl) rows x (1 << patch_pwl)
+  // columns of an in_h x in_w image, patches numbered image-major / patch-row / patch-column.  patch_pwl = 0: tile rows are contiguous tokens.
+  int patch_pwl, patch_np;
 };
+
+// token (row of the token-major tensor) of local row `lr` (0..127) of patch tile `tile_m`; see GemmParams::patch_pwl
+__device__ __forceinline__ long patch_token(const GemmParams& p, int tile_m, int lr) {
+  const int pwl = p.patch_pwl, np = p.patch_np, pp = 128 / np;
+  const int k = lr / pp, q = lr - k * pp;
+  const int th = pp >> pwl, tpr = p.in_w >> pwl, tpi = (p.in_h / th) * tpr;
+  const int g = tile_m * np + k;
+  const int img = g / tpi, rem = g - img * tpi;
+  const int y0 = (rem / tpr) * th, x0 = (rem - (rem / tpr) * tpr) << pwl;
+  return ((long)img * p.in_h + y0 + (q >> pwl)) * p.in_w + x0 + (q & ((1 << pwl) - 1));
+}
 
 
 template <typename T>
@@ -137,10 +151,22 @@ __device__ __forceinline__ int xcd_chunked_block_id(int bid, int nblocks) {
 // epilogue in column chunks so that the LDS bounce stays small); n_base is the column of tile 0, lane offset included.
 // LN: LayerNorm-folded projection (gemm_glds_kernel<..., LN>): the kernel has already turned every accumulator into
 // rstd * (acc - mean * u[n]); the epilogue adds the fp32 vector v[n] = sum_k beta[k] W[n, k] + bias[n] where the bias would go.
-template <typename T, int TM, int TN, int EPI, int J0 = 0, int JN = TN, bool LN = false>
+// Rows of a wave tile -> tokens.  Default: row q (0 .. 32 TM - 1) of the wave tile is token m_wave + mstride * (q / 32) + q % 32 (mstride = 32:
+// contiguous rows; the image width for the slab conv's 32-pixel patch rows).  PR = true (template flag of the epilogue functions; slab conv
+// patch rows of 1 << pwl <= 16 pixels only, so that every other kernel keeps its address arithmetic): m_wave + (q >> pwl) * in_w + (q & ((1 << pwl) - 1)).
+__device__ __forceinline__ long patch_row_token(const GemmParams& p, long m_wave, int q, int pwl) {
+  return m_wave + (long)(q >> pwl) * p.in_w + (q & ((1 << pwl) - 1));
+}
+
+template <typename T, int TM, int TN, int EPI, int J0 = 0, int JN = TN, bool LN = false, bool PR = false>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_base, long n_base, int part,
-                                              long pm0, long pn0, long mstride = 32) {
+                                              long pm0, long pn0, long mstride = 32, int pwl = 0) {
   typedef typename Vec<T>::v4 V4;
+  // m_base = m_wave + (lane & 31)
+  auto row_m = [&](int i) -> long {
+    if constexpr (PR) { const int l31e = (int)threadIdx.x & 31; return patch_row_token(p, m_base - l31e, 32 * i + l31e, pwl); }
+    else return m_base + mstride * i;
+  };
   if constexpr (LN) {
     // (the caller already formed rstd * (acc - mean * u) in place) + v[n]; the direct path is the cold one: V^T columns
 #pragma unroll
@@ -187,7 +213,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
         const long nA = n_base - hi4 + 32 * jq;     // first packed column of the a-block (multiple of 64)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const long m = m_base + mstride * i;
+          const long m = row_m(i);
           if (m >= p.M) continue;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -230,7 +256,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
     }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const long m = m_base + mstride * i;
+    const long m = row_m(i);
     const bool m_ok = m < p.M;
     long b = 0;
     if (bvecp != nullptr || p.n_split > 0) b = (m_ok ? m : 0) / p.rows_per_batch;
@@ -293,9 +319,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
 // per-batch-vector loads, then the 8 LDS writes, then ALL LDS reads of the half, then the arithmetic and the stores
 // (only the store is predicated on the row bound).  fp32: ((acc + bias) + bvec) + res, activation, * scale, one rounding;
 // x + 0 and x * 1 are exact, so this rounds the same value as the direct epilogue.
-template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES, int J0 = 0, int JN = TN, bool LN = false>
+template <typename T, int TM, int TN, int EPI, bool HAS_ADD, bool HAS_RES, int J0 = 0, int JN = TN, bool LN = false, bool PR = false>
 __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr, long mstride = 32) {
+                                                  float* scr, long mstride = 32, int pwl = 0) {
   typedef typename Vec<T>::v8 V8;
   constexpr int W = JN * 32, RS = W + 4, P = W / 8, RPP = 64 / P, NPASS = 32 / RPP;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -324,11 +350,16 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long m_first = m_wave + mstride * i + r0;      // mstride: token distance between the wave tile's 32-row blocks (32 = contiguous rows;
-    V8 add8[NPASS], res8[NPASS];                         // the image width for the slab conv's 32-pixel patch rows)
+    // the image width for the slab conv's 32-pixel patch rows); PR: token of this lane's row in pass `it` from the patch-row mapping
+    auto mrow = [&](int it) -> long {
+      if constexpr (PR) return patch_row_token(p, m_wave, 32 * i + it * RPP + r0, pwl);
+      else return m_first + it * RPP;
+    };
+    V8 add8[NPASS], res8[NPASS];
     if constexpr (HAS_ADD) {
 #pragma unroll
       for (int it = 0; it < NPASS; ++it) {
-        long m = m_first + it * RPP;
+        long m = mrow(it);
         if (m >= p.M) m = p.M - 1;
         add8[it] = *reinterpret_cast<const V8*>(bvecp + (m / p.rows_per_batch) * p.ldbvec + nc);
       }
@@ -336,7 +367,7 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&
     if constexpr (HAS_RES) {
 #pragma unroll
       for (int it = 0; it < NPASS; ++it) {
-        long m = m_first + it * RPP;
+        long m = mrow(it);
         if (m >= p.M) m = p.M - 1;
         res8[it] = *reinterpret_cast<const V8*>(resp + m * p.ldres + nc);
       }
@@ -379,7 +410,11 @@ __device__ __forceinline__ void epilogue_rows_lds(const GemmParams& p, f32x16 (&
       V8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e] * scale);
-      if (m_first + it * RPP < p.M && n_ok) *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
+      if constexpr (PR) {
+        if (const long m = mrow(it); m < p.M && n_ok) *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
+      } else {
+        if (m_first + it * RPP < p.M && n_ok) *reinterpret_cast<V8*>(op + (long)it * RPP * p.ldc) = o;
+      }
     }
   }
 }
@@ -539,14 +574,14 @@ __device__ __forceinline__ void epilogue_tile_reg16(const GemmParams& p, f32x16 
 }
 
 // one column chunk [J0, J0 + JN) of the wave tile through the LDS bounce (or the direct path where the bounce does not apply)
-template <typename T, int TM, int TN, int EPI, int J0, int JN, bool LN = false>
+template <typename T, int TM, int TN, int EPI, int J0, int JN, bool LN = false, bool PR = false>
 __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                   float* scr, int part, long pm0, long pn0, long mstride = 32) {
+                                                   float* scr, int part, long pm0, long pn0, long mstride = 32, int pwl = 0) {
   typedef typename Vec<T>::v4 V4;
   typedef typename Vec<T>::v8 V8;
   const int l31 = lane & 31, hi = lane >> 5;
   if (part >= 0 || !p.epi_lds || (p.n_split > 0 && n_wave + J0 * 32 >= p.n_split)) {
-    epilogue_tile<T, TM, TN, EPI, J0, JN, LN>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0, mstride);
+    epilogue_tile<T, TM, TN, EPI, J0, JN, LN, PR>(p, acc, m_wave + l31, n_wave + 4 * hi, part, pm0, pn0, mstride, pwl);
     return;
   }
   T* outp = reinterpret_cast<T*>(p.out);
@@ -628,28 +663,28 @@ __device__ __forceinline__ void epilogue_chunk_lds(const GemmParams& p, f32x16 (
     // the LayerNorm-fused projections carry no per-batch vector and no residual (QKV, to_q, FF1)
     epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN, true>(p, acc, m_wave, n_wave, lane, scr, mstride);
   } else if (bvecp != nullptr) {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
-    else epilogue_rows_lds<T, TM, TN, EPI, true, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, true, true, J0, JN, false, PR>(p, acc, m_wave, n_wave, lane, scr, mstride, pwl);
+    else epilogue_rows_lds<T, TM, TN, EPI, true, false, J0, JN, false, PR>(p, acc, m_wave, n_wave, lane, scr, mstride, pwl);
   } else {
-    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
-    else epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN>(p, acc, m_wave, n_wave, lane, scr, mstride);
+    if (resp != nullptr) epilogue_rows_lds<T, TM, TN, EPI, false, true, J0, JN, false, PR>(p, acc, m_wave, n_wave, lane, scr, mstride, pwl);
+    else epilogue_rows_lds<T, TM, TN, EPI, false, false, J0, JN, false, PR>(p, acc, m_wave, n_wave, lane, scr, mstride, pwl);
   }
 }
 
 // Whole wave tile.  Up to two 32-column tiles go through the bounce in one piece (the 128x128 / 64x64 kernels: unchanged);
 // wider wave tiles (the big-tile kernels: 5 or 4 tiles) run in 64-column chunks (+ one 32-column rest), so the per-wave
 // scratch stays 32 x 68 floats and every store instruction still covers whole 128-byte rows.
-template <typename T, int TM, int TN, int EPI, bool LN = false>
+template <typename T, int TM, int TN, int EPI, bool LN = false, bool PR = false>
 __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&acc)[TM][TN], long m_wave, long n_wave, int lane,
-                                                  float* scr, int part, long pm0, long pn0, long mstride = 32) {
+                                                  float* scr, int part, long pm0, long pn0, long mstride = 32, int pwl = 0) {
   if constexpr (TN <= 2) {
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
   } else {
     static_assert(!LN, "the LayerNorm fold is instantiated for the 64-column wave tiles only");
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
-    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
-    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
-    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride);
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
     static_assert(TN <= 5, "wave tiles wider than 160 columns are not instantiated");
   }
 }
