@@ -93,6 +93,11 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
+inline long t3_max_tiles() {
+  const char* e = getenv("TG_T3_MAX");
+  return e ? strtol(e, nullptr, 0) : 256;
+}
+
 Plan make_plan(const tg_gemm_desc* d) {
   // Tile: measured on MI355X over the UNet's shapes (scripts/dev_gemm_bench.py) the 128x128 tile with 2 blocks per CU is
   // the best or within a few % of the best everywhere; skinny problems (one dimension <= 64) take the matching tile.
@@ -106,6 +111,11 @@ Plan make_plan(const tg_gemm_desc* d) {
     // few 128x128 tiles (the 8x8 level, M = 1024): 64x64 tiles put 4x as many blocks on the chip (3 per CU):
     // 1024x1280x1280 22 -> 13 us, K = 5120 69 -> 39 us (scripts/dev_tile_sweep.py)
     else if (d->mode == 0 && !d->geglu && ((M + 127) / 128) * ((N + 127) / 128) <= t64_max_tiles()) t = 1;
+    // round 3 (batch-2 plans): up to 256 128x128-tiles (under one tile per CU) the 128 x 64 tile: twice the blocks, 3 stages.  Isolated
+    // (scripts/dev_tile_sweep_b2.py): 2048 x 1280 x 5120 63 -> 52 us, 2048 x 1280 x 1280 21 -> 18 us, 4608 x 640 x 640 14 -> 11 us; in the
+    // graph-replayed steps (same-box A/B, TG_T3_MAX 0 / 256): configs[4] 27.76 -> 26.73 ms/step, configs[3] 11.49 -> 11.39 ms/step.  No SD-1.5
+    // CFG-batch-16 shape falls in the range (its 16 x 16 level is 320 tiles).
+    else if (d->mode == 0 && !d->geglu && N <= 1280 && ((M + 127) / 128) * ((N + 127) / 128) <= t3_max_tiles()) t = 2;
     // dev A/B (TG_GEMM_FLAGS bit 14): short-K plain GEMMs on the 32-wide K stages (three co-resident workgroups per CU)
     // short-K plain GEMMs (K <= 640: the 64x64 / 32x32 levels' attention and proj_in / proj_out projections) take the 128x128 tile
     // on three 32-wide K stages: 48 KB of LDS = THREE co-resident workgroups per CU instead of two, more prologue / epilogue
