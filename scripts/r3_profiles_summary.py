@@ -31,7 +31,7 @@ FAMILIES = [
     ("bt_gemm_kernel<256x256>", lambda n: "bt_gemm_kernel" in n and "Li256ELi256E" in n),
     ("gemm_glds_kernel<conv,128x128>", lambda n: "gemm_glds_kernel" in n and "Li128ELi128ELi2ELi2ELb1E" in n),
     ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n),
-    ("conv_slab_kernel<128x320>+gn", lambda n: "conv_slab_kernel" in n and "ELb1EE" in n),
+    ("conv_slab_kernel<128x320>+gn", lambda n: "conv_slab_kernel" in n and "ELb1ELb" in n),
     ("conv_slab_kernel<128x320,w64>", lambda n: "conv_slab_kernel" in n and "Li64E" in n),
     ("conv_slab_kernel<128x320,w32>", lambda n: "conv_slab_kernel" in n and "Li32E" in n),
     ("conv_slab_kernel<128x320,w16,split2>", lambda n: "conv_slab_kernel" in n and "Li16E" in n),

@@ -70,6 +70,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tiles_m = (int)(p.M / BM);
   const int ntiles = tiles_m * p.tiles_n * S;       // work items
 
+  // work item v -> (tile t = tile_m * tiles_n + tile_n, split sp).  XCD-chunked order in both forms: XCD x owns a contiguous range of
+  // logical ids.  Default: tile-major (an XCD's range is a band of row tiles over all column tiles and splits: every XCD streams the
+  // WHOLE weight tensor through its L2, the window of a row tile is shared).  Weight-heavy layers (p.slab_order = 1: weight bytes >
+  // activation bytes, the 16-wide and smaller maps): (column tile, split)-major / row-tile-minor — an XCD's range covers all row
+  // tiles of one or two (column tile, split) weight slices, e.g. SD-1.5's 16 x 16 level: 32 row tiles x 8 slices of 3.7 MB = one
+  // L2-sized slice per XCD, and the weights cross the fabric once instead of eight times.
+  auto work_item = [&](int v, int& t, int& sp) {
+    const int lbid = xcd_chunked_block_id(v, ntiles);
+    if (p.slab_order == 1) {
+      const int combo = lbid / tiles_m, tm_ = lbid - combo * tiles_m;
+      const int tn_ = combo / S;
+      sp = combo - tn_ * S;
+      t = tm_ * p.tiles_n + tn_;
+    } else {
+      t = lbid / S;
+      sp = lbid - t * S;
+    }
+  };
+
   if (loader) {
     // =========================================================== loader waves ===========================================
 
@@ -171,8 +190,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
     auto setup_tile = [&](int v) {
-      const int lbid = xcd_chunked_block_id(v, ntiles);
-      const int t = lbid / S, sp = lbid - t * S;
+      int t, sp;
+      work_item(v, t, sp);
       const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
       const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
       cfirst = sp * cps;
@@ -322,8 +341,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-    const int lbid = xcd_chunked_block_id(v, ntiles);
-    const int t = lbid / S, sp = lbid - t * S;
+    int t, sp;
+    work_item(v, t, sp);
+    const int lbid = t * S + sp;                    // index of this work item's fp32 partial (reduce kernel: tile-major, split-minor)
     const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
     const int nchunks = nchunks_all - sp * cps < cps ? nchunks_all - sp * cps : cps;
@@ -420,6 +440,8 @@ int launch_slab(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st)
   p.tail_s = splits;
   p.kt_per_split = (nchunks + splits - 1) / splits;   // channel chunks per split
   p.tile_bm = BM; p.tile_bn = 320;
+  // weight-heavy layer: (column tile, split)-major work order (see work_item); TG_GEMM_FLAGS bit 13 (dev A/B) keeps the tile-major order
+  p.slab_order = ((long)d->N * d->K > (long)d->M * (d->K / 9) && !(p.flags & 8192)) ? 1 : 0;
   long grid = tiles_m * tiles_n * splits;
   if (grid > 256) grid = 256;                     // one persistent workgroup per CU
   auto k = conv_slab_kernel<T, WI, NP, PRO, PATCH>;
