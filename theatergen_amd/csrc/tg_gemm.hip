@@ -222,12 +222,6 @@ int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, in
 int tg_conv_halo_launch(const tg_gemm_desc* d, const void* params, int grid, void* stream);
 namespace {
 
-// Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 16 / 32 / 64-wide maps, 128-pixel x 320-channel
-// tiles.  -> K splits per tile (over 64-channel chunks), 0 = not taken.  force_tile 11 / 12 = 1 / 2 splits regardless of the tile
-// count (tests); the heuristic wants the persistent grid (one workgroup per CU, 256) at least 3/4 full in every round, splitting
-// the channel chunks in 2 if that is what it takes (the 16-wide maps: 128 tiles; every split keeps >= 5 chunks = 45 K-steps).
-// TG_GEMM_FLAGS bit 7 (dev) turns it off.  (A 64 x 320 tile for the 16-wide maps was built, measured and dropped: 40 KB of weights
-// per 640 matrix-pipe cycles = 64 B/clk per CU is the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.)
 // Tile geometry of the slab kernel for an out_h x out_w map: patch width *pw and patches per 128-pixel tile *np (tg_conv_slab.hip).
 // Whole image rows for the 64 / 32 / 16-wide maps (*patch = false); wider or odd maps are cut into patches: multiples of 64 -> 2 x 64,
 // of 32 -> 4 x 32 (SD-2.1's 96), of 16 -> 8 x 16 (48, 80), of 8 -> two 8 x 8 patches per tile (the 8 x 8 level, 24, 40).
@@ -246,6 +240,12 @@ inline bool slab_geometry(const tg_gemm_desc* d, int* pw, int* np, bool* patch) 
   return true;
 }
 
+// Slab conv (tg_conv_slab.hip): stride-1 pad-1 convs with N a multiple of 320 on 16 / 32 / 64-wide maps, 128-pixel x 320-channel
+// tiles.  -> K splits per tile (over 64-channel chunks), 0 = not taken.  force_tile 11 / 12 = 1 / 2 splits regardless of the tile
+// count (tests); the heuristic wants the persistent grid (one workgroup per CU, 256) at least 3/4 full in every round, splitting
+// the channel chunks in 2 if that is what it takes (the 16-wide maps: 128 tiles; every split keeps >= 5 chunks = 45 K-steps).
+// TG_GEMM_FLAGS bit 7 (dev) turns it off.  (A 64 x 320 tile for the 16-wide maps was built, measured and dropped: 40 KB of weights
+// per 640 matrix-pipe cycles = 64 B/clk per CU is the L2's whole bandwidth: 52 ms against the halo kernel's 36 per 21 UNet calls.)
 inline int slab_splits_of(const tg_gemm_desc* d) {
   if (d->mode != 1 || d->stride != 1 || d->upsample || d->pad_mode != 0 || d->act != TG_ACT_NONE || d->geglu) return 0;
   if (d->N % 320 != 0 || d->c0 % BK != 0 || (d->a1 && d->c1 % BK != 0) || d->n_split > 0) return 0;
