@@ -51,6 +51,7 @@ struct AttnParams {
   const float* w1_dev;
   void* out; long out_ld, out_bs;
   int causal;
+  int flags;        // dev A/B (env TG_ATTN_FLAGS, read per launch): bit 0 = no intra-wave MFMA / VALU interleave (PIPE)
 };
 
 // Data path: K tile = NP panels of [64 keys][64 d] and V^T tile = [DV d][64 keys], both as 128-byte LDS rows filled by
@@ -260,7 +261,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     else if (p.len1 > 0) issue(kb1, p.k1_ld, vb1, p.vt1_ld, p.len1, 0, st ^ 1);
     const T* sK = sbase + st * STAGE;
     f32x16 s[2];
-    scores(s, sK, p.len0, kv0, p.causal != 0);
+    // PIPE (DV = 64 variants: head dims 40 and 64), full tiles only: MFMA and VALU work of ONE wave interleaved in program order.  The
+    // chain QK^T -> max -> exp2 -> convert -> PV is dependent end to end inside a wave, and the rocprofv3 trace of the SD-1.5 step
+    // (5 level-0 self-attention launches of 499 us = 1096 cycles per wave-tile and SIMD against ~450 of VALU + ~450 of matrix pipe)
+    // says the three waves of a SIMD do not hide each other's phases.  So: the second 32-key half's QK^T MFMAs run with the max over
+    // the first half in their shadow, and the PV MFMAs of the first half run with the exp2s of the second half between them (an MFMA
+    // executes asynchronously; the wave keeps issuing independent VALU instructions behind it).  Same arithmetic, same order of
+    // every accumulation: bit-identical to the straight-line path (which ragged / causal tiles keep).  Measured (MI355X, same box,
+    // TG_ATTN_FLAGS 1 / 0): level-0 self-attention in isolation 660 -> 634 us and 719 -> 698 us on two boxes (-3 .. -4 %), the SD-1.5
+    // bench +0.2 .. +0.6 % — at 152 instead of 125 VGPRs (three resident waves per SIMD instead of four).  What it says about the
+    // hardware: a wave-tile costs about the SUM of its VALU and matrix-pipe time whatever the issue order, so the remaining levers
+    // are fewer instructions, not more overlap.
+    constexpr bool PIPE = DV == 64 && NKS <= 3;      // head dim 40 (the d = 64 variant would spill at three waves per SIMD)
+    const bool piped = PIPE && !(kv0 + KV > p.len0 || p.causal != 0) && !(p.flags & 1);
+    float tm;
+    if (piped) {
+      V8 kf0[NKS], kf1[NKS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        kf0[ks] = *reinterpret_cast<const V8*>(sK + kofs[ks & 3] + (ks >> 2) * 4096);
+        kf1[ks] = *reinterpret_cast<const V8*>(sK + kofs[ks & 3] + ((ks >> 2) * 4096 + 32 * 64));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+      float mx = -INFINITY;
+      if (!(p.flags & 2)) {
+        // S0 chain first, the S1 chain with the max over S0 in its shadow
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) s[0] = mfma32(kf0[ks], qf[ks], s[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          s[1] = mfma32(kf1[ks], qf[ks], s[1]);
+#pragma unroll
+          for (int r = ks * 16 / NKS; r < (ks + 1) * 16 / NKS; ++r) mx = fmaxf(mx, s[0][r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        // dev A/B (TG_ATTN_FLAGS bit 1): the two halves' accumulation chains alternate (a dependent 32x32x16 MFMA can issue only when
+        // its predecessor has left the pipe); measured equal to the default within noise
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          s[0] = mfma32(kf0[ks], qf[ks], s[0]);
+          s[1] = mfma32(kf1[ks], qf[ks], s[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+      float a = mx, b2 = mx;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b2));
+      tm = fmaxf(a, b2);
+    } else {
+      scores(s, sK, p.len0, kv0, p.causal != 0);
+      tm = tile_max(s);
+    }
     // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
     // v_exp_f32 directly (__builtin_amdgcn_exp2f): results stay far inside the fp32 range, exp2(-inf) = 0 — none of
     // exp2f()'s denormal-range rescaling (v_ldexp + compares + selects per element) is needed.
@@ -270,8 +327,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     // accumulators have the range).  With a strict "any row has a new max" test the rescale ran on most tiles: over 32
     // rows a new maximum keeps turning up somewhere.
     constexpr float LAZY_LOG2 = 8.f;
-    const float tm = tile_max(s);
     float ps = 0.f;
+    float mc = 0.f;                                  // generic path: the reference in exp2 units
     if constexpr (FOLD) {
       // s already holds exp2's argument relative to the current reference (-qbias)
       if (t == 0 || __any(tm > LAZY_LOG2)) {
@@ -291,14 +348,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
         qbias = nb;
         if (hi) qf[NKS - 1][0] = from_f32<T>(nb);
       }
-#pragma unroll
-      for (int kvt = 0; kvt < 2; ++kvt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kvt][r]);
-          s[kvt][r] = e;
-          if (!ONES) ps += e;
-        }
     } else {
       if (__any(tm * p.scale_log2 > m_run * p.scale_log2 + LAZY_LOG2)) {
         const float m_new = fmaxf(m_run, tm);
@@ -310,18 +359,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
         if (!ONES) l_run *= alpha;
         m_run = m_new;
       }
-      const float mc = m_run * p.scale_log2;
+      mc = m_run * p.scale_log2;
+    }
+    // exp2 of one score register: FOLD scores are exp2's argument already
+    auto ex = [&](float x) { return FOLD ? __builtin_amdgcn_exp2f(x) : __builtin_amdgcn_exp2f(__builtin_fmaf(x, p.scale_log2, -mc)); };
+    const T* sV = sK + K_ELEMS;
+    if (piped) {
+      V8 vf[2][DT];                                  // V^T fragments of the first half's two chunks: requested before its exp2s
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2) vf[c][t2] = *reinterpret_cast<const V8*>(sV + vofs[c] + t2 * 32 * 64);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = ex(s[0][r]);
+        s[0][r] = e;
+        if (!ONES) ps += e;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int EPM = 16 / (2 * DT);             // exp2s of the second half behind every PV MFMA of the first
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        V8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[0][8 * c + j]);
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2) {
+          o[t2] = mfma32(vf[c][t2], pf, o[t2]);
+#pragma unroll
+          for (int r = (c * DT + t2) * EPM; r < (c * DT + t2 + 1) * EPM; ++r) {
+            const float e = ex(s[1][r]);
+            s[1][r] = e;
+            if (!ONES) ps += e;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int c = 2; c < 4; ++c) {
+        V8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(s[1][8 * (c & 1) + j]);
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2) {
+          const V8 vf2 = *reinterpret_cast<const V8*>(sV + vofs[c] + t2 * 32 * 64);
+          o[t2] = mfma32(vf2, pf, o[t2]);
+        }
+      }
+      if (!ONES) l_run += ps;
+    } else {
 #pragma unroll
       for (int kvt = 0; kvt < 2; ++kvt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvt][r], p.scale_log2, -mc));
+          const float e = ex(s[kvt][r]);
           s[kvt][r] = e;
           if (!ONES) ps += e;
         }
+      if (!ONES) l_run += ps;
+      pv(s, sV);
     }
-    if (!ONES) l_run += ps;
-    pv(s, sK + K_ELEMS);
   }
   {
     float l_tot;
@@ -504,6 +601,7 @@ extern "C" int tg_attention(const tg_attn_desc* d, void* stream) {
   p.w1_dev = d->w1_dev;
   p.out = d->out; p.out_ld = d->out_ld; p.out_bs = d->out_bs;
   p.causal = d->causal;
+  { const char* e = getenv("TG_ATTN_FLAGS"); p.flags = e ? (int)strtol(e, nullptr, 0) : 0; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return dispatch_attn<bf16_t>(d, p, st);
   return dispatch_attn<f16_t>(d, p, st);
