@@ -424,6 +424,25 @@ def bench_sd21_editing(args):
     assert torch.isfinite(gg).all() and float(gg.abs().max()) > 0
     saved.clear()
     by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(unet_call)
+    # the same iteration captured into ONE hipGraph (what it costs on the GPU without the host's Python between ~3000 launches)
+    guide_graph_ms, guide_graph_note = None, None
+    try:
+        gph = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(gph):
+                gl2, gg2 = eng_g.loss_and_grad(lat1, 741, enc1, loss_fn, keys)
+            gph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                gph.replay()
+            torch.cuda.synchronize()
+            guide_graph_ms = (time.perf_counter() - t1) / 3 * 1e3
+        guide_graph_note = "bit-identical to the eager iteration" if torch.equal(gg2, gg) and torch.equal(gl2, gl) else \
+            f"max |graph - eager| = {float((gg2 - gg).abs().max()):.3e}"
+        del gph
+    except Exception as e:                                  # capture is a measurement aid here, never a reason to lose the line
+        guide_graph_note = "capture failed: " + repr(e)[:160]
     ms_step = elapsed / n_timed * 1e3
     unet_ms = parts["unet"] / 5
     ach = PLAN_FLOP_PER_CFG_CALL["sd21"] / (unet_ms * 1e-3) / 1e12
@@ -440,6 +459,8 @@ def bench_sd21_editing(args):
         "images_per_s": round(1.0 / (ms_step * 1e-3 * steps), 4),
         "per_step_ms": {k: round(v / 5, 3) for k, v in parts.items()}, "compose_align_ms_once": round(compose_ms, 2),
         "latent_backward_guidance_iteration_ms": round(guide_ms, 1),
+        "latent_backward_guidance_iteration_graph_ms": None if guide_graph_ms is None else round(guide_graph_ms, 1),
+        "latent_backward_guidance_graph_note": guide_graph_note,
         "latent_backward_guidance_note": "one iteration = cond-only UNet forward to the last guidance key + compute_ca_lossv3 + d loss / d latents "
                                          "(explicit reverse pass, materialised attention probabilities per head: 9216-key self-attention rows at level 0); "
                                          "host wall time, eager; the reference runs up to 5 per step for the first 10 steps (dead code in its shipped flow)",

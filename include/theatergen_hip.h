@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 300
+#define TG_ABI_VERSION 301
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -277,8 +277,12 @@ int tg_step_epilogue(const float* noise_pred, float* latents, int32_t n_img, int
  *                     dtype with pitch ld_out >= length, pad columns zeroed            (ip_adapter/attention_processor.py:187-219)
  * tg_sumpool2x2     : sum over the 2 x 2 block of an upsampled token-major map [batch, 2h, 2w, C] -> [batch, h, w, C] (Upsample2D)
  */
+/* `partials`: fp32 scratch of tg_groupnorm_bwd_scratch_bytes(batch, hw, groups) — the rows of a batch item are cut into slabs so that the
+ * batch-1 backward pass spreads over the chip (three launches: statistics, gradient sums, apply; fixed-order folds).  NULL, or channels not a
+ * multiple of 8, runs the one-workgroup-per-(item, group) kernel. */
+int64_t tg_groupnorm_bwd_scratch_bytes(int32_t batch, int64_t hw, int32_t groups);
 int tg_groupnorm_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int64_t hw, int32_t channels, int32_t groups, float eps,
-                     const void* gamma, const void* beta, int32_t silu, void* dx, void* stream);
+                     const void* gamma, const void* beta, int32_t silu, void* dx, void* partials, void* stream);
 int tg_layernorm_bwd(int32_t dtype, const void* x, const void* dy, int64_t rows, int32_t channels, float eps, const void* gamma, void* dx,
                      void* stream);
 int tg_geglu_bwd(int32_t dtype, const void* h, const void* dg, int64_t rows, int64_t inner, void* dh, void* stream);

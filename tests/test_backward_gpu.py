@@ -35,7 +35,10 @@ def test_norm_and_activation_jacobians(dtype):
     g = torch.Generator().manual_seed(1)
     l2, mx = jt(dtype)
     # GroupNorm (+SiLU): token-major [B*hw, C]; 10 channels per group (SD level 0), 40 per group, and a tiny map
-    for (B, hw, C, groups, silu) in ((2, 64, 320, 32, True), (1, 256, 64, 32, False), (2, 16, 1280, 32, True), (1, 4, 64, 32, True)):
+    # round 3: slab-parallel kernels (rows of an item cut into slabs, 16-byte chunks): 2560 channels = two chunks per thread, a row count
+    # that leaves a ragged last slab, 9216 rows of the 768^2 plan's level 0; 36 channels = the one-workgroup-per-group fallback
+    for (B, hw, C, groups, silu) in ((2, 64, 320, 32, True), (1, 256, 64, 32, False), (2, 16, 1280, 32, True), (1, 4, 64, 32, True),
+                                     (1, 144, 2560, 32, True), (2, 577, 640, 32, False), (1, 9216, 320, 32, True), (1, 100, 36, 4, True)):
         x, dy = rnd((B * hw, C), dtype, g), rnd((B * hw, C), dtype, g)
         gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype), (0.2 * torch.randn(C, generator=g)).to(dtype)
         xr = x.float().reshape(B, hw, C).permute(0, 2, 1).clone().requires_grad_(True)

@@ -67,6 +67,136 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const T* x, const T*
   }
 }
 
+// ---- round 3: the same Jacobian spread over the chip --------------------------------------------------------------------
+// groupnorm_bwd_kernel above gives ONE workgroup to each (batch item, group): 32 workgroups for the batch-1 backward pass of
+// `latent_backward_guidance`, four scalar passes over strided 2-byte elements (222 us per launch on the 768^2 plan, a quarter
+// of the whole iteration).  Here the rows of a batch item are cut into slabs and a workgroup owns (batch item, slab) over ALL
+// channels with 16-byte accesses, in three launches that share one loop skeleton:
+//   PHASE 0  sum x, sum x^2 per (slab, group)                                   -> part[b][slab][g][0..1]
+//   PHASE 1  fold the statistics, then sum gy, sum gy * xhat per (slab, group)  -> part[b][slab][g][2..3]
+//   PHASE 2  fold both, dx = rstd * (gy - mean(gy) - xhat * mean(gy * xhat))
+// gy = gamma * dy * act'(gamma * xhat + beta).  Thread (tr, tc) walks rows tr, tr + TR, ... of the slab and the 8-channel chunks
+// tc, tc + 256 of every row; per-channel partial sums go through LDS and are folded per group in a FIXED order (channel-major,
+// then thread row), slabs are folded in fp64 in slab order: deterministic, no atomics.
+constexpr int GNB_MAX_SLOTS = 2;              // 8-channel chunks per thread and row: C <= 4096
+
+__host__ __device__ inline int gnb_slabs(int batch, long hw) {
+  long s = (hw + 31) / 32;                    // at least 32 rows per slab
+  const long cap = batch >= 512 ? 1 : 512 / batch;
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;                       // folded by one thread per group
+  return s < 1 ? 1 : (int)s;
+}
+
+template <typename T, int PHASE>
+__global__ __launch_bounds__(256) void gn_bwd_slab_kernel(const T* x, const T* dy, long hw, int C, int groups, float eps, const T* gamma,
+                                                         const T* beta, int silu, T* dx, float* part, int nslab) {
+  typedef typename Vec<T>::v8 V8;
+  extern __shared__ float gnb_smem[];
+  const int nch = C >> 3, cg = C / groups;
+  const int TC = nch < 256 ? nch : 256, TR = 256 / TC;
+  const int tid = threadIdx.x, tc = tid % TC, tr = tid / TC;
+  const bool active = tr < TR;
+  const int b = blockIdx.x / nslab, slab = blockIdx.x % nslab;
+  const long rows_per = (hw + nslab - 1) / nslab;
+  const long r0 = (long)slab * rows_per, r1 = r0 + rows_per < hw ? r0 + rows_per : hw;
+  float* sstat = gnb_smem;                    // [4][groups]: mean, rstd, m1, m2
+  float* spart = gnb_smem + 4 * groups;       // [2][TR][C]
+  const double inv_n = 1.0 / ((double)hw * cg);
+  float* pb = part + (long)b * nslab * groups * 4;
+  if (PHASE >= 1) {
+    if (tid < groups) {
+      double sx = 0.0, sq = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int z = 0; z < nslab; ++z) {
+        const float* q = pb + ((long)z * groups + tid) * 4;
+        sx += q[0]; sq += q[1];
+        if (PHASE == 2) { s1 += q[2]; s2 += q[3]; }
+      }
+      const double mean = sx * inv_n;
+      double var = sq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      sstat[tid] = (float)mean;
+      sstat[groups + tid] = (float)(1.0 / sqrt(var + (double)eps));
+      sstat[2 * groups + tid] = (float)(s1 * inv_n);
+      sstat[3 * groups + tid] = (float)(s2 * inv_n);
+    }
+    __syncthreads();
+  }
+  float a0[GNB_MAX_SLOTS][8], a1[GNB_MAX_SLOTS][8];
+#pragma unroll
+  for (int sl = 0; sl < GNB_MAX_SLOTS; ++sl)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0[sl][e] = 0.f; a1[sl][e] = 0.f; }
+#pragma unroll
+  for (int sl = 0; sl < GNB_MAX_SLOTS; ++sl) {
+    const int ch = tc + sl * 256;
+    if (!active || ch >= nch) continue;
+    const int c0 = ch * 8;
+    float mean8[8], rstd8[8], ga8[8], be8[8], m18[8], m28[8];
+    if (PHASE >= 1) {
+      const V8 gv = *reinterpret_cast<const V8*>(gamma + c0);
+      const V8 bv = *reinterpret_cast<const V8*>(beta + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / cg;
+        mean8[e] = sstat[g]; rstd8[e] = sstat[groups + g]; m18[e] = sstat[2 * groups + g]; m28[e] = sstat[3 * groups + g];
+        ga8[e] = to_f32<T>(gv[e]); be8[e] = to_f32<T>(bv[e]);
+      }
+    }
+    for (long r = r0 + tr; r < r1; r += TR) {
+      const long o = ((long)b * hw + r) * C + c0;
+      const V8 xv = *reinterpret_cast<const V8*>(x + o);
+      if (PHASE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = to_f32<T>(xv[e]); a0[sl][e] += v; a1[sl][e] += v * v; }
+      } else {
+        const V8 dv = *reinterpret_cast<const V8*>(dy + o);
+        V8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (to_f32<T>(xv[e]) - mean8[e]) * rstd8[e];
+          float gy = to_f32<T>(dv[e]);
+          if (silu) gy *= silu_grad_f(ga8[e] * xh + be8[e]);
+          gy *= ga8[e];
+          if (PHASE == 1) { a0[sl][e] += gy; a1[sl][e] += gy * xh; }
+          else ov[e] = from_f32<T>(rstd8[e] * (gy - m18[e] - xh * m28[e]));
+        }
+        if (PHASE == 2) *reinterpret_cast<V8*>(dx + o) = ov;
+      }
+    }
+    if (PHASE < 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        spart[(long)tr * C + c0 + e] = a0[sl][e];
+        spart[(long)(TR + tr) * C + c0 + e] = a1[sl][e];
+      }
+    }
+  }
+  if (PHASE < 2) {
+    __syncthreads();
+    if (tid < groups) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int c = tid * cg; c < (tid + 1) * cg; ++c)
+        for (int t = 0; t < TR; ++t) { s0 += spart[(long)t * C + c]; s1 += spart[(long)(TR + t) * C + c]; }
+      float* q = pb + ((long)slab * groups + tid) * 4;
+      q[PHASE == 0 ? 0 : 2] = s0;
+      q[PHASE == 0 ? 1 : 3] = s1;
+    }
+  }
+}
+
+template <typename T>
+void launch_gn_bwd_slabs(const T* x, const T* dy, int batch, long hw, int C, int groups, float eps, const T* gamma, const T* beta, int silu,
+                         T* dx, float* part, hipStream_t st) {
+  const int nslab = gnb_slabs(batch, hw);
+  const int nch = C >> 3, TC = nch < 256 ? nch : 256, TR = 256 / TC;
+  const size_t lds = ((size_t)4 * groups + (size_t)2 * TR * C) * sizeof(float);
+  const dim3 grid((unsigned)(batch * nslab));
+  hipLaunchKernelGGL((gn_bwd_slab_kernel<T, 0>), grid, dim3(256), lds, st, x, dy, hw, C, groups, eps, gamma, beta, silu, dx, part, nslab);
+  hipLaunchKernelGGL((gn_bwd_slab_kernel<T, 1>), grid, dim3(256), lds, st, x, dy, hw, C, groups, eps, gamma, beta, silu, dx, part, nslab);
+  hipLaunchKernelGGL((gn_bwd_slab_kernel<T, 2>), grid, dim3(256), lds, st, x, dy, hw, C, groups, eps, gamma, beta, silu, dx, part, nslab);
+}
+
 // LayerNorm backward wrt its input: one wave per row.
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* x, const T* dy, long rows, int C, float eps, const T* gamma, T* dx) {
@@ -158,11 +288,31 @@ inline unsigned grid_of(long n) {
 
 }  // namespace
 
-extern "C" int tg_groupnorm_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int64_t hw, int32_t channels, int32_t groups,
-                                float eps, const void* gamma, const void* beta, int32_t silu, void* dx, void* stream) {
+extern "C" int64_t tg_groupnorm_bwd_scratch_bytes(int32_t batch, int64_t hw, int32_t groups) {
+  if (batch <= 0 || hw <= 0 || groups <= 0) return 0;
+  return (int64_t)batch * gnb_slabs(batch, hw) * groups * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int tg_groupnorm_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int64_t hw, int32_t channels, int32_t groups, float eps,
+                                const void* gamma, const void* beta, int32_t silu, void* dx, void* partials, void* stream) {
   TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && dy && dx && gamma && beta, TG_ERR_ARG, "tg_groupnorm_bwd: bad args");
   TG_CHECK(batch > 0 && hw > 0 && groups > 0 && channels % groups == 0, TG_ERR_ARG, "tg_groupnorm_bwd: bad shape");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  // slab kernels: whole 16-byte channel chunks, at most two per thread and row, one folding thread per group; anything else (and a
+  // call without scratch) keeps the one-workgroup-per-group kernel
+  const bool slabs = partials != nullptr && channels % 8 == 0 && channels <= 8 * 256 * GNB_MAX_SLOTS && groups <= 256 && al16(x) && al16(dy) &&
+                     al16(dx) && al16(gamma) && al16(beta);
+  if (slabs) {
+    if (dtype == TG_BF16)
+      launch_gn_bwd_slabs<bf16_t>((const bf16_t*)x, (const bf16_t*)dy, batch, (long)hw, channels, groups, eps, (const bf16_t*)gamma, (const bf16_t*)beta, silu,
+                                  (bf16_t*)dx, (float*)partials, st);
+    else
+      launch_gn_bwd_slabs<f16_t>((const f16_t*)x, (const f16_t*)dy, batch, (long)hw, channels, groups, eps, (const f16_t*)gamma, (const f16_t*)beta, silu,
+                                 (f16_t*)dx, (float*)partials, st);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+  }
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(groupnorm_bwd_kernel<bf16_t>, dim3((unsigned)(batch * groups)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (int)hw,
                        channels, groups, eps, (const bf16_t*)gamma, (const bf16_t*)beta, silu, (bf16_t*)dx);

@@ -462,8 +462,10 @@ def guidance_ratio(attn, token, mask, scale, out, grad=None):
 def groupnorm_bwd(x, dy, batch, hw, groups, eps, gamma, beta, silu=False):
     _need_cuda(x)
     dx = torch.empty_like(x)
-    _lib.check(_lib.lib().tg_groupnorm_bwd(_dt(x), _ptr(x), _ptr(dy), int(batch), int(hw), x.shape[-1], int(groups), float(eps), _ptr(gamma),
-                                           _ptr(beta), 1 if silu else 0, _ptr(dx), _stream()))
+    L = _lib.lib()
+    scratch = workspace(L.tg_groupnorm_bwd_scratch_bytes(int(batch), int(hw), int(groups)), x.device)
+    _lib.check(L.tg_groupnorm_bwd(_dt(x), _ptr(x), _ptr(dy), int(batch), int(hw), x.shape[-1], int(groups), float(eps), _ptr(gamma),
+                                  _ptr(beta), 1 if silu else 0, _ptr(dx), _ptr(scratch), _stream()))
     return dx
 
 
