@@ -417,10 +417,11 @@ def bench_sd21_editing(args):
         gl, gg = eng_g.loss_and_grad(lat1, 741, enc1, loss_fn, keys)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(3):
+        n_guide = int(os.environ.get("TG_GUIDE_ITERS", "3"))       # dev: more iterations for a kernel-level profile of the reverse pass
+        for _ in range(n_guide):
             gl, gg = eng_g.loss_and_grad(lat1, 741, enc1, loss_fn, keys)
         torch.cuda.synchronize()
-        guide_ms = (time.perf_counter() - t1) / 3 * 1e3
+        guide_ms = (time.perf_counter() - t1) / n_guide * 1e3
     assert torch.isfinite(gg).all() and float(gg.abs().max()) > 0
     saved.clear()
     by_kernel, gemm_ms, gemm_fl = gemm_by_kernel(unet_call)
