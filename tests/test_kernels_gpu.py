@@ -922,3 +922,17 @@ def test_gemm_layernorm_fold_argument_errors():
         ops.gemm(x, w, 256, 64, 64, ln=(u, u, 0.0))                    # eps must be positive
     with pytest.raises(RuntimeError):
         ops.gemm(x, w, 256, 64, 64, ln=(u, u, 1e-5), force_split_k=2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 50, 37), (1, 64, 320), (3, 128, 64), (2, 384, 320), (1, 2304, 2304)])
+def test_transpose_bit_exact(dtype, shape):
+    """tg_transpose: the 32 x 32 tile kernel (any shape) and the 128 x 64 tile kernel (rows % 128 == 0, cols % 64 == 0: the long
+    self-attention maps of the reverse pass) move bits only."""
+    from theatergen_amd import ops
+    dev = _dev()
+    b, r, c = shape
+    g = torch.Generator().manual_seed(b * r + c)
+    x = torch.randn((b, r, c), generator=g).to(dtype).to(dev)
+    got = ops.transpose(x, b, r, c)
+    assert got.shape == (b, c, r) and torch.equal(got, x.transpose(1, 2).contiguous())

@@ -152,10 +152,14 @@ def attention_input_grad(attn, proc, h2d, B, N, enc, dout, extra):
                 dS, Pst = res if self_attn else (res, None)
                 ops.gemm(dS, kT[b, hh], N, d, Lp, res=dqh[b, hh], out=dqh[b, hh])                 # dQ += dS K   [N, d]
                 if self_attn:
-                    dST = torch.zeros((L, Np), dtype=dt, device=dev)
-                    dST[:, :N] = dS[:, :L].t()
-                    PT = torch.zeros((L, Np), dtype=dt, device=dev)
-                    PT[:, :N] = Pst[:, :L].t()
+                    if Np == N and Lp == L and dS.is_contiguous() and Pst.is_contiguous():
+                        dST = ops.transpose(dS, 1, N, L)              # tiled HIP transpose (tg_transpose): [N, L] -> [L, N]
+                        PT = ops.transpose(Pst, 1, N, L)
+                    else:                                             # row counts that need zero padding to a multiple of 8
+                        dST = torch.zeros((L, Np), dtype=dt, device=dev)
+                        dST[:, :N] = dS[:, :L].t()
+                        PT = torch.zeros((L, Np), dtype=dt, device=dev)
+                        PT[:, :N] = Pst[:, :L].t()
                     ops.gemm(dST, qT[b, hh], L, d, Np, out=dkh[b, hh])                            # dK = dS^T Q  [L, d]
                     ops.gemm(PT, doT[b, hh], L, d, Np, out=dvh[b, hh])                            # dV = P^T dO  [L, d]
 

@@ -281,6 +281,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src, int rows, 
     if (c0 + i < cols && r0 + tx < rows) d[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+// The same for large maps (rows % 128 == 0, cols % 64 == 0, 16-byte aligned): 128 x 64 tiles, 16-byte global reads along the source
+// rows, 64-byte contiguous pieces of the destination rows per thread.  Round 3: the reverse pass transposes dS and P of the long
+// self-attention rows (9216 x 9216 at 768^2: 170 MB each) per head; the strided torch copy it used ran at ~1 TB/s (355 us).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_big_kernel(const T* src, int rows, int cols, T* dst) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int TR = 128, TCc = 64, PITCH = TCc + 2;     // 33 dwords per tile row: the column gather below is conflict-free
+  __shared__ T tile[TR * PITCH];
+  const int b = blockIdx.z;
+  const long r0 = (long)blockIdx.y * TR, c0 = (long)blockIdx.x * TCc;
+  const T* s = src + (long)b * rows * cols;
+  T* d = dst + (long)b * rows * cols;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = it * 256 + tid;                         // vector index: row v / 8, 8-column group v % 8
+    const int r = v >> 3, cgp = v & 7;
+    const V8 x = *reinterpret_cast<const V8*>(s + (r0 + r) * cols + c0 + cgp * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {                      // 4-byte LDS stores (PITCH is even, cgp * 8 + e is even)
+      typedef T __attribute__((ext_vector_type(2))) V2;
+      V2 p2; p2[0] = x[e]; p2[1] = x[e + 1];
+      *reinterpret_cast<V2*>(&tile[r * PITCH + cgp * 8 + e]) = p2;
+    }
+  }
+  __syncthreads();
+  const int c = tid & 63, rg = tid >> 6;                  // destination row c0 + c, source rows rg * 32 .. + 32
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = tile[(rg * 32 + q * 8 + e) * PITCH + c];
+    *reinterpret_cast<V8*>(d + (c0 + c) * rows + r0 + rg * 32 + q * 8) = o;
+  }
+}
+
 inline int grid_for(long n, int per_thread = 1) {
   long b = (n / per_thread + 255) / 256;
   if (b < 1) b = 1;
@@ -695,6 +731,13 @@ extern "C" int tg_transpose(int32_t dtype, const void* src, int32_t batch, int32
   TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && src && dst && batch > 0 && rows > 0 && cols > 0 && src != dst, TG_ERR_ARG,
            "tg_transpose: bad args");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (rows % 128 == 0 && cols % 64 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    dim3 gridb(cols / 64, rows / 128, batch);
+    if (dtype == TG_BF16) hipLaunchKernelGGL(transpose_big_kernel<bf16_t>, gridb, dim3(256), 0, st, (const bf16_t*)src, rows, cols, (bf16_t*)dst);
+    else hipLaunchKernelGGL(transpose_big_kernel<f16_t>, gridb, dim3(256), 0, st, (const f16_t*)src, rows, cols, (f16_t*)dst);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+  }
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   if (dtype == TG_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, rows, cols, (bf16_t*)dst);
   else hipLaunchKernelGGL(transpose_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)src, rows, cols, (f16_t*)dst);
