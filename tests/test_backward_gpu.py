@@ -187,6 +187,18 @@ def test_unet_latent_gradient_and_guided_update(dtype, variant):
         # determinism of the whole reverse pass
         loss2, grad2 = UNetInputGrad(unet).loss_and_grad(lat.to(DEV, dtype), t, enc.to(DEV, dtype), loss_fn, keys)
         assert torch.equal(grad, grad2) and loss.item() == loss2.item()
+        # the same iteration captured into one hipGraph with the per-head chains on forked streams: same bits, also for a second input
+        from theatergen_amd.backward import GraphedInputGrad
+        gig = GraphedInputGrad(unet, lat.to(DEV, dtype), t, enc.to(DEV, dtype), loss_fn, keys, streams=3)
+        loss3, grad3 = gig.run()
+        torch.cuda.synchronize()
+        assert torch.equal(grad3, grad) and loss3.item() == loss.item()
+        lat_b = (lat * 0.5 + 0.1).to(DEV, dtype)
+        loss4, grad4 = gig.run(lat_b)
+        torch.cuda.synchronize()
+        loss5, grad5 = UNetInputGrad(unet).loss_and_grad(lat_b, t, enc.to(DEV, dtype), loss_fn, keys)
+        assert torch.equal(grad4, grad5) and loss4.item() == loss5.item()
+        del gig
     # one guided update through the reference-shaped entry point (smooth loss)
     loss_ref, grad_ref = grads_ref["ratio"]
     sch = DDIMScheduler()
