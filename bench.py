@@ -726,7 +726,7 @@ def other_configs_leg(args):
         try:
             r = fn(a)
             keep = ("metric", "value", "unit", "dtype", "images_per_s", "per_step_ms", "latent_backward_guidance_iteration_ms",
-                    "resampler_us_per_character", "resampler_us_per_character_graph_replay", "guidance")
+                    "latent_backward_guidance_iteration_graph_ms", "latent_backward_guidance_graph_note", "resampler_us_per_character", "resampler_us_per_character_graph_replay", "guidance")
             c = {k: r[k] for k in keep if k in r}
             c["workload"] = r["config"]["workload"]
             c["roofline"] = r["roofline"]
