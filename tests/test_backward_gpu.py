@@ -203,7 +203,8 @@ def test_unet_latent_gradient_and_guided_update(dtype, variant):
     loss_ref, grad_ref = grads_ref["ratio"]
     sch = DDIMScheduler()
     sch.set_timesteps(50)
-    new_lat, new_loss = latent_backward_guidance(None, sch, unet, enc.to(DEV, dtype), 0, boxes, pos, t, lat.to(DEV, dtype), 1e6,
+    enc_dev = enc.to(DEV, dtype)
+    new_lat, new_loss = latent_backward_guidance(None, sch, unet, enc_dev, 0, boxes, pos, t, lat.to(DEV, dtype), 1e6,
                                                  loss_scale=loss_scale, loss_threshold=0.0, max_iter=1, guidance_attn_keys=keys, **GUIDE_RATIO)
     osch = oddim.DDIMSchedule()
     step = float((1 - osch.alphas_cumprod[t]) ** 0.5)
@@ -211,6 +212,15 @@ def test_unet_latent_gradient_and_guided_update(dtype, variant):
     pm.check(new_lat, want, f"latents after one guidance iteration {dtype}", 4e-3 if dtype == torch.bfloat16 else 8e-4,
              2e-2 if dtype == torch.bfloat16 else 4e-3)
     assert abs(float(new_loss) - loss_ref.item()) <= 2e-2 * abs(loss_ref.item())
+    # the same update with the iteration replayed from a captured hipGraph (graphed=True), at this and at another timestep: same bits as eager
+    for tt in (t, 581):
+        eager_lat, eager_loss = latent_backward_guidance(None, sch, unet, enc_dev, 0, boxes, pos, tt, lat.to(DEV, dtype), 1e6, loss_scale=loss_scale,
+                                                         loss_threshold=0.0, max_iter=2, guidance_attn_keys=keys, **GUIDE_RATIO)
+        graph_lat, graph_loss = latent_backward_guidance(None, sch, unet, enc_dev, 0, boxes, pos, tt, lat.to(DEV, dtype), 1e6, loss_scale=loss_scale,
+                                                         loss_threshold=0.0, max_iter=2, guidance_attn_keys=keys, graphed=True, **GUIDE_RATIO)
+        assert torch.equal(eager_lat, graph_lat) and float(eager_loss) == float(graph_loss), tt
+    assert len(unet.__dict__["_graphed_input_grad"]) == 1          # one capture served both timesteps
+    unet.__dict__["_graphed_input_grad"].clear()
     # index >= max_index_step: untouched (reference :66)
     same, _ = latent_backward_guidance(None, sch, unet, enc.to(DEV, dtype), 10, boxes, pos, t, lat.to(DEV, dtype), 1e6, guidance_attn_keys=keys)
     assert torch.equal(same.cpu(), lat.to(dtype))

@@ -430,11 +430,15 @@ class GraphedInputGrad:
 def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss,
                              loss_scale=30, loss_threshold=0.2, max_iter=5, max_index_step=10, cross_attention_kwargs=None,
                              ref_ca_saved_attns=None, guidance_attn_keys=None, verbose=False, clear_cache=False, prompt_embeds=None,
-                             final=False, **kwargs):
+                             final=False, graphed=False, **kwargs):
     """Reference ``models/pipelines.py:62-128`` with the same signature: while the (de-scaled) loss is above the threshold, run the
     UNet on ``latents`` with the attention-map side channel, evaluate ``compute_ca_lossv3`` times ``loss_scale``, take
     d loss / d latents and step ``latents -= sqrt(1 - alpha_bar_t) * grad`` (the ``alphas_cumprod`` branch :108-115: DDIM has no
-    ``sigmas``).  ``loss`` is a Python float or a tensor (the reference passes a large initial value)."""
+    ``sigmas``).  ``loss`` is a Python float or a tensor (the reference passes a large initial value).
+    ``graphed=True`` (not a reference argument): the iteration is captured ONCE per (shapes, conditioning tensor, boxes, positions, keys,
+    loss arguments) into a hipGraph (``GraphedInputGrad``, cached on the UNet) and replayed for every iteration of every step — the
+    timestep is a device buffer of the graph; same bits as the eager loop.  Not available with ``ref_ca_saved_attns`` (per-step reference
+    maps are host-side inputs of the loss)."""
     from . import guidance as G
     from .pipelines import DEFAULT_GUIDANCE_ATTN_KEYS
     keys = [tuple(k) for k in (guidance_attn_keys if guidance_attn_keys is not None else DEFAULT_GUIDANCE_ATTN_KEYS)]
@@ -455,9 +459,24 @@ def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, b
     def val(v):
         return float(v.item()) if torch.is_tensor(v) else float(v)
 
+    gig = None
+    if graphed:
+        if ref_ca_saved_attns is not None or cross_attention_kwargs:
+            raise RuntimeError("latent_backward_guidance(graphed=True): ref_ca_saved_attns / cross_attention_kwargs need the eager loop")
+        cache = unet.__dict__.setdefault("_graphed_input_grad", {})
+        gkey = (tuple(latents.shape), str(unet.dtype), repr(bboxes), repr(object_positions), repr(keys), float(loss_scale),
+                repr(sorted(kwargs.items())))
+        gig = cache.get(gkey)
+        if gig is None or gig.enc is not cond_embeddings:
+            cache.clear()                                              # one captured iteration at a time (its buffers are GB-scale at 768^2)
+            gig = cache[gkey] = GraphedInputGrad(unet, scheduler.scale_model_input(lat32, t).to(unet.dtype), t, cond_embeddings, loss_fn, keys)
+
     while val(loss) / loss_scale > loss_threshold and iteration < max_iter and index < max_index_step:
         model_in = scheduler.scale_model_input(lat32, t).to(unet.dtype)
-        loss, grad = engine.loss_and_grad(model_in, t, cond_embeddings, loss_fn, keys, cross_attention_kwargs=cross_attention_kwargs)
+        if gig is not None:
+            loss, grad = gig.run(model_in, float(t))
+        else:
+            loss, grad = engine.loss_and_grad(model_in, t, cond_embeddings, loss_fn, keys, cross_attention_kwargs=cross_attention_kwargs)
         if not math.isfinite(val(loss)):
             print("**Loss is NaN**")
         if hasattr(scheduler, "sigmas"):
@@ -469,4 +488,6 @@ def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, b
         one = torch.ones(1, dtype=torch.float32, device=lat32.device)
         lat32 = ops.add_noise(lat32.reshape(-1), grad.reshape(-1), one, -step * one)[0].reshape(lat32.shape)       # latents - step * grad
         iteration += 1
+    if gig is not None and torch.is_tensor(loss):
+        loss = loss.clone()                                            # the graph's static output would change under the caller at the next replay
     return lat32.to(latents.dtype), loss
