@@ -49,6 +49,10 @@ def parse():
                          "HIP streams (same UNet weights).  2 is +2 % images/s, but every launch is then a half-batch call "
                          "overlapping with the other chain, so per-kernel roofline / rocprof figures are no longer those of "
                          "one kernel owning the chip: the default line keeps 1")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the SCALE line): every rank denoises ITS OWN story per step — work grows with N.  strong: ONE "
+                         "story per step in total, its 8 (turn, character) jobs split over the ranks (rank r: jobs r, r + N, ...; N must "
+                         "divide 8), image tokens broadcast from rank 0, final latents all-gathered back into job order")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--plan", default="sd15", choices=["sd15", "sd21", "sdxl"],
                     help="sd15 = the north-star line (BASELINE.json configs[1]); sd21 = configs[3] (768px editing step with 4-box "
@@ -582,8 +586,13 @@ def main():
     T = 4
     cfg, sd, unet, adapter = build_model(args.plan, dtype, device, num_tokens=T)
     ctx = cfg.cross_attention_dim
-    cb = args.char_batch
+    strong = args.scaling == "strong"
     jobs_per_story = 8
+    if strong:
+        if jobs_per_story % world or args.stage2 or args.with_vae or args.streams != 1:
+            raise SystemExit("bench.py: --scaling strong needs --gpus in {1, 2, 4, 8} and none of --stage2 / --with-vae / --streams")
+        args.char_batch = jobs_per_story // world            # a rank's share of the story is ONE CFG batch
+    cb = args.char_batch
     assert jobs_per_story % cb == 0, "--char-batch must divide 8"
     controlnet = None
     if args.stage2:
@@ -616,24 +625,31 @@ def main():
     D.broadcast_conditioning(shared, src=0)
 
     n_steps_total = args.warmup + args.steps
-    # every rank owns dialogues rank, rank + world, ...: one dialogue (story) per step
-    my_dialogues = [rank + world * s for s in range(n_steps_total)]
+    # weak: every rank owns dialogues rank, rank + world, ...: one dialogue (story) per step.  strong: every rank works on the SAME
+    # dialogue s and owns its jobs rank, rank + world, ... (theatergen_amd.distributed.run_story_strong)
+    my_dialogues = list(range(n_steps_total)) if strong else [rank + world * s for s in range(n_steps_total)]
     prepared = []
     for d in my_dialogues:
         jobs = story.story_jobs(d)
         char_ids = sorted({j.char_id for j in jobs})
         img_tok = story.character_image_tokens(char_ids, ctx, T, dtype, device)
+        if strong:
+            # the per-character image tokens are the shared payload of this partitioning: rank 0's copy is the one everybody uses
+            if rank != 0:
+                img_tok.zero_()
+            D.broadcast_conditioning({"image_tokens": img_tok}, src=0)
         cidx = {c: i for i, c in enumerate(char_ids)}
         batches = []
-        for b0 in range(0, len(jobs), cb):
-            jb = jobs[b0:b0 + cb]
+        mine = D.shard(jobs, rank, world) if strong else jobs
+        for b0 in range(0, len(mine), cb):
+            jb = mine[b0:b0 + cb]
             enc = story.job_conditioning(jb, shared, img_tok, cidx, ctx, dtype, device)
             lat = story.job_latents(jb, adapter)
             batches.append((enc, lat))
         prepared.append(batches)
     torch.cuda.synchronize()
 
-    finals = torch.zeros((jobs_per_story, cfg.in_channels, 64, 64), dtype=torch.float32, device=device)
+    finals = torch.zeros((cb if strong else jobs_per_story, cfg.in_channels, 64, 64), dtype=torch.float32, device=device)
 
     def run_story(batches):
         for bi, (enc, lat) in enumerate(batches):
@@ -657,7 +673,8 @@ def main():
             with torch.no_grad():
                 images_out = vae.decode_latents(finals)[0]
             assert images_out.shape[-1] == 512
-        return D.gather_latents(finals)
+        gathered = D.gather_latents(finals)
+        return D.unshard(gathered, world) if strong and world > 1 else gathered          # strong: back into (turn, character) order
 
     for s in range(args.warmup):
         run_story(prepared[s])
@@ -672,22 +689,25 @@ def main():
     elapsed = D.max_over_ranks(elapsed, device)
     assert torch.isfinite(gathered).all()
 
-    images = jobs_per_story * args.steps * world
+    images = jobs_per_story * args.steps * (1 if strong else world)
     value = images / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     cfg_calls = images * args.ddim_steps          # algorithmic units (batch-2 CFG UNet calls)
     result = {
         "metric": "512px 50-step char images/sec (node), CMIGBench 4-turn story",
         "value": round(value, 4), "unit": "char_images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SD-1.5 512x512, 4-turn story x 2 characters = 8 char images per step per GPU, {args.ddim_steps} DDIM "
                                f"steps, CFG 7.5, IP-Adapter 77+4 tokens scale 0.4, {args.dtype}, random-init weights",
                    "plan": args.plan, "char_batch": cb, "cfg_batch": 2 * cb, "streams": ns, "ddim_steps": args.ddim_steps,
-                   "parallelism": f"dialogue-sharded x{world} (RCCL broadcast + all_gather only)"},
+                   "parallelism": (f"one story's 8 (turn, character) jobs split x{world} (RCCL broadcast of image tokens + all_gather only)"
+                                   if strong else f"dialogue-sharded x{world} (RCCL broadcast + all_gather only)")},
         "whole_job_tflops": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12, 2),
         "whole_job_mfma_frac": round(cfg_calls * SD15_FLOP_PER_CFG_CALL / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
     }
+    if strong:
+        result["config"]["workload"] = result["config"]["workload"].replace("8 char images per step per GPU", "8 char images per step in TOTAL")
     if args.with_vae:
         result["metric"] = result["metric"] + " + VAE decode of every image"
         result["config"]["workload"] += "; each final latent decoded to 512x512 by the SD VAE decoder (49.5 M params) inside the timed region"

@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 301
+#define TG_ABI_VERSION 302
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -172,6 +172,10 @@ typedef struct {
   const float* w1_dev;  /* non-NULL: segment 1's weight is READ FROM THE DEVICE at run time (one fp32) and `w1` is ignored — the IP scale that
                          * IPAdapter.set_scale mutates per character and ip_adapter/custom_pipelines.py:328-333 gates per step: a captured
                          * hipGraph of the step replays with the current value */
+  const float* mask;    /* non-NULL: additive bias on segment 0's scores, fp32, score units (the diffusers `attention_mask` after
+                         * `prepare_attention_mask`, ip_adapter/attention_processor.py:193-206, 221-259):
+                         * mask[b * mask_bs + h * mask_hs + i * mask_qs + j]; zero strides broadcast over heads / queries */
+  int64_t mask_bs, mask_hs, mask_qs;
 } tg_attn_desc;
 
 int tg_attention(const tg_attn_desc* d, void* stream);

@@ -2,6 +2,8 @@
 """50-step drift curve: SD-1.5 512x512, one character box, 50 DDIM steps, CFG 7.5, latents by the
 reference recipe; the HIP path (bf16 / fp16, hipGraph engine) against the fp32 CPU oracle loop, relative L2 and max error of the
 latents after steps 1 / 5 / 10 / 20 / 50.  ~4-5 minutes of fp32 CPU oracle at 64 threads per dtype.
+The asserting version of this at the BENCH shape (8 images x 50 steps) is tests/test_parity_fullsize_gpu.py::
+test_bench_shape_8_images_50_steps_vs_oracle_loop; the chain / metric logic lives in tests/parity_metrics.py (one copy).
 
 Round 3: with random-init weights the predicted noise is uncorrelated with the latents, so both chains grow by
 sqrt(alpha_bar_0 / alpha_bar_T) ~ 14x over the run (|x|max 3.9 -> 54) and the latents' rel-L2 mostly measures that common mode.
@@ -27,8 +29,6 @@ def main():
     ap.add_argument("--dtypes", default="bf16")
     ap.add_argument("--steps", type=int, default=50)
     args = ap.parse_args()
-    from oracle import ddim as oddim
-    from oracle import unet as ou
     from tests import parity_metrics as pm
     from theatergen_amd import config, latents as L, story, weights as W
     from theatergen_amd.ip_adapter import IPAdapter
@@ -52,28 +52,9 @@ def main():
         eng = DenoiseEngine(unet, None, n_img=1, height=512, width=512, num_inference_steps=args.steps, guidance_scale=7.5, enc_len=81)
         eng.set_conditioning(enc.to(dev, dtype))
         hist = eng.run(lat).cpu()
-        osch = oddim.DDIMSchedule()
-        osch.set_timesteps(args.steps)
-        ref, encr, curve = lat.clone(), enc.to(dtype).float(), {}
-
-        def net_terms(x_prev, x_next, t):
-            """(eps, x0) of the epsilon-prediction DDIM step that took x_prev to x_next (eta = 0): x_next = A x_prev + B eps"""
-            a_t, a_prev = [float(v) for v in osch.coeffs(t)]
-            A = (a_prev / a_t) ** 0.5
-            B = (1 - a_prev) ** 0.5 - A * (1 - a_t) ** 0.5
-            eps = (x_next.double() - A * x_prev.double()) / B
-            return eps, (x_prev.double() - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
-        for i, t in enumerate(osch.timesteps.tolist()):
-            mi = torch.cat([ref] * 2).to(dtype).float()
-            prev = ref
-            ref = oddim.step_epilogue(osch, ou.unet_forward(cfg, sd_r, mi, t, encr, ip_scale=0.4, num_tokens=4), t, ref, 7.5)
-            if i + 1 in marks:
-                curve[str(i + 1)] = pm.metrics(hist[i + 1], ref)
-                eps_r, x0_r = net_terms(prev, ref, t)
-                eps_h, x0_h = net_terms(hist[i], hist[i + 1], t)
-                curve[str(i + 1)]["eps"] = pm.metrics(eps_h, eps_r)
-                curve[str(i + 1)]["x0"] = pm.metrics(x0_h, x0_r)
-                print(name, i + 1, curve[str(i + 1)], file=sys.stderr, flush=True)
+        curve = pm.oracle_chain_metrics(cfg, sd_r, hist[:, 0:1], lat, enc, dtype, args.steps, marks,
+                                        log=lambda k, m: print(name, k, m, file=sys.stderr, flush=True))
+        curve = {str(k): v for k, v in curve.items()}
         out["curves"][name] = curve
         del unet, eng, adapter
         torch.cuda.empty_cache()

@@ -136,3 +136,56 @@ class FakeTokenizer:
 
     def _convert_id_to_token(self, i):
         return self.inv[i]
+
+
+# ---- round 4: the pre-projection branches of AttnProcessor (reference ip_adapter/attention_processor.py:316-347) ----
+# (name, ctor kwargs of Attention, cross?, mask kind, 4-D input?)
+BRANCH_C, BRANCH_HEADS, BRANCH_CTX, BRANCH_N, BRANCH_L = 128, 4, 96, 64, 24
+BRANCH_CASES = [
+    ("gn_self4d", dict(norm_num_groups=8, residual_connection=True, rescale_output_factor=2.0), False, None, True),
+    ("gn_self_bias", dict(norm_num_groups=16, bias=True), False, None, False),
+    ("lnx_cross", dict(cross_attention_norm="layer_norm"), True, None, False),
+    ("gnx_cross", dict(cross_attention_norm="group_norm", cross_attention_norm_num_groups=8), True, None, False),
+    ("mask_self_b1l", dict(), False, "b1l", False),
+    ("mask_self_bql", dict(), False, "bql", False),
+    ("mask_cross_b1l", dict(bias=True), True, "b1l", False),
+    ("mask_cross_bhql", dict(), True, "bhql", False),
+]
+
+
+def branch_params(name, kw, cross, seed):
+    """state dict (reference parameter names) + inputs of one branch case"""
+    g = torch.Generator().manual_seed(seed)
+    C, ctx = BRANCH_C, (BRANCH_CTX if cross else BRANCH_C)
+    sd = {"to_q.weight": _u((C, C), C, g), "to_k.weight": _u((C, ctx), ctx, g), "to_v.weight": _u((C, ctx), ctx, g),
+          "to_out.0.weight": _u((C, C), C, g), "to_out.0.bias": _u((C,), C, g)}
+    if kw.get("bias"):
+        for n in ("to_q", "to_k", "to_v"):
+            sd[n + ".bias"] = 0.3 * torch.randn(C, generator=g)
+    if kw.get("norm_num_groups"):
+        sd["group_norm.weight"] = 1 + 0.2 * torch.randn(C, generator=g)
+        sd["group_norm.bias"] = 0.2 * torch.randn(C, generator=g)
+    if kw.get("cross_attention_norm"):
+        sd["norm_cross.weight"] = 1 + 0.2 * torch.randn(ctx, generator=g)
+        sd["norm_cross.bias"] = 0.2 * torch.randn(ctx, generator=g)
+    x = torch.randn(2, BRANCH_N, C, generator=g) * 1.5 + 0.5
+    enc = (torch.randn(2, BRANCH_L, ctx, generator=g) * 0.7 + 0.2) if cross else None
+    return sd, x, enc
+
+
+def branch_mask(kind, cross, seed):
+    """additive bias masks in the form UNet2DConditionModel builds them ((1 - m) * -10000, models/unet_2d_condition.py:785-796) and
+    the denser forms baddbmm accepts"""
+    if kind is None:
+        return None
+    g = torch.Generator().manual_seed(seed)
+    L = BRANCH_L if cross else BRANCH_N
+    if kind == "b1l":
+        keep = (torch.rand(2, 1, L, generator=g) > 0.3).float()
+        keep[..., 0] = 1
+        return (1 - keep) * -10000.0
+    if kind == "bql":
+        return torch.randn(2, BRANCH_N, L, generator=g) * 2
+    if kind == "bhql":
+        return torch.randn(2 * BRANCH_HEADS, BRANCH_N, L, generator=g) * 2
+    raise ValueError(kind)

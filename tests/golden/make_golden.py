@@ -121,6 +121,25 @@ def gen_attention(ref, out):
         print("attention", name, "done")
 
 
+def gen_attention_branches(ref, out):
+    """AttnProcessor's pre-projection branches on the reference's own Attention / AttnProcessor (:316-347): group_norm (+ 4-D
+    input, residual, rescale), q/k/v bias, norm_cross (LayerNorm / GroupNorm), attention_mask as an additive bias."""
+    A = ref.attnproc
+    for ci, (name, kw, cross, mkind, four_d) in enumerate(gc.BRANCH_CASES):
+        sd, x, enc = gc.branch_params(name, kw, cross, seed=700 + ci)
+        attn = A.Attention(query_dim=gc.BRANCH_C, cross_attention_dim=gc.BRANCH_CTX if cross else None, heads=gc.BRANCH_HEADS,
+                           dim_head=gc.BRANCH_C // gc.BRANCH_HEADS, **kw)
+        attn.load_state_dict(sd)
+        mask = gc.branch_mask(mkind, cross, seed=800 + ci)
+        xin = x
+        if four_d:
+            h = int(gc.BRANCH_N ** 0.5)
+            xin = x.transpose(1, 2).reshape(2, gc.BRANCH_C, h, h).contiguous()
+        with torch.no_grad():
+            out[f"{name}.out"] = A.AttnProcessor()(attn, xin, encoder_hidden_states=enc, attention_mask=mask).numpy()
+        print("attention branch", name, "done")
+
+
 def gen_resampler(ref, out):
     from theatergen_amd import weights as W
     for ci, (name, case) in enumerate(gc.RESAMPLER_CASES.items()):
@@ -320,7 +339,7 @@ def gen_geometry_latents(ref, out):
 def main():
     ref = load_reference()
     torch.set_num_threads(8)
-    jobs = {"attn": gen_attention, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
+    jobs = {"attn": gen_attention, "attn_branches": gen_attention_branches, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
             "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half}
     only = sys.argv[1:]
     for name, fn in jobs.items():

@@ -406,26 +406,139 @@ def test_shift_tensor_ignore_last_dim_matches_reference_formula():
 
 
 def test_processor_branches_outside_the_hot_path_fail_loudly():
-    """The diffusers processor features the TheaterGen flow never uses (ip_adapter/attention_processor.py:316-331, 340-354:
-    attention_mask / prepare_attention_mask, attn_process_fn, group_norm / spatial_norm / norm_cross, added_kv) are refused with an
-    explicit error — never silently ignored, never a CPU fallback."""
+    """Processor features no diffusers SD / SDXL module builds (ip_adapter/attention_processor.py:316-317 spatial_norm, :350-352
+    attn_process_fn, added_kv) are refused with an explicit error — never silently ignored, never a CPU fallback.  group_norm,
+    norm_cross and attention_mask ARE implemented since round 4 (tests/test_round4_gpu.py); a malformed mask is a RuntimeError."""
     import pytest
     import torch
     from theatergen_amd.attention_processor import Attention, AttnProcessor, IPAttnProcessor
     attn = Attention(query_dim=64, heads=2, dim_head=32)
     x = torch.zeros(1, 8, 64)
     with pytest.raises(NotImplementedError):
-        AttnProcessor()(attn, x, attention_mask=torch.zeros(1, 8, 8))
-    with pytest.raises(NotImplementedError):
         AttnProcessor()(attn, x, attn_process_fn=lambda p: p)
     with pytest.raises(RuntimeError):
         AttnProcessor()(attn, x)                                     # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        AttnProcessor()(attn, x, attention_mask=torch.zeros(1, 8, 8))     # still a CPU tensor
     cross = Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                                 # the reference's baddbmm rejects the shapes too (:461-477)
         IPAttnProcessor(64, 32)(cross, x, encoder_hidden_states=torch.zeros(1, 9, 32), attention_mask=torch.zeros(1, 8, 9))
-    for kw in (dict(norm_num_groups=32), dict(spatial_norm_dim=8), dict(cross_attention_norm="layer_norm"), dict(added_kv_proj_dim=16)):
+    for kw in (dict(spatial_norm_dim=8), dict(added_kv_proj_dim=16)):
         with pytest.raises(ValueError):
             Attention(query_dim=64, heads=2, dim_head=32, **kw)
+    with pytest.raises(ValueError):
+        Attention(query_dim=64, heads=2, dim_head=32, cross_attention_norm="batch_norm")
+    # the norms the reference constructor builds (:80-110) are built here as well
+    a2 = Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32, norm_num_groups=8, cross_attention_norm="layer_norm", bias=True)
+    assert isinstance(a2.group_norm, torch.nn.GroupNorm) and isinstance(a2.norm_cross, torch.nn.LayerNorm) and a2.to_q.bias is not None
+    a3 = Attention(query_dim=64, cross_attention_dim=64, heads=2, dim_head=32, cross_attention_norm="group_norm")
+    assert isinstance(a3.norm_cross, torch.nn.GroupNorm) and a3.norm_cross.num_groups == 32
+    spat = Attention(query_dim=64, heads=2, dim_head=32)
+    spat.spatial_norm = object()
+    with pytest.raises(NotImplementedError):
+        AttnProcessor()(spat, x)
+
+
+def _fake_ops():
+    """shape-only stand-ins for theatergen_amd.ops (no compute): lets the processors' HOST logic run on CPU tensors"""
+    import types
+    import torch
+
+    def gemm(a0, w, M, N, K, **kw):
+        return kw["out"] if kw.get("out") is not None else torch.empty((M, N), dtype=a0.dtype)
+
+    def attn_probs(q, q_ld, q_bs, k, k_ld, k_bs, batch, b0, heads, head_dim, n_q, length, scale, tokens=None):
+        return torch.zeros((batch - b0, heads, n_q, length if tokens is None else tokens.numel()))
+
+    return types.SimpleNamespace(
+        gemm=gemm, attn_probs=attn_probs,
+        linear=lambda x, w, bias=None, **kw: torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype),
+        attention=lambda *a, **kw: a[15],
+        groupnorm=lambda x0, *a, **kw: torch.empty_like(x0),
+        layernorm=lambda x, *a, **kw: torch.empty_like(x),
+        transpose=lambda src, batch, rows, cols, out=None: torch.empty((batch, cols, rows), dtype=src.dtype))
+
+
+class _AttrRecorder:
+    """forwards attribute reads to a REFERENCE Attention instance and records every name that instance does not have"""
+
+    def __init__(self, target):
+        object.__setattr__(self, "_target", target)
+        object.__setattr__(self, "seen", set())
+        object.__setattr__(self, "missing", set())
+
+    def __getattr__(self, name):
+        self.seen.add(name)
+        if not hasattr(self._target, name):
+            self.missing.add(name)
+            raise AttributeError(name)
+        return getattr(self._target, name)
+
+
+def _reference_attention_module():
+    """ip_adapter/attention_processor.py of the reference, imported by path with a stub `diffusers.utils` (build container only)"""
+    import importlib.util
+    import logging
+    import sys
+    import types
+    ref = os.environ.get("TG_REFERENCE", "/root/reference")
+    path = os.path.join(ref, "ip_adapter", "attention_processor.py")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("the reference checkout is only present in the build container")
+    saved = {k: sys.modules.get(k) for k in ("diffusers", "diffusers.utils")}
+    du = types.ModuleType("diffusers.utils")
+    du.deprecate = lambda *a, **k: None
+    du.logging = types.SimpleNamespace(get_logger=logging.getLogger)
+    d = types.ModuleType("diffusers")
+    d.utils = du
+    d.__path__ = []
+    sys.modules.update({"diffusers": d, "diffusers.utils": du})
+    try:
+        spec = importlib.util.spec_from_file_location("ref_ip_attnproc_boundary", path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return m
+
+
+def test_processors_touch_only_attributes_of_the_reference_attention(monkeypatch):
+    """SURVEY §8(b) / INTEGRATION.md level 2: our processors installed on the REFERENCE `Attention` (ip_adapter/attention_processor.py
+    :12-279).  Every attribute they read must exist on that class — `inner_dim` / `dim_head` / packed-weight helpers do not."""
+    import torch
+    from theatergen_amd import attention_processor as AP
+    A = _reference_attention_module()
+    monkeypatch.setattr(AP, "ops", _fake_ops())
+    monkeypatch.setattr(AP, "_need_gpu", lambda t: None)
+    x = torch.zeros(2, 16, 64)
+    enc = torch.zeros(2, 77 + 4, 32)
+    cases = [
+        (A.Attention(query_dim=64, heads=2, dim_head=32), AP.AttnProcessor(), dict()),
+        (A.Attention(query_dim=64, heads=2, dim_head=32, norm_num_groups=8, residual_connection=True, bias=True), AP.AttnProcessor(),
+         dict(attention_mask=torch.zeros(2, 1, 16))),
+        (A.Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32, cross_attention_norm="layer_norm"), AP.AttnProcessor(),
+         dict(encoder_hidden_states=enc, save_attn_to_dict={}, attn_key=["mid", 0, 0, 0], return_cond_ca_only=True, return_token_ca_only=3)),
+        (A.Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32), AP.IPAttnProcessor(64, 32, scale=0.4, num_tokens=4),
+         dict(encoder_hidden_states=enc, save_attn_to_dict={}, attn_key=["mid", 0, 0, 0])),
+        (A.Attention(query_dim=64, cross_attention_dim=32, heads=2, dim_head=32), AP.CNAttnProcessor(num_tokens=4),
+         dict(encoder_hidden_states=enc)),
+    ]
+    for ref_attn, proc, kw in cases:
+        rec = _AttrRecorder(ref_attn)
+        out = proc(rec, x, **kw)
+        out = out[0] if isinstance(out, tuple) else out
+        assert out.shape == x.shape
+        assert not rec.missing, f"{type(proc).__name__} read attributes the reference Attention lacks: {sorted(rec.missing)}"
+        assert {"heads", "to_q", "to_out"} <= rec.seen
+    # 4-D input (the VAE mid-block usage) on the reference module, dispatched through ITS set_processor / forward
+    ref_attn = A.Attention(query_dim=64, heads=2, dim_head=32, norm_num_groups=8, residual_connection=True, rescale_output_factor=2.0)
+    ref_attn.set_processor(AP.AttnProcessor())
+    assert ref_attn(torch.zeros(2, 64, 4, 4)).shape == (2, 64, 4, 4)
 
 
 def test_ip_scale_is_a_plain_mutable_attribute():

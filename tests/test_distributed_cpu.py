@@ -75,3 +75,88 @@ def test_bench_self_launches_its_ranks_world2():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
+
+
+def _strong_inputs_and_denoise(shared, img_tok, cidx, ctx):
+    """CPU stand-ins with the engine's interface: conditioning by the bench's own story.job_conditioning, a per-image deterministic
+    'denoiser' (every image computed on its own, so the bits cannot depend on which rank or batch an image lands in)."""
+    from theatergen_amd import story
+
+    def make_inputs(jobs):
+        enc = story.job_conditioning(jobs, shared, img_tok, cidx, ctx, torch.float32, "cpu")
+        lat = torch.stack([torch.randn((4, 8, 8), generator=torch.Generator().manual_seed(j.bg_seed * 7 + j.char)) for j in jobs])
+        return enc, lat
+
+    def denoise(enc, lat):
+        n = lat.shape[0]
+        out = []
+        for i in range(n):
+            neg, pos = enc[i], enc[n + i]
+            x = lat[i]
+            for _ in range(3):
+                x = torch.tanh(x * pos[-4:].mean() + neg.std()) + 0.1 * pos[:77].mean(0)[:8].reshape(1, 1, 8)
+            out.append(x)
+        return torch.stack(out)
+
+    return make_inputs, denoise
+
+
+def _strong_worker(rank, world, port, out):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from theatergen_amd import distributed as D
+    from theatergen_amd import story
+    D.init(backend="gloo")
+    ctx, T = 32, 4
+    jobs = story.story_jobs(2)
+    shared = story.shared_conditioning(ctx, T, torch.float32, "cpu")
+    char_ids = sorted({j.char_id for j in jobs})
+    img_tok = story.character_image_tokens(char_ids, ctx, T, torch.float32, "cpu")
+    if rank != 0:                       # only rank 0's copy counts: what the others hold before the broadcast must not matter
+        for v in shared.values():
+            v.fill_(123.0)
+        img_tok.fill_(-7.0)
+    D.broadcast_conditioning(shared, src=0)
+    D.broadcast_conditioning({"image_tokens": img_tok}, src=0)
+    cidx = {c: i for i, c in enumerate(char_ids)}
+    make_inputs, denoise = _strong_inputs_and_denoise(shared, img_tok, cidx, ctx)
+    got = D.run_story_strong(jobs, rank, world, make_inputs, denoise)
+    mine = [(j.turn, j.char) for j in D.shard(jobs, rank, world)]
+    out.put((rank, mine, got))
+    torch.distributed.destroy_process_group()
+
+
+def test_strong_scaling_partition_equals_single_rank_bit_for_bit():
+    """SURVEY §8(e), second partitioning: one story's 8 (turn, character) jobs over 2 ranks, image tokens
+    broadcast, final latents all-gathered and un-sharded == the single-rank result, bit for bit (reference independence argument:
+    theatergen.py:214-271, one independent generation per (turn, character))."""
+    from theatergen_amd import distributed as D
+    from theatergen_amd import story
+    ctx_, T = 32, 4
+    jobs = story.story_jobs(2)
+    shared = story.shared_conditioning(ctx_, T, torch.float32, "cpu")
+    char_ids = sorted({j.char_id for j in jobs})
+    img_tok = story.character_image_tokens(char_ids, ctx_, T, torch.float32, "cpu")
+    cidx = {c: i for i, c in enumerate(char_ids)}
+    make_inputs, denoise = _strong_inputs_and_denoise(shared, img_tok, cidx, ctx_)
+    single = D.run_story_strong(jobs, 0, 1, make_inputs, denoise)            # no process group: the whole story on one rank
+    assert single.shape == (8, 4, 8, 8)
+    # unshard is the exact inverse of the round-robin shard
+    ids = torch.arange(8.0)
+    gathered = torch.cat([ids[r::2] for r in range(2)])
+    assert torch.equal(D.unshard(gathered, 2), ids)
+    gathered4 = torch.cat([ids[r::4] for r in range(4)])
+    assert torch.equal(D.unshard(gathered4, 4), ids)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [(1, 0), (2, 0), (3, 0), (4, 0)] and res[1][1] == [(1, 1), (2, 1), (3, 1), (4, 1)]      # rank = character here
+    for rank, _, got in res:
+        assert torch.equal(got, single), f"rank {rank}: gathered story differs from the single-rank result"

@@ -23,6 +23,28 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
+def _branch_call(ci):
+    """(oracle kwargs, inputs) of gc.BRANCH_CASES[ci] — shared with the GPU test"""
+    name, kw, cross, mkind, four_d = gc.BRANCH_CASES[ci]
+    sd, x, enc = gc.branch_params(name, kw, cross, seed=700 + ci)
+    mask = gc.branch_mask(mkind, cross, seed=800 + ci)
+    xin = x
+    if four_d:
+        h = int(gc.BRANCH_N ** 0.5)
+        xin = x.transpose(1, 2).reshape(2, gc.BRANCH_C, h, h).contiguous()
+    okw = {k: v for k, v in kw.items() if k != "bias"}
+    return name, sd, xin, enc, mask, okw
+
+
+@pytest.mark.parametrize("ci", range(len(gc.BRANCH_CASES)))
+def test_attention_processor_branches(golden_dir, ci):
+    """group_norm / q-k-v bias / norm_cross / attention_mask branches of AttnProcessor (reference :316-347) vs the imported reference"""
+    gold = _load(golden_dir, "attn_branches")
+    name, sd, xin, enc, mask, okw = _branch_call(ci)
+    got = oattn.attn_processor(sd, gc.BRANCH_HEADS, xin, enc, attention_mask=mask, **okw)
+    np.testing.assert_allclose(got.numpy(), gold[f"{name}.out"], rtol=2e-5, atol=4e-6)
+
+
 @pytest.mark.parametrize("ci", range(len(gc.ATTN_CASES)))
 def test_attention_processors(golden_dir, ci):
     gold = _load(golden_dir, "attn")

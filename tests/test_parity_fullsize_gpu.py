@@ -104,6 +104,46 @@ def test_config1_sd15_one_box_20_steps_vs_oracle_loop():
         assert m["finite"] and m["rel_l2"] <= 1.5e-2 and m["max_rel"] <= 3.0e-2, f"latents after step {k}/20: {m}"
 
 
+def test_bench_shape_8_images_50_steps_vs_oracle_loop():
+    """BASELINE.json configs[1] at the shape bench.py times: ONE whole story = 8 character images, CFG batch 16,
+    50 DDIM steps on the hipGraph engine, built by the same story.* helpers as bench.py; the fp32 CPU oracle loop follows ONE of the
+    eight images (image 5 = turn 3, character 1) for all 50 steps (~4.5 min at 64 threads).
+    Asserted at steps 1 / 10 / 25 / 50: latents rel-L2 <= 1.5e-2, max <= 3e-2; and the network's own contribution (x0 recovered in
+    fp64 from consecutive history rows, tests/parity_metrics.py::ddim_net_terms) does NOT compound: rel-L2 of x0 at step 50 within
+    1.5x of its value at step 1, every mark <= 4e-2 (measured round 3 at batch 1: 2.3e-2 -> 1.3e-2 -> 1.1e-2)."""
+    from theatergen_amd import config, story
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.pipelines import DenoiseEngine, SDPipe
+    dtype = torch.bfloat16
+    cfg = config.sd15()
+    unet, sd_r = _build(cfg, dtype)
+    adapter = IPAdapter(SDPipe(unet), None, None, DEV, num_tokens=4)
+    adapter.set_scale(0.4)
+    steps, T, ctx = 50, 4, cfg.cross_attention_dim
+    jobs = story.story_jobs(3)                                  # dialogue 3: 4 turns x 2 characters
+    assert len(jobs) == 8
+    shared = story.shared_conditioning(ctx, T, dtype, DEV)
+    char_ids = sorted({j.char_id for j in jobs})
+    img_tok = story.character_image_tokens(char_ids, ctx, T, dtype, DEV)
+    cidx = {c: i for i, c in enumerate(char_ids)}
+    enc = story.job_conditioning(jobs, shared, img_tok, cidx, ctx, dtype, DEV)          # [16, 81, 768]: negatives first
+    lat = story.job_latents(jobs, adapter)                                              # [8, 4, 64, 64] fp32
+    eng = DenoiseEngine(unet, None, n_img=8, height=512, width=512, num_inference_steps=steps, guidance_scale=7.5, enc_len=77 + T)
+    eng.set_conditioning(enc)
+    hist = eng.run(lat).cpu()
+    assert hist.shape == (steps + 1, 8, 4, 64, 64) and torch.isfinite(hist).all()
+    _threads()
+    img = 5
+    curve = pm.oracle_chain_metrics(cfg, sd_r, hist[:, img:img + 1], lat[img:img + 1].cpu(), enc[[img, 8 + img]].float().cpu(), dtype, steps,
+                                    marks=(1, 10, 25, 50),
+                                    log=lambda k, m: pm.record(f"bench shape (8 images, CFG batch 16): image {img} after step {k}/50 vs fp32 oracle loop",
+                                                               m, step=k))
+    for k, m in curve.items():
+        assert m["finite"] and m["rel_l2"] <= 1.5e-2 and m["max_rel"] <= 3.0e-2, f"latents after step {k}/50: {m}"
+        assert m["x0"]["rel_l2"] <= 4e-2, f"x0 at step {k}/50: {m['x0']}"
+    assert curve[50]["x0"]["rel_l2"] <= 1.5 * curve[1]["x0"]["rel_l2"], f"x0 error compounds: {curve[1]['x0']} -> {curve[50]['x0']}"
+
+
 def test_reference_shaped_loop_two_characters_fresh_embeddings():
     """reference models/pipelines.py:406-453 on the drop-in boundary (INTEGRATION.md level 1), two characters back to back."""
     from oracle import ddim as oddim

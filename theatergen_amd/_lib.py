@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 301          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 302          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -38,6 +38,7 @@ class AttnDesc(C.Structure):
         ("k0", vp), ("k0_ld", i64), ("k0_bs", i64), ("vt0", vp), ("vt0_ld", i64), ("vt0_bs", i64), ("len0", i32),
         ("k1", vp), ("k1_ld", i64), ("k1_bs", i64), ("vt1", vp), ("vt1_ld", i64), ("vt1_bs", i64), ("len1", i32),
         ("scale", f32), ("w1", f32), ("out", vp), ("out_ld", i64), ("out_bs", i64), ("causal", i32), ("w1_dev", vp),
+        ("mask", vp), ("mask_bs", i64), ("mask_hs", i64), ("mask_qs", i64),
     ]
 
 
@@ -125,7 +126,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         got = h.tg_version()
-        if got != ABI_VERSION:
+        # dev A/B of an OLDER build of the same ABI family (scripts/ab.py: old .so vs new .so on one box): descriptor fields are only ever
+        # appended, so a library one revision behind reads a prefix of what this binding writes.  Never the default path.
+        compat = os.environ.get("THEATERGEN_HIP_LIB") and os.environ.get("THEATERGEN_HIP_ABI_COMPAT") == str(got)
+        if got != ABI_VERSION and not compat:
             raise RuntimeError(f"theatergen_amd: {LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: "
                                "rebuild with `python -m theatergen_amd.build` (a stale library would misread descriptors)")
         _lib = h

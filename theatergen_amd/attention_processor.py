@@ -15,6 +15,14 @@ What differs: the computation.  ``baddbmm -> softmax -> bmm`` with a materialise
 disappear because the kernel reads Q / K / V^T straight from the projection GEMM outputs; the two softmaxes
 of the IP path stay independent (segment 1 of the kernel).  ``torch.nn`` modules are used as parameter
 containers only; there is no PyTorch compute and no CPU fallback.
+
+DROP-IN CONTRACT (INTEGRATION.md level 2): the processors read from ``attn`` ONLY what the reference
+``Attention`` (:12-279) and diffusers 0.21.4's carry — ``heads``, ``scale``, ``to_q`` / ``to_k`` / ``to_v`` / ``to_out``,
+``group_norm`` / ``spatial_norm`` / ``norm_cross``, ``residual_connection``, ``rescale_output_factor`` — so they run on a FOREIGN
+``Attention`` installed through ``unet.set_attn_processor({...})``.  Head geometry is derived from the weights
+(``inner = to_q.weight.shape[0]``, ``d = inner // heads``: ``inner_dim`` is a local of the reference constructor, :52); the packed
+``q|k|v`` / ``k|v`` / LayerNorm-folded weights live in a PROCESSOR-SIDE cache keyed by the ``attn`` object (weak reference) and the
+parameters' ``_version`` / storage, never on the module.
 """
 import weakref
 
@@ -69,43 +77,117 @@ class StaticSlots:
         return len(self._slots)
 
 
+# ---- processor-side packed-weight cache -----------------------------------------------------------------------------------
+_PACKS = weakref.WeakKeyDictionary()          # attn module (any class) -> {name: (key, payload)}
+
+
+def _cached(attn, name, tensors, build):
+    """``build()`` once per (attn object, name) and again whenever one of ``tensors`` was written in place (``_version``),
+    re-allocated, cast or moved.  The entry dies with the module."""
+    try:
+        packs = _PACKS.get(attn)
+        if packs is None:
+            packs = _PACKS[attn] = {}
+    except TypeError:                           # an attn object that cannot be weakly referenced: no caching
+        packs = {}
+    key = tuple((t.data_ptr(), tensor_version(t), t.dtype, t.device) for t in tensors)
+    hit = packs.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, build())
+        packs[name] = hit
+    return hit[1]
+
+
+def attn_dims(attn):
+    """(inner, heads, head_dim) of any diffusers-shaped ``Attention``: from the projection weight, not from attributes the reference
+    class does not have."""
+    inner = attn.to_q.weight.shape[0]
+    heads = int(attn.heads)
+    if inner % heads or (inner // heads) % 8:
+        raise RuntimeError(f"theatergen_amd: to_q has {inner} rows for {heads} heads; head_dim must be a multiple of 8")
+    return inner, heads, inner // heads
+
+
+def _cat_bias(lins, dtype_like):
+    """concatenated q|k|v bias (None when no projection has one; zeros for the ones that lack it)"""
+    if all(getattr(l, "bias", None) is None for l in lins):
+        return None
+    return torch.cat([l.bias.detach() if l.bias is not None else torch.zeros(l.weight.shape[0], dtype=dtype_like.dtype, device=dtype_like.device)
+                      for l in lins]).to(dtype_like.dtype).contiguous()
+
+
+def qkv_weight(attn):
+    """([3*inner, C] rows = to_q ; to_k ; to_v, bias or None): self-attention in one GEMM."""
+    lins = [attn.to_q, attn.to_k, attn.to_v]
+    ws = [l.weight for l in lins]
+    bs = [l.bias for l in lins if l.bias is not None]
+    return _cached(attn, "qkv", ws + bs, lambda: (torch.cat([w.detach() for w in ws], dim=0).contiguous(), _cat_bias(lins, ws[0])))
+
+
+def kv_weight(attn):
+    lins = [attn.to_k, attn.to_v]
+    ws = [l.weight for l in lins]
+    bs = [l.bias for l in lins if l.bias is not None]
+    return _cached(attn, "kv", ws + bs, lambda: (torch.cat([w.detach() for w in ws], dim=0).contiguous(), _cat_bias(lins, ws[0])))
+
+
+def ln_weight(attn, name, norm):
+    """(W', u, v) of ``pack_ln_linear`` for the projection that consumes ``norm`` (a ``nn.LayerNorm``): ``name`` = "qkv" (self-
+    attention: to_q ; to_k ; to_v rows) or "q" (cross-attention query)."""
+    from .weights_pack import pack_ln_linear
+    lins = [attn.to_q, attn.to_k, attn.to_v] if name == "qkv" else [attn.to_q]
+    ws = [l.weight for l in lins]
+    bs = [l.bias for l in lins if l.bias is not None]
+    return _cached(attn, "ln_" + name, ws + bs + [norm.weight, norm.bias],
+                   lambda: pack_ln_linear(torch.cat([w.detach() for w in ws], dim=0), _cat_bias(lins, ws[0]), norm.weight, norm.bias))
+
+
 class Attention(nn.Module):
-    """Parameter container + dispatcher (reference attention_processor.py:12-167)."""
+    """Parameter container + dispatcher (reference attention_processor.py:12-167).  Carries exactly the reference's attribute set
+    (plus ``query_dim`` / ``is_cross`` for this package's UNet); the processors below do not depend on this class."""
 
     def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
-                 upcast_attention=False, upcast_softmax=False, cross_attention_norm=None, added_kv_proj_dim=None,
-                 norm_num_groups=None, spatial_norm_dim=None, out_bias=True, scale_qk=True, only_cross_attention=False,
-                 eps=1e-5, rescale_output_factor=1.0, residual_connection=False, processor=None):
+                 upcast_attention=False, upcast_softmax=False, cross_attention_norm=None, cross_attention_norm_num_groups=32,
+                 added_kv_proj_dim=None, norm_num_groups=None, spatial_norm_dim=None, out_bias=True, scale_qk=True,
+                 only_cross_attention=False, eps=1e-5, rescale_output_factor=1.0, residual_connection=False,
+                 _from_deprecated_attn_block=False, processor=None):
         super().__init__()
-        for name, val in (("cross_attention_norm", cross_attention_norm), ("added_kv_proj_dim", added_kv_proj_dim),
-                          ("norm_num_groups", norm_num_groups), ("spatial_norm_dim", spatial_norm_dim)):
+        for name, val in (("added_kv_proj_dim", added_kv_proj_dim), ("spatial_norm_dim", spatial_norm_dim)):
             if val is not None:
                 raise ValueError(f"theatergen_amd.Attention: {name} is not on the TheaterGen hot path (unsupported)")
         if only_cross_attention:
             raise ValueError("`only_cross_attention` can only be set to True if `added_kv_proj_dim` is not None.")
         inner_dim = dim_head * heads
         self.query_dim = query_dim
-        self.inner_dim = inner_dim
         self.is_cross = cross_attention_dim is not None
-        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.cross_attention_dim = cross_attention_dim
         self.upcast_attention = upcast_attention      # accumulation / softmax are always fp32 in the kernel
         self.upcast_softmax = upcast_softmax
         self.rescale_output_factor = rescale_output_factor
         self.residual_connection = residual_connection
+        self._from_deprecated_attn_block = _from_deprecated_attn_block
         self.scale_qk = scale_qk
         self.scale = dim_head ** -0.5 if scale_qk else 1.0
         self.heads = heads
-        self.dim_head = dim_head
-        self.group_norm = None
+        self.sliceable_head_dim = heads
+        self.added_kv_proj_dim = None
+        self.only_cross_attention = False
+        self.group_norm = nn.GroupNorm(num_channels=query_dim, num_groups=norm_num_groups, eps=eps, affine=True) if norm_num_groups is not None else None
         self.spatial_norm = None
-        self.norm_cross = None
+        if cross_attention_norm is None:
+            self.norm_cross = None
+        elif cross_attention_norm == "layer_norm":
+            self.norm_cross = nn.LayerNorm(cross_attention_dim)
+        elif cross_attention_norm == "group_norm":
+            self.norm_cross = nn.GroupNorm(num_channels=cross_attention_dim, num_groups=cross_attention_norm_num_groups, eps=1e-5, affine=True)
+        else:
+            raise ValueError(f"unknown cross_attention_norm: {cross_attention_norm}. Should be None, 'layer_norm' or 'group_norm'")
         self.to_q = nn.Linear(query_dim, inner_dim, bias=bias)
-        self.to_k = nn.Linear(self.cross_attention_dim, inner_dim, bias=bias)
-        self.to_v = nn.Linear(self.cross_attention_dim, inner_dim, bias=bias)
+        self.to_k = nn.Linear(cross_attention_dim, inner_dim, bias=bias)
+        self.to_v = nn.Linear(cross_attention_dim, inner_dim, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(inner_dim, query_dim, bias=out_bias), nn.Dropout(dropout)])
-        if bias:
-            raise ValueError("theatergen_amd.Attention: q/k/v bias is not used by SD UNets (unsupported)")
-        self._packed = {}
         self.set_processor(processor if processor is not None else AttnProcessor())
 
     def set_processor(self, processor):
@@ -117,41 +199,66 @@ class Attention(nn.Module):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **cross_attention_kwargs)
 
-    # ---- packed (fused) projection weights, rebuilt when the parameters change ---------------------------
-    def _cached(self, name, tensors, build):
-        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in tensors)
-        hit = self._packed.get(name)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, build())
-            self._packed[name] = hit
-        return hit[1]
 
-    def qkv_weight(self):
-        """[3*inner, C]: rows = to_q ; to_k ; to_v (self-attention, one GEMM)."""
-        ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight]
-        return self._cached("qkv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
-
-    def ln_weight(self, name, norm):
-        """(W', u, v) of ``pack_ln_linear`` for the projection that consumes ``norm`` (a ``nn.LayerNorm``): ``name`` = "qkv" (self-
-        attention: to_q ; to_k ; to_v rows) or "q" (cross-attention query)."""
-        from .weights_pack import pack_ln_linear
-        ws = [self.to_q.weight, self.to_k.weight, self.to_v.weight] if name == "qkv" else [self.to_q.weight]
-        return self._cached("ln_" + name, ws + [norm.weight, norm.bias],
-                            lambda: pack_ln_linear(torch.cat([w.detach() for w in ws], dim=0), None, norm.weight, norm.bias))
-
-    def kv_weight(self):
-        ws = [self.to_k.weight, self.to_v.weight]
-        return self._cached("kv", ws, lambda: torch.cat([w.detach() for w in ws], dim=0).contiguous())
-
-
-def _check_common(attn, hidden_states, attention_mask, attn_process_fn):
-    if attention_mask is not None:
-        raise NotImplementedError("theatergen_amd: attention_mask is not used on the TheaterGen hot path")
+def _check_common(attn, hidden_states, attn_process_fn):
     if attn_process_fn is not None:
+        # reference :350-352 hands the MATERIALISED [B*h, N, L] probabilities to a Python callback; no caller in the reference passes one
         raise NotImplementedError("theatergen_amd: attn_process_fn would need materialised probabilities (unsupported)")
-    if not hidden_states.is_cuda:
+    if getattr(attn, "spatial_norm", None) is not None:
+        # reference :316-317 (SpatialNorm of the MoVQ decoder: conditioned on `temb` as a latent image); not built by any SD / SDXL UNet or VAE
+        raise NotImplementedError("theatergen_amd: attn.spatial_norm (MoVQ SpatialNorm) is not supported")
+    if getattr(attn, "added_kv_proj_dim", None) is not None:
+        raise NotImplementedError("theatergen_amd: added_kv_proj_dim belongs to the AttnAddedKV processors (unsupported)")
+    _need_gpu(hidden_states)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
         raise RuntimeError("theatergen_amd: attention runs on the GPU only (no CPU fallback)")
+
+
+def _group_norm_tokens(gn, x2d, B, N):
+    """``attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)`` (reference :330-331) on the token-major [B*N, C] view:
+    statistics per (batch item, channel group) over all N tokens."""
+    return ops.groupnorm(x2d, B, N, gn.num_groups, gn.eps, gn.weight, gn.bias)
+
+
+def _norm_encoder(attn, enc):
+    """``attn.norm_encoder_hidden_states`` (reference :261-279): LayerNorm over the channel dim, or GroupNorm over (channel group x
+    sequence) per batch item.  ``enc`` [B, L, ctx] -> normalised contiguous [B, L, ctx]."""
+    nc = attn.norm_cross
+    B, L, ctx = enc.shape
+    e2 = enc.contiguous().reshape(B * L, ctx)
+    if isinstance(nc, nn.LayerNorm):
+        return ops.layernorm(e2, nc.weight, nc.bias, nc.eps).reshape(B, L, ctx)
+    if isinstance(nc, nn.GroupNorm):
+        return ops.groupnorm(e2, B, L, nc.num_groups, nc.eps, nc.weight, nc.bias).reshape(B, L, ctx)
+    raise RuntimeError(f"theatergen_amd: unknown attn.norm_cross {type(nc).__name__}")
+
+
+def _prepare_mask(attention_mask, L, B, heads, N):
+    """``attn.prepare_attention_mask`` (reference :221-259, out_dim 3) + the broadcast rules of ``baddbmm(mask, q, k^T)`` (:193-206)
+    -> fp32 [Bm, Hm, Qm, L] for ``ops.attention(mask=)``.  Accepted, like the reference: [B, Q, L] (repeated over heads) or
+    [B*heads, Q, L], with Q in {1, N}; a mask whose key length is not L is padded by the reference with L more zeros and then fails
+    in baddbmm — here it is a RuntimeError up front."""
+    m = attention_mask
+    if m.ndim != 3:
+        raise RuntimeError(f"theatergen_amd: attention_mask must be 3-D [batch(*heads), 1 or queries, keys], got {tuple(m.shape)}")
+    if m.shape[-1] != L:
+        raise RuntimeError(f"theatergen_amd: attention_mask covers {m.shape[-1]} keys, the key sequence has {L} "
+                           "(prepare_attention_mask would pad it to a length baddbmm rejects)")
+    if m.shape[1] not in (1, N):
+        raise RuntimeError(f"theatergen_amd: attention_mask has {m.shape[1]} query rows for {N} queries")
+    m = m.to(torch.float32)
+    if m.shape[0] == B * heads and heads > 1:
+        m = m.reshape(B, heads, m.shape[1], L)
+    elif m.shape[0] == B:
+        m = m.reshape(B, 1, m.shape[1], L)
+    elif m.shape[0] == 1:
+        m = m.reshape(1, 1, m.shape[1], L)
+    else:
+        raise RuntimeError(f"theatergen_amd: attention_mask batch {m.shape[0]} matches neither batch {B} nor batch * heads {B * heads}")
+    return m.contiguous()
 
 
 def _to_tokens(hidden_states):
@@ -201,7 +308,8 @@ def _save_probs(attn, q, q_ld, k, k_ld, B, N, L, save_attn_to_dict, save_keys, a
             tokens = torch.tensor([return_token_ca_only], dtype=torch.int32, device=q.device)
         else:
             tokens = torch.as_tensor(return_token_ca_only).to(device=q.device, dtype=torch.int32).reshape(-1)
-    probs = ops.attn_probs(q, q_ld, N * q_ld, k, k_ld, L * k_ld, B, b0, attn.heads, attn.dim_head, N, L, attn.scale, tokens)
+    _, heads, d = attn_dims(attn)
+    probs = ops.attn_probs(q, q_ld, N * q_ld, k, k_ld, L * k_ld, B, b0, heads, d, N, L, attn.scale, tokens)
     if offload_cross_attn_to_cpu:
         probs = probs.cpu()
     if save_attn_to_dict is not None and (save_keys is None or (tuple(attn_key) in save_keys)):
@@ -221,40 +329,52 @@ class AttnProcessor(nn.Module):
                  enable_flash_attn=True, _fused_residual=None, _fused_ln=None):
         """``_fused_ln`` = (nn.LayerNorm, row statistics or None) (internal, ``BasicTransformerBlock``): ``hidden_states`` is the block's
         UN-normalised stream and the norm is folded into the first projection (tg_gemm ``ln_u`` / ``ln_v`` / ``ln_rows``)."""
-        _check_common(attn, hidden_states, attention_mask, attn_process_fn)
+        _check_common(attn, hidden_states, attn_process_fn)
         x, B, N, C, shape4 = _to_tokens(hidden_states)
-        inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
+        inner, heads, d = attn_dims(attn)
+        xin = x                                                 # the residual of `residual_connection` is the UN-normalised input (:313)
+        if getattr(attn, "group_norm", None) is not None:
+            if _fused_ln is not None:
+                raise RuntimeError("theatergen_amd: group_norm and a folded LayerNorm cannot both precede the projections")
+            x = _group_norm_tokens(attn.group_norm, x, B, N)
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
         lnq = None
         if _fused_ln is not None:
             norm, rows = _fused_ln                           # (nn.LayerNorm, layernorm_stats tensor or None = statistics inside the kernel)
-            wl, ul, vl = attn.ln_weight("qkv" if encoder_hidden_states is None else "q", norm)
+            wl, ul, vl = ln_weight(attn, "qkv" if encoder_hidden_states is None else "q", norm)
             lnq = (ul, vl, norm.eps, rows)
         if encoder_hidden_states is None:
             # one GEMM: [Q | K] token-major + V^T per batch item
+            mask = _prepare_mask(attention_mask, N, B, heads, N) if attention_mask is not None else None
             ldt = _round8(N)
             qk = torch.empty((B * N, 2 * inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
-            ops.gemm(x, wl if lnq else attn.qkv_weight(), B * N, 3 * inner, C, rows_per_batch=N, out=qk, n_split=2 * inner, out_t=vt, ldt=ldt,
-                     ln=lnq)
+            w3, b3 = (wl, None) if lnq else qkv_weight(attn)
+            ops.gemm(x, w3, B * N, 3 * inner, C, bias=b3, rows_per_batch=N, out=qk, n_split=2 * inner, out_t=vt, ldt=ldt, ln=lnq)
             ops.attention(qk, 2 * inner, N * 2 * inner, qk[:, inner:], 2 * inner, N * 2 * inner, vt, ldt, inner * ldt, N,
-                          B, heads, d, N, attn.scale, o, inner, N * inner)
+                          B, heads, d, N, attn.scale, o, inner, N * inner, mask=mask)
         else:
+            if getattr(attn, "norm_cross", None):
+                encoder_hidden_states = _norm_encoder(attn, encoder_hidden_states)
             enc, L, enc_bs = _enc_rows(encoder_hidden_states)
+            mask = _prepare_mask(attention_mask, L, B, heads, N) if attention_mask is not None else None
             ctx = enc.shape[2]
-            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight)
+            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight, attn.to_q.bias)
             ldt = _round8(L)
             k = torch.empty((B * L, inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
-            ops.gemm(enc, attn.kv_weight(), B * L, 2 * inner, ctx, rows_per_batch=L, out=k, n_split=inner,
+            w2, b2 = kv_weight(attn)
+            ops.gemm(enc, w2, B * L, 2 * inner, ctx, bias=b2, rows_per_batch=L, out=k, n_split=inner,
                      out_t=vt, ldt=ldt, a_rows_per_batch=L, a_batch_stride=enc_bs)
             ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
-                          o, inner, N * inner)
+                          o, inner, N * inner, mask=mask)
             # like the reference (:371) self.return_attntion_probs is forced False; maps are still saved (:386-389)
             if save_attn_to_dict is not None:
+                if mask is not None:
+                    raise NotImplementedError("theatergen_amd: attention-map capture with an attention_mask is not supported")
                 _save_probs(attn, q, inner, k, inner, B, N, L, save_attn_to_dict, save_keys, attn_key, return_cond_ca_only,
                             return_token_ca_only, bool(save_attn_to_dict) or offload_cross_attn_to_cpu)
-        return _finish(attn, o, B, N, C, shape4, x, _fused_residual)
+        return _finish(attn, o, B, N, C, shape4, xin, _fused_residual)
 
 
 AttentionProcessor = AttnProcessor
@@ -314,10 +434,11 @@ class IPAttnProcessor(nn.Module):
         B, Ltot, ctx = enc.shape
         T = self.num_tokens
         L = Ltot - T
-        inner = attn.inner_dim
+        inner = attn_dims(attn)[0]
         k, vt, kip, vtip = bufs
         ldt, ldi = _round8(L), _round8(T)
-        ops.gemm(enc, attn.kv_weight(), B * L, 2 * inner, ctx, rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt,
+        w2, b2 = kv_weight(attn)
+        ops.gemm(enc, w2, B * L, 2 * inner, ctx, bias=b2, rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt,
                  a_rows_per_batch=L, a_batch_stride=Ltot * ctx)
         ops.gemm(enc.reshape(-1)[L * ctx:], self._ip_weight(), B * T, 2 * inner, ctx, rows_per_batch=T, out=kip,
                  n_split=inner, out_t=vtip, ldt=ldi, a_rows_per_batch=T, a_batch_stride=Ltot * ctx)
@@ -329,7 +450,7 @@ class IPAttnProcessor(nn.Module):
         L = Ltot - T
         if L < 1 or T < 1 or T > 64:
             raise RuntimeError(f"IPAttnProcessor: need 1 <= num_tokens <= 64 and at least one text token (L={L}, T={T})")
-        inner = attn.inner_dim
+        inner = attn_dims(attn)[0]
         kw = dict(dtype=enc.dtype, device=enc.device)
         # the pad columns of V^T (keys L..ldt) are multiplied by exact-zero probabilities: they must be finite
         return (torch.empty((B * L, inner), **kw), torch.zeros((B, inner, _round8(L)), **kw),
@@ -340,7 +461,7 @@ class IPAttnProcessor(nn.Module):
         embeddings into it: (re)project K / V^T into buffers that belong to that tensor.  The buffers are allocated once per
         (tensor, shape) and refreshed IN PLACE, so a captured hipGraph of the UNet step keeps valid pointers."""
         slot = self._kv.get(enc)
-        bkey = (tuple(enc.shape), enc.dtype, enc.device, self.num_tokens, attn.inner_dim)
+        bkey = (tuple(enc.shape), enc.dtype, enc.device, self.num_tokens, attn_dims(attn)[0])
         if slot is None or slot["bkey"] != bkey or slot["attn"]() is not attn:
             slot = self._kv.put(enc, {"bkey": bkey, "attn": weakref.ref(attn), "bufs": self._alloc(attn, enc)})
         slot["kv"] = self._project_into(attn, enc, slot["bufs"])
@@ -363,24 +484,36 @@ class IPAttnProcessor(nn.Module):
                  return_attntion_probs=False, attn_key=None, attn_process_fn=None, return_cond_ca_only=False,
                  return_token_ca_only=None, offload_cross_attn_to_cpu=False, save_attn_to_dict=None, save_keys=None,
                  enable_flash_attn=True, _fused_residual=None, _fused_ln=None):
-        _check_common(attn, hidden_states, attention_mask, attn_process_fn)
+        _check_common(attn, hidden_states, attn_process_fn)
         if encoder_hidden_states is None:
             raise RuntimeError("IPAttnProcessor is a cross-attention processor: encoder_hidden_states is required")
+        if attention_mask is not None:
+            # reference :461-463 prepares the mask for the FULL (text + image) sequence and :477 adds it to text-only scores: baddbmm
+            # rejects the shapes for every mask length, so there is no behaviour to reproduce
+            raise RuntimeError("IPAttnProcessor: attention_mask cannot be combined with the decoupled text / image split "
+                               "(the reference's baddbmm fails on the shapes as well)")
         x, B, N, C, shape4 = _to_tokens(hidden_states)
-        inner, heads, d = attn.inner_dim, attn.heads, attn.dim_head
+        inner, heads, d = attn_dims(attn)
+        xin = x
+        if getattr(attn, "group_norm", None) is not None:
+            x = _group_norm_tokens(attn.group_norm, x, B, N)
+        if getattr(attn, "norm_cross", None):
+            # the reference normalises the whole [text ; image] sequence before the split (:465-466); a normalised copy is a fresh tensor,
+            # so the registered-tensor K / V^T cache does not apply to it
+            encoder_hidden_states = _norm_encoder(attn, encoder_hidden_states)
         enc = encoder_hidden_states.contiguous()
         k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
         if _fused_ln is not None:
             norm, rows = _fused_ln
-            wl, ul, vl = attn.ln_weight("q", norm)
+            wl, ul, vl = ln_weight(attn, "q", norm)
             q = ops.linear(x, wl, ln=(ul, vl, norm.eps, rows))
         else:
-            q = ops.linear(x, attn.to_q.weight)
+            q = ops.linear(x, attn.to_q.weight, attn.to_q.bias)
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
         ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
                       o, inner, N * inner, k1=kip, k1_ld=inner, k1_bs=T * inner, vt1=vtip, vt1_ld=ldi, vt1_bs=inner * ldi,
                       len1=T, w1=float(self.scale), w1_dev=self.scale_device(x.device))
-        out = _finish(attn, o, B, N, C, shape4, x, _fused_residual)
+        out = _finish(attn, o, B, N, C, shape4, xin, _fused_residual)
         if return_attntion_probs or save_attn_to_dict is not None:
             probs = _save_probs(attn, q, inner, k, inner, B, N, L, save_attn_to_dict, save_keys, attn_key,
                                 return_cond_ca_only, return_token_ca_only, offload_cross_attn_to_cpu)

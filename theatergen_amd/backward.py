@@ -114,7 +114,8 @@ def attention_input_grad(attn, proc, h2d, B, N, enc, dout, extra):
     """Gradient of ``to_out(attention(to_q(h), K, V))`` wrt ``h`` [B*N, C].  Self-attention: K, V from ``h`` too; cross-attention:
     K, V (and the IP-Adapter image segment) are constants.  ``dout`` [B*N, C] or None; ``extra`` fp32 [B, heads, N, L_text] or None
     = d loss / d (text attention probabilities) from the guidance loss."""
-    heads, d, inner = attn.heads, attn.dim_head, attn.inner_dim
+    from .attention_processor import attn_dims
+    inner, heads, d = attn_dims(attn)
     dt, dev = h2d.dtype, h2d.device
     if dout is None and extra is None:
         return None

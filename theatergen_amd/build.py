@@ -53,17 +53,19 @@ def build(force=False, verbose=True):
         stamp = o + ".sha"
         dg = _digest([s] + deps)
         objs.append(o)
-        if force or not os.path.exists(o) or not os.path.exists(stamp) or open(stamp).read() != dg:
+        if force or not os.path.exists(o) or not os.path.exists(o + ".res") or not os.path.exists(stamp) or open(stamp).read() != dg:
             todo.append((s, o, stamp, dg))
 
     def compile_one(job):
         s, o, stamp, dg = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+        with open(o + ".res", "w") as f:                      # the compiler's per-kernel resource remarks (parsed by kernel_resources)
+            f.write(r.stderr)
         with open(stamp, "w") as f:
             f.write(dg)
 
@@ -77,8 +79,135 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if todo or not os.path.exists(RESOURCES_JSON):
+        write_resources(check=True, verbose=verbose)           # the register / scratch gate is part of every build
     return LIB
 
 
+# ---- kernel resource report + gate ------------------------------------------------------------------
+# `python -m theatergen_amd.build --resources [--check]` recompiles every source with -Rpass-analysis=kernel-resource-usage
+# (device pass only, no objects kept), writes profiles/r4_kernel_resources.json (VGPR / AGPR / scratch / spills / occupancy per
+# kernel symbol) and, with --check, fails when a kernel matching HOT_GATES exceeds its allowance.  A hot kernel that gains
+# scratch must be a decision, not an accident (round 3 shipped 6 spills inside the d = 40 attention tile loop).
+RESOURCES_JSON = os.path.join(os.path.dirname(HERE), "profiles", "r4_kernel_resources.json")
+# (substring of the DEMANGLED name, max scratch bytes / lane, max VGPRs)
+HOT_GATES = [
+    ("attention_kernel<bf16,48,64,true,true,false>", 0, 128),      # SD-1.5 level 0 (d = 40): four waves per SIMD, nothing spilled
+    ("attention_kernel<f16,48,64,true,true,false>", 0, 128),
+    ("attention_kernel<", 0, 256),
+    ("gemm_glds_kernel<", 0, 256),                                 # the LDS-DMA GEMM family: no scratch anywhere
+    ("conv_halo_kernel<", 0, 256),
+    # families that DO spill today (8-wave loader / compute kernels, 256-register budget): ceilings = the round-3 values, so a
+    # change can only lower them (VERDICT r3 item 4 asks for 0 inside the K loops)
+    ("conv_slab_kernel<", 320, 256),
+    ("bt_gemm_kernel<", 132, 256),
+    ("lc_gemm_kernel<", 100, 256),
+]
+
+
+def _pretty(sym):
+    """Readable form of an Itanium-mangled kernel symbol: `attention_kernel<bf16,48,64,true,true,false>` (c++filt of this image
+    predates the DF16b / DF16_ manglings, so the few constructs our kernels use are decoded here)."""
+    import re
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", sym) or re.match(r"_Z(\d+)", sym)
+    if not m:
+        return sym
+    n = int(m.group(1))
+    base, rest = sym[m.end():m.end() + n], sym[m.end() + n:]
+    if not rest.startswith("I"):
+        return base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("DF16b", i):
+            args.append("bf16"); i += 5
+        elif rest.startswith("DF16_", i):
+            args.append("f16"); i += 5
+        elif rest[i] == "L":
+            j = rest.index("E", i)
+            tok = rest[i + 1:j]
+            if tok[0] == "b":
+                args.append("true" if tok[1:] == "1" else "false")
+            else:
+                args.append(re.sub(r"^[a-z]n?", lambda mm: "-" if mm.group(0).endswith("n") and len(mm.group(0)) > 1 else "", tok))
+            i = j + 1
+        elif rest[i] in "fidjlmb":
+            args.append({"f": "float", "i": "int", "d": "double", "j": "unsigned", "l": "long", "m": "unsigned long", "b": "bool"}[rest[i]]); i += 1
+        else:
+            args.append("?" + rest[i:i + 12]); break
+    return base + "<" + ",".join(args) + ">"
+
+
+def _demangle(names):
+    return [_pretty(n) for n in names]
+
+
+def kernel_resources(verbose=True):
+    """{demangled kernel name: {file, vgprs, agprs, scratch, sgpr_spill, vgpr_spill, occupancy}} for every kernel of csrc/, parsed
+    from the remarks the build keeps next to each object (csrc/_build/*.o.res)."""
+    import re
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "SGPRs": "sgprs"}
+    all_recs = []
+    for src in sources():
+        path = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o.res")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run build() first")
+        cur = None
+        for line in open(path).read().splitlines():
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = {"symbol": m.group(1), "file": os.path.basename(src)}
+                all_recs.append(cur)
+                continue
+            m = re.search(r"remark:\s+([A-Za-z][A-Za-z \[\]/]*): (\d+)", line)
+            if m and cur is not None and m.group(1).strip() in keys:
+                cur[keys[m.group(1).strip()]] = int(m.group(2))
+    names = _demangle([r["symbol"] for r in all_recs])
+    out = {}
+    for r, n in zip(all_recs, names):
+        r = dict(r)
+        if n in out:                                  # two symbols with one readable name: keep both
+            n = n + " " + r["symbol"]
+        out[n] = r
+    if verbose:
+        print(f"[resources] {len(out)} kernels", flush=True)
+    return out
+
+
+def check_resources(res):
+    """Every kernel is checked against the FIRST gate whose substring it contains."""
+    bad = []
+    for name, r in res.items():
+        for sub, max_scratch, max_vgpr in HOT_GATES:
+            if sub in name:
+                if r.get("scratch", 0) > max_scratch or r.get("vgprs", 0) > max_vgpr:
+                    bad.append(f"{name}: {r.get('vgprs')} VGPRs (<= {max_vgpr}), scratch {r.get('scratch')} B (<= {max_scratch})")
+                break
+    return bad
+
+
+def write_resources(check=False, verbose=True):
+    import json
+    res = kernel_resources(verbose=verbose)
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=HERE).stdout.strip()
+    except OSError:
+        commit = ""
+    os.makedirs(os.path.dirname(RESOURCES_JSON), exist_ok=True)
+    with open(RESOURCES_JSON, "w") as f:
+        json.dump({"flags": FLAGS, "built_from_commit_or_later": commit, "gates": HOT_GATES, "kernels": dict(sorted(res.items()))}, f, indent=1)
+    bad = check_resources(res)
+    for b in bad:
+        print("[resources] GATE:", b, flush=True)
+    if check and bad:
+        raise RuntimeError("kernel resource gate failed:\n" + "\n".join(bad))
+    return res
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--resources" in sys.argv:
+        build()
+        write_resources(check="--check" in sys.argv)
+        print(RESOURCES_JSON)
+    else:
+        print(build(force="--force" in sys.argv))

@@ -51,7 +51,8 @@ struct AttnParams {
   const float* w1_dev;
   void* out; long out_ld, out_bs;
   int causal;
-  int flags;        // dev A/B (env TG_ATTN_FLAGS, read per launch): bit 0 = no intra-wave MFMA / VALU interleave (PIPE)
+  const float* mask; long mask_bs, mask_hs, mask_qs;   // MASK instances: additive score bias mask[b*bs + h*hs + q*qs + key] (fp32, score units)
+  float inv_scale;
 };
 
 // Data path: K tile = NP panels of [64 keys][64 d] and V^T tile = [DV d][64 keys], both as 128-byte LDS rows filled by
@@ -68,7 +69,10 @@ struct AttnParams {
 // -(running reference) — so the MFMA itself delivers exp2's argument and the 32 fmas per tile disappear.  The reference is a
 // storage-dtype value (softmax is invariant to it); it moves lazily as before, and a move shifts the current tile's scores by the
 // exact difference of the two representable values.
-template <typename T, int DPAD, int DV, bool ONES, bool FOLD>
+// MASK (own instantiations, never the hot path): `attention_mask` of the diffusers processors — an additive bias on segment 0's scores
+// (`baddbmm(mask, q, k^T, beta=1, alpha=scale)`, ip_adapter/attention_processor.py:193-206), broadcast over heads and / or queries by
+// zero strides.  It is added in raw-score units (mask / scale) right after the QK^T tile, so the online softmax is unchanged.
+template <typename T, int DPAD, int DV, bool ONES, bool FOLD, bool PIPE, bool MASK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 3 : (DV <= 96 ? 2 : 1)))) void attention_kernel(AttnParams p) {
   typedef typename Vec<T>::v8 V8;
   typedef typename Vec<T>::v4 V4;
@@ -272,8 +276,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
     // bench +0.2 .. +0.6 % — at 152 instead of 125 VGPRs (three resident waves per SIMD instead of four).  What it says about the
     // hardware: a wave-tile costs about the SUM of its VALU and matrix-pipe time whatever the issue order, so the remaining levers
     // are fewer instructions, not more overlap.
-    constexpr bool PIPE = DV == 64 && NKS <= 3;      // head dim 40 (the d = 64 variant would spill at three waves per SIMD)
-    const bool piped = PIPE && !(kv0 + KV > p.len0 || p.causal != 0) && !(p.flags & 1);
+    // PIPE is a TEMPLATE parameter (its own instantiation, dev switch TG_ATTN_PIPE=1): compiled into the default kernel behind a
+    // run-time flag (round 3) it took the d = 40 kernel from 125 VGPRs / 0 scratch to 168 VGPRs / 6 spills with scratch reloads
+    // inside the tile loop (+30 % per launch) — the default instantiation carries none of it.
+    static_assert(!PIPE || (DV == 64 && NKS <= 3), "PIPE: head dim 40 only");
+    const bool piped = PIPE && !(kv0 + KV > p.len0 || p.causal != 0);
     float tm;
     if (piped) {
       V8 kf0[NKS], kf1[NKS];
@@ -285,29 +292,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
       float mx = -INFINITY;
-      if (!(p.flags & 2)) {
-        // S0 chain first, the S1 chain with the max over S0 in its shadow
+      // S0 chain first, the S1 chain with the max over S0 in its shadow
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) s[0] = mfma32(kf0[ks], qf[ks], s[0]);
+      for (int ks = 0; ks < NKS; ++ks) s[0] = mfma32(kf0[ks], qf[ks], s[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        s[1] = mfma32(kf1[ks], qf[ks], s[1]);
+#pragma unroll
+        for (int r = ks * 16 / NKS; r < (ks + 1) * 16 / NKS; ++r) mx = fmaxf(mx, s[0][r]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          s[1] = mfma32(kf1[ks], qf[ks], s[1]);
-#pragma unroll
-          for (int r = ks * 16 / NKS; r < (ks + 1) * 16 / NKS; ++r) mx = fmaxf(mx, s[0][r]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        // dev A/B (TG_ATTN_FLAGS bit 1): the two halves' accumulation chains alternate (a dependent 32x32x16 MFMA can issue only when
-        // its predecessor has left the pipe); measured equal to the default within noise
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          s[0] = mfma32(kf0[ks], qf[ks], s[0]);
-          s[1] = mfma32(kf1[ks], qf[ks], s[1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
@@ -316,6 +310,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
       tm = fmaxf(a, b2);
     } else {
       scores(s, sK, p.len0, kv0, p.causal != 0);
+      if constexpr (MASK) {
+        const float* mp = p.mask + (long)b * p.mask_bs + (long)h * p.mask_hs + (q_ok ? qrow : 0) * p.mask_qs;
+#pragma unroll
+        for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + kvt * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+            if (kv < p.len0) s[kvt][r] += mp[kv] * p.inv_scale;
+          }
+      }
       tm = tile_max(s);
     }
     // m_run is kept in RAW score units; exp2 arguments are formed as fma(s, c, -m*c) with c = scale * log2(e) > 0.
@@ -489,14 +493,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DV <= 64 ? 
   }
 }
 
-template <typename T, int DPAD, int DV, bool ONES, bool FOLD = false>
+template <typename T, int DPAD, int DV, bool ONES, bool FOLD = false, bool PIPE = false, bool MASK = false>
 int launch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
   constexpr int NP = (DPAD + 63) / 64;
   const size_t lds = (size_t)2 * (NP * 64 * 64 + DV * 64) * sizeof(T);
   AttnParams pp = p;
   pp.n_qblk = (d->n_q + 127) / 128;
   dim3 grid((unsigned)(pp.n_qblk * d->heads * d->batch));
-  auto k = attention_kernel<T, DPAD, DV, ONES, FOLD>;
+  auto k = attention_kernel<T, DPAD, DV, ONES, FOLD, PIPE, MASK>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, pp);
@@ -508,9 +512,22 @@ template <typename T>
 int dispatch_attn(const tg_attn_desc* d, const AttnParams& p, hipStream_t st) {
   // ONES variants need a spare V^T row (DV > head dim): 40 -> (48, 64), 80 -> (80, 96), <= 16 -> (16, 32)
   const int hd = d->head_dim;
+  if (p.mask != nullptr) {
+    if (hd <= 16) return launch_attn<T, 16, 32, true, false, false, true>(d, p, st);
+    if (hd <= 32) return launch_attn<T, 32, 32, false, false, false, true>(d, p, st);
+    if (hd <= 48) return launch_attn<T, 48, 64, true, false, false, true>(d, p, st);
+    if (hd <= 64) return launch_attn<T, 64, 64, false, false, false, true>(d, p, st);
+    if (hd <= 80) return launch_attn<T, 80, 96, true, false, false, true>(d, p, st);
+    if (hd <= 96) return launch_attn<T, 96, 96, false, false, false, true>(d, p, st);
+    if (hd <= 128) return launch_attn<T, 128, 128, false, false, false, true>(d, p, st);
+    return launch_attn<T, 160, 160, false, false, false, true>(d, p, st);
+  }
   if (hd <= 16) return launch_attn<T, 16, 32, true>(d, p, st);
   if (hd <= 32) return launch_attn<T, 32, 32, false>(d, p, st);
-  if (hd == 40 && !getenv("TG_ATTN_NOFOLD")) return launch_attn<T, 48, 64, true, true>(d, p, st);    // bias folded into QK^T (dev switch for A/B)
+  if (hd == 40 && !getenv("TG_ATTN_NOFOLD")) {                                                       // bias folded into QK^T (dev switch for A/B)
+    static const bool pipe = getenv("TG_ATTN_PIPE") != nullptr;                                       // dev A/B: the intra-wave interleave instantiation
+    return pipe ? launch_attn<T, 48, 64, true, true, true>(d, p, st) : launch_attn<T, 48, 64, true, true>(d, p, st);
+  }
   if (hd <= 48) return launch_attn<T, 48, 64, true>(d, p, st);
   if (hd <= 64) return launch_attn<T, 64, 64, false>(d, p, st);
   if (hd <= 80) return launch_attn<T, 80, 96, true>(d, p, st);
@@ -601,7 +618,11 @@ extern "C" int tg_attention(const tg_attn_desc* d, void* stream) {
   p.w1_dev = d->w1_dev;
   p.out = d->out; p.out_ld = d->out_ld; p.out_bs = d->out_bs;
   p.causal = d->causal;
-  { const char* e = getenv("TG_ATTN_FLAGS"); p.flags = e ? (int)strtol(e, nullptr, 0) : 0; }
+  if (d->mask != nullptr) {
+    TG_CHECK(d->scale > 0.f, TG_ERR_ARG, "tg_attention: an additive mask needs scale > 0");
+    p.mask = d->mask; p.mask_bs = d->mask_bs; p.mask_hs = d->mask_hs; p.mask_qs = d->mask_qs;
+    p.inv_scale = 1.0f / d->scale;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return dispatch_attn<bf16_t>(d, p, st);
   return dispatch_attn<f16_t>(d, p, st);

@@ -6,6 +6,8 @@ The reference has no distributed code at all (zero ``torch.distri
 (``torch.distributed`` backend "nccl" on ROCm) is used only for
   * ``broadcast`` of the shared conditioning (negative-prompt text embeds, per-character image tokens) from rank 0,
   * ``all_gather`` of the final latents (32-64 KB per image) at the end of a step.
+Two partitionings: by DIALOGUE (weak scaling: every rank denoises its own story per step — the SCALE line) and
+WITHIN a dialogue by (turn, character) (``run_story_strong``: one story's 8 jobs split over the ranks, `bench.py --scaling strong`).
 Messages are KB-scale and latency-bound; there is no all-reduce and no ring.  The same code runs on CPU tensors
 with the ``gloo`` backend (world_size-2 tests in tests/test_distributed_cpu.py).
 """
@@ -46,6 +48,30 @@ def is_dist(force=False):
 def shard(items, rank, world):
     """Round-robin partition of independent work items (dialogues / character jobs)."""
     return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def unshard(gathered, world):
+    """Inverse of ``shard`` for an ``all_gather`` result: ``gathered`` [world * per, ...] is rank-major (rank r's items r, r + world,
+    ...), the result is in ITEM order (item k * world + r = gathered[r * per + k]).  Needs the same count on every rank."""
+    per = gathered.shape[0] // world
+    assert per * world == gathered.shape[0]
+    return gathered.reshape(world, per, *gathered.shape[1:]).transpose(0, 1).reshape(gathered.shape)
+
+
+def run_story_strong(jobs, rank, world, make_inputs, denoise, force=False):
+    """SECOND partitioning of SURVEY §8(e) — strong scaling WITHIN one dialogue: the story's (turn, character) jobs are independent
+    50-step chains (reference theatergen.py:214-271: one `generate_single_object_with_box` call each, nothing shared but the
+    character's image tokens), so rank r denoises jobs r, r + world, ...; the final latents are all-gathered and put back in job
+    order.  ``make_inputs(my_jobs) -> (enc, lat)`` builds the conditioning from the (already broadcast) shared tensors;
+    ``denoise(enc, lat) -> finals [n_local, C, h, w]``.  No data-path collective: one all_gather of 64 KB per image at the end."""
+    if len(jobs) % world:
+        raise ValueError(f"{len(jobs)} character jobs do not split evenly over {world} ranks")
+    mine = shard(jobs, rank, world)
+    enc, lat = make_inputs(mine)
+    finals = denoise(enc, lat)
+    if not is_dist(force):
+        return finals
+    return unshard(gather_latents(finals, force), dist.get_world_size())
 
 
 def broadcast_conditioning(tensors, src=0, force=False):

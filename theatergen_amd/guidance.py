@@ -18,14 +18,19 @@ from .utils import scale_proportion
 
 _mask_cache = {}           # (boxes, H, W, device) -> (host mask, device mask): box masks are step-invariant, uploaded once
 _MASK_CACHE_MAX = 256
+_mask_pinned = {}          # masks a stream capture has read: their device address is baked into a hipGraph, so they are never evicted
 
 
 def _box_mask(obj_boxes, H, W, device):
     if not isinstance(obj_boxes[0], Iterable):
         obj_boxes = [obj_boxes]
     key = (tuple(tuple(float(v) for v in bx) for bx in obj_boxes), int(H), int(W), str(device))
-    hit = _mask_cache.get(key)
+    capturing = ops.capturing_now()
+    hit = _mask_pinned.get(key) or _mask_cache.get(key)
     if hit is None:
+        if capturing:
+            raise RuntimeError("guidance: this box mask is not on the device yet and a stream capture is in progress (the upload cannot "
+                               "be captured): run the same call once eagerly before capturing it")
         m = torch.zeros(H, W)
         for bx in obj_boxes:
             x0, y0, x1, y1 = scale_proportion(bx, H=H, W=W)
@@ -33,6 +38,8 @@ def _box_mask(obj_boxes, H, W, device):
         if len(_mask_cache) >= _MASK_CACHE_MAX:
             _mask_cache.pop(next(iter(_mask_cache)))
         hit = _mask_cache[key] = (m, m.to(device))
+    if capturing:
+        _mask_pinned[key] = hit
     return hit
 
 

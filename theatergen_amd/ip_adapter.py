@@ -14,11 +14,15 @@ it is only constructed when ``image_encoder_path`` is given; with ``image_encode
 pre-computed ``clip_image_embeds`` (what the benchmark's synthetic image tokens stand for).
 """
 import os
+import re
 
 import torch
 
 from .attention_processor import AttnProcessor, CNAttnProcessor, IPAttnProcessor
 from .resampler import ImageProjModel, MLPProjModel, Resampler
+
+
+_LAYER_NAME = re.compile(r"^(mid_block|up_blocks|down_blocks)(?:\.(\d+))?\.")
 
 
 class IPAdapter:
@@ -64,47 +68,55 @@ class IPAdapter:
                               clip_embeddings_dim=self._clip_projection_dim,
                               clip_extra_context_tokens=self.num_tokens).to(self.device, dtype=self.dtype)
 
+    def _processor_table(self):
+        """(name, hidden width or None) per attention layer, in ``unet.attn_processors`` order.  The contract of reference :95-113:
+        ``attn1`` layers are self-attention (no width needed), every other layer is a cross-attention of its block's width —
+        ``block_out_channels`` indexed forwards for ``down_blocks.<i>``, backwards for ``up_blocks.<i>``, last entry for ``mid_block``."""
+        widths = list(self.pipe.unet.config.block_out_channels)
+        pick = {"mid_block": lambda i: widths[-1], "up_blocks": lambda i: widths[::-1][i], "down_blocks": lambda i: widths[i]}
+        table = []
+        for name in self.pipe.unet.attn_processors.keys():
+            if name.endswith("attn1.processor"):
+                table.append((name, None))
+                continue
+            m = _LAYER_NAME.match(name)
+            if m is None:
+                raise RuntimeError(f"IPAdapter: cannot place attention layer {name!r} in a UNet block")
+            table.append((name, pick[m.group(1)](int(m.group(2) or 0))))
+        return table
+
     def set_ip_adapter(self):
         unet = self.pipe.unet
-        attn_procs = {}
-        for name in unet.attn_processors.keys():
-            cross_attention_dim = None if name.endswith("attn1.processor") else unet.config.cross_attention_dim
-            if name.startswith("mid_block"):
-                hidden_size = unet.config.block_out_channels[-1]
-            elif name.startswith("up_blocks"):
-                block_id = int(name[len("up_blocks.")])
-                hidden_size = list(reversed(unet.config.block_out_channels))[block_id]
-            elif name.startswith("down_blocks"):
-                block_id = int(name[len("down_blocks.")])
-                hidden_size = unet.config.block_out_channels[block_id]
-            if cross_attention_dim is None:
-                attn_procs[name] = AttnProcessor()
-            else:
-                old = unet.attn_processors[name]
-                if isinstance(old, IPAttnProcessor) and old.num_tokens == self.num_tokens and old.hidden_size == hidden_size:
-                    attn_procs[name] = old                      # keep already-loaded IP weights
-                else:
-                    attn_procs[name] = IPAttnProcessor(hidden_size=hidden_size, cross_attention_dim=cross_attention_dim,
-                                                       scale=1.0, num_tokens=self.num_tokens).to(self.device, dtype=self.dtype)
-        unet.set_attn_processor(attn_procs)
-        if hasattr(self.pipe, "controlnet") and self.pipe.controlnet is not None:
-            nets = getattr(self.pipe.controlnet, "nets", None)
-            for net in (nets if nets is not None else [self.pipe.controlnet]):
-                net.set_attn_processor(CNAttnProcessor(num_tokens=self.num_tokens))
+        ctx = unet.config.cross_attention_dim
+        current = unet.attn_processors
+        procs = {}
+        for name, width in self._processor_table():
+            if width is None:
+                procs[name] = AttnProcessor()
+                continue
+            old = current[name]
+            keep = isinstance(old, IPAttnProcessor) and old.num_tokens == self.num_tokens and old.hidden_size == width
+            procs[name] = old if keep else IPAttnProcessor(hidden_size=width, cross_attention_dim=ctx, scale=1.0,      # keep loaded IP weights
+                                                           num_tokens=self.num_tokens).to(self.device, dtype=self.dtype)
+        unet.set_attn_processor(procs)
+        controlnet = getattr(self.pipe, "controlnet", None)
+        for net in (getattr(controlnet, "nets", None) or ([controlnet] if controlnet is not None else [])):
+            net.set_attn_processor(CNAttnProcessor(num_tokens=self.num_tokens))        # reference :120-125 (Multi- or single ControlNet)
 
     def load_ip_adapter(self):
+        """checkpoint -> the two sub-dicts ``image_proj`` / ``ip_adapter`` (reference :127-140): a ``.safetensors`` file stores them flat
+        under those two prefixes, a ``.bin`` already nested"""
         if os.path.splitext(self.ip_ckpt)[-1] == ".safetensors":
             from safetensors import safe_open
-            state_dict = {"image_proj": {}, "ip_adapter": {}}
+            parts = {"image_proj": {}, "ip_adapter": {}}
             with safe_open(self.ip_ckpt, framework="pt", device="cpu") as f:
                 for key in f.keys():
-                    if key.startswith("image_proj."):
-                        state_dict["image_proj"][key.replace("image_proj.", "")] = f.get_tensor(key)
-                    elif key.startswith("ip_adapter."):
-                        state_dict["ip_adapter"][key.replace("ip_adapter.", "")] = f.get_tensor(key)
+                    prefix, _, rest = key.partition(".")
+                    if prefix in parts:
+                        parts[prefix][rest] = f.get_tensor(key)
         else:
-            state_dict = torch.load(self.ip_ckpt, map_location="cpu")
-        self.load_state_dicts(state_dict["image_proj"], state_dict["ip_adapter"])
+            parts = torch.load(self.ip_ckpt, map_location="cpu")
+        self.load_state_dicts(parts["image_proj"], parts["ip_adapter"])
 
     def load_state_dicts(self, image_proj_sd, ip_adapter_sd):
         self.image_proj_model.load_state_dict(image_proj_sd)
@@ -150,10 +162,25 @@ class IPAdapterPlus(IPAdapter):
                          embedding_dim=self._clip_hidden_size, output_dim=unet_cfg.cross_attention_dim,
                          ff_mult=4).to(self.device, dtype=self.dtype)
 
+    def _zero_image_states(self, like):
+        """CLIP penultimate hidden states of an all-zero image (reference :313-315): a constant of the encoder, computed once"""
+        if self.image_encoder is None:
+            raise RuntimeError("IPAdapterPlus.get_image_embeds: the unconditional branch is the CLIP hidden state of an all-zero image "
+                               "(ip_adapter/ip_adapter.py:313-315); this adapter was built without an image encoder, so pass "
+                               "uncond_clip_image_embeds= next to clip_image_embeds=")
+        cached = getattr(self, "_zero_states", None)
+        if cached is None:
+            size = self.image_encoder.config.image_size
+            zeros = torch.zeros((1, 3, size, size), device=self.device, dtype=self.dtype)
+            cached = self._zero_states = self.image_encoder(zeros, output_hidden_states=True).hidden_states[-2]
+        return cached.expand(like.shape[0], -1, -1)
+
     @torch.inference_mode()
     def get_image_embeds(self, pil_image=None, clip_image_embeds=None, uncond_clip_image_embeds=None):
-        """``clip_image_embeds``: penultimate hidden states [b, 257, hidden] (``hidden_states[-2]``, :310);
-        ``uncond_clip_image_embeds``: the same for an all-zero image (:313-315)."""
+        """Reference signature ``(pil_image=None, clip_image_embeds=None)`` (:305-317; there only ``pil_image`` is honoured).  Here
+        ``clip_image_embeds`` = precomputed penultimate hidden states [b, 257, hidden] (``hidden_states[-2]``, :310) is honoured too;
+        the unconditional states come from ``uncond_clip_image_embeds`` (extension) or are computed from a zero image with the
+        adapter's own encoder."""
         if pil_image is not None:
             if self.image_encoder is None:
                 raise RuntimeError("IPAdapterPlus was built without a CLIP image encoder: pass clip_image_embeds=")
@@ -162,14 +189,16 @@ class IPAdapterPlus(IPAdapter):
             clip_image = self.clip_image_processor(images=pil_image, return_tensors="pt").pixel_values
             clip_image = clip_image.to(self.device, dtype=self.dtype)
             clip_image_embeds = self.image_encoder(clip_image, output_hidden_states=True).hidden_states[-2]
-            uncond_clip_image_embeds = self.image_encoder(torch.zeros_like(clip_image), output_hidden_states=True).hidden_states[-2]
+        elif clip_image_embeds is None:
+            raise RuntimeError("IPAdapterPlus.get_image_embeds: pass pil_image= or clip_image_embeds=")
+        clip_image_embeds = clip_image_embeds.to(self.device, dtype=self.dtype)
         if uncond_clip_image_embeds is None:
-            raise RuntimeError("IPAdapterPlus.get_image_embeds needs uncond_clip_image_embeds (CLIP hidden states of a zero image)")
+            uncond_clip_image_embeds = self._zero_image_states(clip_image_embeds)
         # the Resampler is ~40 launch-bound kernels per call: replayed from a hipGraph when it has one to offer (Resampler.graphed)
         proj = getattr(self.image_proj_model, "graphed", None) if getattr(self, "use_graph", True) else None
         proj = proj if proj is not None else self.image_proj_model
-        image_prompt_embeds = proj(clip_image_embeds.to(self.device, dtype=self.dtype))
-        uncond_image_prompt_embeds = proj(uncond_clip_image_embeds.to(self.device, dtype=self.dtype))
+        image_prompt_embeds = proj(clip_image_embeds)
+        uncond_image_prompt_embeds = proj(uncond_clip_image_embeds.to(self.device, dtype=self.dtype).contiguous())
         return image_prompt_embeds, uncond_image_prompt_embeds
 
 

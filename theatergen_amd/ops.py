@@ -193,8 +193,10 @@ def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, ups
 
 
 def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch, heads, head_dim, n_q, scale,
-              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0, causal=False, w1_dev=None):
-    """``w1_dev``: fp32 device scalar read by the kernel instead of the launch constant ``w1`` (graph-replayable IP scale)"""
+              out, out_ld, out_bs, k1=None, k1_ld=0, k1_bs=0, vt1=None, vt1_ld=0, vt1_bs=0, len1=0, w1=0.0, causal=False, w1_dev=None,
+              mask=None):
+    """``w1_dev``: fp32 device scalar read by the kernel instead of the launch constant ``w1`` (graph-replayable IP scale).
+    ``mask``: additive score bias, fp32 [Bm, Hm, Qm, len0] with Bm in {1, batch}, Hm in {1, heads}, Qm in {1, n_q} (size-1 dims broadcast)."""
     _need_cuda(q)
     d = AttnDesc()
     d.dtype = _dt(q)
@@ -213,6 +215,16 @@ def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch,
         if w1_dev.dtype != torch.float32 or not w1_dev.is_cuda:
             raise RuntimeError("attention: w1_dev must be an fp32 device tensor")
         d.w1_dev = w1_dev.data_ptr()
+    if mask is not None:
+        if mask.dtype != torch.float32 or not mask.is_cuda or mask.ndim != 4 or not mask.is_contiguous() or mask.shape[3] != len0:
+            raise RuntimeError("attention: mask must be a contiguous fp32 device tensor [Bm, Hm, Qm, len0]")
+        bm, hm, qm, _ = mask.shape
+        if bm not in (1, batch) or hm not in (1, heads) or qm not in (1, n_q):
+            raise RuntimeError(f"attention: mask shape {tuple(mask.shape)} does not broadcast to [{batch}, {heads}, {n_q}, {len0}]")
+        d.mask = mask.data_ptr()
+        d.mask_bs = hm * qm * len0 if bm > 1 else 0
+        d.mask_hs = qm * len0 if hm > 1 else 0
+        d.mask_qs = len0 if qm > 1 else 0
     _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
     return out
 
@@ -507,6 +519,11 @@ def sumpool2x2(du, batch, h, w):
     return out
 
 
+def capturing_now():
+    """True while the current stream is being captured into a hipGraph"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class GuidanceBatch:
     """Collects the terms of one ``compute_ca_lossv3`` call (one per attention map x object x token position) and evaluates
     them with ONE ``tg_guidance_plan_run`` launch pair (+ an in-order fold) instead of one dependent launch each.
@@ -524,6 +541,8 @@ class GuidanceBatch:
     KIND_TOPK, KIND_RATIO, KIND_REF = 0, 1, 2
     _tables = {}            # (device index, item signature) -> (device table tensor, n_items, max_hw_topk, max_heads)
     _TABLES_MAX = 128
+    _pinned = {}            # entries a stream CAPTURE has read: a captured hipGraph bakes the table's device address, so they are never
+                            # evicted (a 64-byte row per term; ADVICE r3: the FIFO above recycled tables under still-cached graphs)
 
     def __init__(self, device):
         self.device = device
@@ -567,8 +586,12 @@ class GuidanceBatch:
             self._launch(now[half:], loss)
             return
         key = (self.device.index, tuple(rows))
-        hit = GuidanceBatch._tables.get(key)
+        capturing = capturing_now()
+        hit = GuidanceBatch._pinned.get(key) or GuidanceBatch._tables.get(key)
         if hit is None:
+            if capturing:
+                raise RuntimeError("guidance: this term layout has no device table yet and a stream capture is in progress (the upload "
+                                   "cannot be captured): run the same call once eagerly before capturing it")
             arr = (_lib.GuidancePItem * len(rows))()
             for a, r in zip(arr, rows):
                 (a.attn_slot, a.grad_slot, a.mask_slot, a.ref_slot, a.heads, a.hw, a.n_tok, a.token, a.kind, a.k_fg, a.k_bg,
@@ -578,6 +601,8 @@ class GuidanceBatch:
             if len(GuidanceBatch._tables) >= GuidanceBatch._TABLES_MAX:
                 GuidanceBatch._tables.pop(next(iter(GuidanceBatch._tables)))
             GuidanceBatch._tables[key] = hit
+        if capturing:
+            GuidanceBatch._pinned[key] = hit
         table, n, max_hw, max_heads = hit
         ptrs = (C.c_void_p * len(slots))(*[t.data_ptr() for t in slots])
         head_terms = torch.empty(n * max_heads, dtype=torch.float32, device=self.device)
@@ -599,6 +624,7 @@ class GuidanceBatch:
                     now.append(it)
             self._launch(now, loss)
             items = later
-        # nothing is pinned beyond the last launch: every tensor is used on the current stream only, and the caching allocator
-        # hands a freed block back to that same stream (stream-ordered reuse)
+        # eager launches pin nothing beyond the last launch: every tensor is used on the current stream only, and the caching allocator
+        # hands a freed block back to that same stream (stream-ordered reuse).  Under a stream capture the item table is pinned above,
+        # the box masks by guidance._box_mask, and the per-call tensors (maps, gradients, head terms) live in the graph's private pool.
         return loss
