@@ -118,8 +118,23 @@ def gemm_by_kernel(step_fn):
     return table, tot_ms, tot_fl
 
 
+def _family(label):
+    """kernel TEMPLATE of a per-launch label: `gemm_glds_kernel<plain+ln,128x128>` -> `gemm_glds_kernel` (the sum over its instantiations
+    decides which kernel is dominant: a template split into two symbols must not change the headline)"""
+    return label.split("<", 1)[0]
+
+
+def _library_build():
+    try:
+        with open(os.path.join(ROOT, "theatergen_amd", "lib", "build_info.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def roofline_leg(unet, engine):
-    """One eager CFG step with HIP events around every GEMM/conv launch -> the dominant kernel's achieved TFLOP/s."""
+    """One eager CFG step with HIP events around every GEMM / conv / ATTENTION launch -> the dominant kernel TEMPLATE's achieved TFLOP/s
+    (all instantiations of one template summed)."""
     from theatergen_amd import ops
     with torch.no_grad():
         engine._reset(engine.history[0].clone())
@@ -134,58 +149,68 @@ def roofline_leg(unet, engine):
     if os.environ.get("TG_DUMP_RECS"):
         with open(os.environ["TG_DUMP_RECS"], "w") as f:
             json.dump(recs, f)
-    by = {}
+    by, fam = {}, {}
     for r in recs:
-        k = by.setdefault(r["kernel"], dict(launches=0, ms=0.0, flops=0.0))
-        k["launches"] += 1
-        k["ms"] += r["ms"]
-        k["flops"] += r["flops"]
-    name, top = max(by.items(), key=lambda kv: kv[1]["ms"])
+        for table, key in ((by, r["kernel"]), (fam, _family(r["kernel"]))):
+            k = table.setdefault(key, dict(launches=0, ms=0.0, flops=0.0))
+            k["launches"] += 1
+            k["ms"] += r["ms"]
+            k["flops"] += r["flops"]
+    name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    members = {k: v for k, v in by.items() if _family(k) == name}
     tot_ms = sum(v["ms"] for v in by.values())
     tot_fl = sum(v["flops"] for v in by.values())
     ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
-    # process); algorithmic bytes (operands once + result once) from the live launch records for comparison
-    traffic, traffic_src = None, None
+    # HBM traffic of the same kernel template from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+    # process): launch-weighted mean over the template's instantiations; the file names the library build it was collected on
+    traffic, traffic_src, traffic_build = None, None, None
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for fn in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True):   # newest round first
         try:
             with open(os.path.join(pdir, fn)) as f:
                 pmc = json.load(f)
-            traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+            rows = [v for k, v in pmc["kernels"].items() if _family(k) == name]
+            if not rows:
+                continue
+            traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows)
+            traffic_build = {"commit": pmc.get("commit", "n/a"), "sources_sha256": pmc.get("sources_sha256")}
             traffic_src = (f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this bench command, gfx950 x2 "
-                           f"fetch correction; collected at commit {pmc.get('commit', 'n/a')}: rocprofv3 cannot run inside this process)")
+                           f"fetch correction, launch-weighted over the template's instantiations; collected at commit "
+                           f"{pmc.get('commit', 'n/a')}: rocprofv3 cannot run inside this process)")
             break
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     # algorithmic bytes per launch: operands once + result once + the residual tensor where the layer adds one; a 3x3 conv reads its
-    # input ONCE (M x C, not the M x 9C of the implicit GEMM); the fused GEGLU writes N / 2 columns
+    # input ONCE (M x C, not the M x 9C of the implicit GEMM); the fused GEGLU writes N / 2 columns; attention reads Q, K, V and writes O
     def alg_bytes(r):
+        if r.get("attention"):
+            return 2.0 * (2 * r["M"] * r["N"] + 2 * r["batch"] * r["K"] * r["N"])          # Q + O, K + V (once per batch item)
         a_elems = r["M"] * (r["K"] // 9 if "conv" in r["kernel"] else r["K"])
         n_out = r.get("n_out", r["N"])
         return 2.0 * (a_elems + r["N"] * r["K"] + r["M"] * n_out + (r["M"] * n_out if r.get("has_res") else 0))
-    alg = sum(alg_bytes(r) for r in recs if r["kernel"] == name) / top["launches"]
+    alg = sum(alg_bytes(r) for r in recs if _family(r["kernel"]) == name) / top["launches"]
     avg_s = top["ms"] / top["launches"] * 1e-3
     # the other roof: HBM-side rate of the same launches, from the counters (traffic) and from the algorithmic bytes
     hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic": round(alg / avg_s / 1e9, 1), "algorithmic_frac": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4),
            "measured": round(traffic / avg_s / 1e9, 1) if traffic else None,
            "measured_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
            "traffic_over_algorithmic": round(traffic / alg, 3) if traffic else None}
-    # the 128x128 LDS-DMA GEMM is two kernel symbols since round 3 (plain, and the LayerNorm-folded instances): their sum, so that the
-    # family that was round 2's dominant kernel stays comparable
-    fam = [v for k, v in by.items() if k.startswith("gemm_glds_kernel<plain")]
-    fam_ms, fam_fl, fam_n = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam), sum(v["launches"] for v in fam)
-    family = {"kernels": "gemm_glds_kernel<plain,*> + gemm_glds_kernel<plain+ln,*>", "launches": fam_n, "ms": round(fam_ms, 3),
-              "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms else None,
-              "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if fam_ms else None}
+    lib = _library_build()
+    families = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch_avg": round(alg), "hbm": hbm,
-            "gemm_glds_family": family,
-            "kernel": name, "launches_per_cfg_call": top["launches"], "cfg_batch_of_measured_call": 2 * engine.n_img,
+            "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src, "traffic_collected_on_build": traffic_build,
+            "library_build": lib,
+            "traffic_build_matches_library": (bool(traffic_build) and bool(lib) and traffic_build.get("sources_sha256") == lib.get("sources_sha256")) if traffic else None,
+            "algorithmic_bytes_per_launch_avg": round(alg), "hbm": hbm,
+            "kernel": name + "<*> (all instantiations: " + ", ".join(sorted(members)) + ")", "dominant_by": "kernel template, summed over instantiations",
+            "launches_per_cfg_call": top["launches"], "cfg_batch_of_measured_call": 2 * engine.n_img,
             "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
             "flop_per_launch_avg": top["flops"] / top["launches"],
-            "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
-                                 "flop_per_cfg_call": tot_fl, "launches": len(recs)},
+            "by_template": families,
+            "all_timed_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
+                                  "flop_per_cfg_call": tot_fl, "launches": len(recs), "includes": "GEMM / conv / attention launches"},
             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                           for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
 
@@ -474,12 +499,12 @@ def bench_sd21_editing(args):
                      "all_gemm_kernels": {"achieved": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(gemm_ms, 3),
                                           "note": "eager launches, HIP events per launch (event overhead ~2 us each)"},
                      "by_kernel": by_kernel},
-        "guidance": {"bound": "hbm", "achieved": round(gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 5),
+        "guidance": {"bound": "latency", "achieved": round(gb, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 5),
                      "bytes_per_step": map_bytes, "ms": round(parts["guidance"] / 5, 3),
                      "ms_in_graph": round(out["guid_graph_ms"], 4) if "guid_graph_ms" in out else None,
                      "note": "4 maps x 20 heads x (144 | 576) x 77 fp32 read + gradients written (1.5 MB per step); `ms` = eager call incl. the host's Python "
                              "(loop over keys / boxes / positions), `ms_in_graph` = the same call replayed from a hipGraph: what it costs inside the captured step; "
-                             "achieved / frac use `ms`"},
+                             "achieved / frac use `ms`; 23 MB per call is far below what fills HBM: the call is LATENCY-bound (launch + a 31-step radix select per term), the GB/s figure is informational"},
     }
     return result
 

@@ -20,6 +20,25 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result"]
 
 
+BUILD_INFO = os.path.join(LIBDIR, "build_info.json")
+
+
+def _write_build_info():
+    """which sources the shipped .so was built from: HEAD's commit + whether csrc/ differed from it (travels to the GPU box next to the
+    library; bench.py puts it beside the commit a committed PMC file was collected at, so a stale counter file is visible)"""
+    import json
+
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", HERE] + list(a), capture_output=True, text=True).stdout.strip()
+        except OSError:
+            return ""
+    info = {"commit": git("rev-parse", "--short", "HEAD"), "csrc_dirty": bool(git("status", "--porcelain", "--", CSRC, HEADER)),
+            "sources_sha256": _digest(sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [HEADER])[:16]}
+    with open(BUILD_INFO, "w") as f:
+        json.dump(info, f)
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -79,6 +98,8 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if todo or not os.path.exists(BUILD_INFO):
+        _write_build_info()
     if todo or not os.path.exists(RESOURCES_JSON):
         write_resources(check=True, verbose=verbose)           # the register / scratch gate is part of every build
     return LIB

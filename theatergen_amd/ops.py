@@ -225,7 +225,19 @@ def attention(q, q_ld, q_bs, k0, k0_ld, k0_bs, vt0, vt0_ld, vt0_bs, len0, batch,
         d.mask_bs = hm * qm * len0 if bm > 1 else 0
         d.mask_hs = qm * len0 if hm > 1 else 0
         d.mask_qs = len0 if qm > 1 else 0
+    if _gemm_profile is None:
+        _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
+        return out
+    # profiling mode (bench.py roofline leg): HIP events around this launch; algorithmic flops = QK^T + PV of both segments, no padding
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.check(_lib.lib().tg_attention(C.byref(d), _stream()))
+    e1.record()
+    keys = int(len0) + int(len1)
+    _gemm_profile.append(dict(kernel=f"attention_kernel<d{int(head_dim)},{'self' if int(len0) == int(n_q) else 'cross'}>", splits=1,
+                              M=int(batch) * int(n_q), N=int(heads) * int(head_dim), K=keys,
+                              flops=4.0 * batch * heads * n_q * keys * head_dim, events=(e0, e1), has_res=False,
+                              n_out=int(heads) * int(head_dim), attention=True, batch=int(batch)))
     return out
 
 
