@@ -255,3 +255,34 @@ def test_bench_two_gpus_over_rccl_when_the_box_has_them(scaling):
     rec = _run_bench(["--gpus", "2", "--scaling", scaling, "--steps", "1", "--warmup", "1", "--ddim-steps", "5"], timeout=1500)
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["value"] > 0
     assert rec["config"]["char_batch"] == (4 if scaling == "strong" else 8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mean,std", [(100.0, 1.0), (-40.0, 0.125), (300.0, 2.0)])
+def test_gemm_layernorm_fold_rows_with_large_mean(dtype, mean, std):
+    """the LayerNorm fold took var = E[x^2] - mean^2 in one pass; for rows with |mean| >> std that cancels.  Rows whose
+    one-pass variance falls below 1e-4 * mean^2 now get a centred second pass (csrc/tg_gemm_glds.h).  Mixed tensor: most rows
+    ordinary, every 7th row offset by `mean` with spread `std`; reference = fp32 layer_norm of the STORED values, then the projection;
+    also against the two-launch path (tg_layernorm + tg_gemm), which always took the two-pass variance."""
+    import math
+    import torch.nn.functional as F
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear
+    M, C, eps = 1024, 320, 1e-5
+    g = torch.Generator().manual_seed(int(abs(mean)) + 3)
+    x = torch.randn(M, C, generator=g)
+    x[::7] = mean + std * torch.randn(M // 7 + 1, C, generator=g)[: x[::7].shape[0]]
+    x = x.to(dtype)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.3 * torch.randn(C, generator=g)).to(dtype)
+    w = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+    xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps)
+    ref = xn @ w.float().t()
+    xd = x.to(DEV)
+    wl, u, v = pack_ln_linear(w.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+    assert ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)[3] == 6
+    got = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
+    two = ops.linear(ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), eps), w.to(DEV))
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 4e-3
+    close(got, ref, tol, f"ln fold, offset rows mean {mean} std {std}")
+    close(got[::7], ref[::7], 2 * tol, f"ln fold, ONLY the offset rows (mean {mean} std {std})")
+    close(got[::7], two[::7].float(), 2 * tol, f"ln fold vs two-launch path on the offset rows (mean {mean} std {std})")

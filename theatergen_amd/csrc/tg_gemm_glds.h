@@ -324,7 +324,24 @@ void gemm_glds_kernel(GemmParams p) {
       const float s_all = ln_s + __shfl_xor(ln_s, 1, 64), q_all = ln_q + __shfl_xor(ln_q, 1, 64);
       const float inv_k = 1.0f / (float)p.K;
       const float mean = s_all * inv_k;
-      const float var = fmaxf(__builtin_fmaf(-mean, mean, q_all * inv_k), 0.f);
+      float var = fmaxf(__builtin_fmaf(-mean, mean, q_all * inv_k), 0.f);
+      // E[x^2] - mean^2 cancels when |mean| >> std: its absolute error is ~1e-6 * mean^2, so below var = 1e-4 * mean^2
+      // (|mean| / std > 100) the row's variance is RE-TAKEN centred, from global memory, by the row's two threads (rare rows only: the
+      // fast path of every other row is untouched; tg_layernorm takes the same two-pass form)
+      if (var < 1e-4f * mean * mean && m0 + srow < p.M) {
+        const long m = m0 + srow;
+        long off = m * p.c0;
+        if (p.a_rpb > 0) { const long bb = m / p.a_rpb; off = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
+        const T* xr = A0 + off;
+        float c2 = 0.f;
+        for (long k = shalf * 8; k < p.K; k += 16) {
+          const V8 v = *reinterpret_cast<const V8*>(xr + k);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float dlt = to_f32<T>(v[e]) - mean; c2 = __builtin_fmaf(dlt, dlt, c2); }
+        }
+        c2 += __shfl_xor(c2, 1, 64);
+        var = c2 * inv_k;
+      }
       const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
       if (shalf == 0) {
         lnrow[2 * srow] = rstd;
