@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 302
+#define TG_ABI_VERSION 303
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -370,6 +370,53 @@ typedef struct {
 } tg_guidance_pitem;
 int tg_guidance_plan_run(const tg_guidance_pitem* items_device, int32_t n_items, int32_t max_hw_topk, int32_t max_heads,
                          const void* const* slots_host, int32_t n_slots, float* head_terms, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-chain kernels (round 4, csrc/tg_rowchain.hip): row-local layers at K = C in {320, 640} with the TOKEN ON THE LANE — a wave
+ * keeps its 32 token rows in registers as MFMA operands, the weights arrive fragment-packed (theatergen_amd/weights_pack.py::rc_pack)
+ * through LDS.  tg_rc_linear: out[m, :] = [LayerNorm-folded] x[m, :] W^T + v (+ res[m, :]), the projections of `Attention`
+ * (ip_adapter/attention_processor.py:113-128) and `Transformer2DModel.proj_in / proj_out` (models/transformer_2d.py:150-163) at the
+ * first UNet level.  `wpk`: N / 64 chunks of (128 K + 1024) bytes: the chunk's weight fragments, then one vector page (fp32 v[64]:
+ * bias, or W beta + bias with the fold; fp32 u[64]: row sums of the rounded W gamma, fold only).  `ln` != 0: x is the UN-normalised
+ * stream, statistics per row in fp32 (two-pass, as tg_layernorm).  `variant`: dev switch between workgroup shapes / schedules. */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  const void* wpk;
+  const void* res; int64_t ldres;
+  void* out; int64_t ldc;
+  int64_t M;
+  int32_t N, K;
+  int32_t ln;
+  float ln_eps;
+  int32_t variant;
+} tg_rc_linear_desc;
+int tg_rc_linear(const tg_rc_linear_desc* d, void* stream);
+
+/* tg_rc_xattn: norm2 + attn2 (IPAttnProcessor / AttnProcessor cross-attention) + residual of a first-level BasicTransformerBlock in one
+ * launch for SD-1.5's geometry (320 channels = 8 heads x 40, 77 text keys, 0 / 4 / 16 image keys):
+ *     out = to_out(softmax(q Kt^T) Vt + w softmax(q Kip^T) Vip) + bias + h,    q = to_q(LayerNorm(h))
+ * (models/attention.py:206-224; ip_adapter/attention_processor.py:445-529, 282-393).  `wq` / `wo`: rc_pack chunk streams of the
+ * permuted weights (theatergen_amd/rowchain.py: LayerNorm and softmax scale * log2(e) folded into wq); `kv`: tg_rc_kv_pack output
+ * [batch][8][24 KiB]; `ip_scale`: DEVICE fp32 scalar (IPAttnProcessor.scale, graph-replayable) or NULL (= 1).
+ * tg_rc_kv_pack: text K [batch * text_len, 320] / V^T [batch, 320, ldt] and image K [batch * ip_tokens, 320] / V^T [batch, 320, ldi]
+ * (the layouts IPAttnProcessor's projection GEMMs write) -> `out` fragments, batch * 8 * 24 KiB. */
+typedef struct {
+  int32_t dtype;
+  const void* h; int64_t ldh;
+  const void* wq;
+  const void* kv;
+  const void* wo;
+  void* out; int64_t ldc;
+  int64_t M;
+  int32_t rows_per_batch;
+  int32_t text_len, ip_tokens;
+  float ln_eps;
+  const float* ip_scale;
+} tg_rc_xattn_desc;
+int tg_rc_xattn(const tg_rc_xattn_desc* d, void* stream);
+int tg_rc_kv_pack(int32_t dtype, int32_t batch, const void* k, const void* vt, int64_t ldt, int32_t text_len, const void* kip,
+                  const void* vtip, int64_t ldi, int32_t ip_tokens, void* out, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

@@ -550,3 +550,62 @@ def test_ip_scale_is_a_plain_mutable_attribute():
     assert p.scale == 0.0
     p.scale = 1
     assert p.scale == 1 and "scale" not in dict(p.named_parameters())
+
+
+def test_rc_pack_layout_emulated_mfma():
+    """``weights_pack.rc_pack`` / ``rc_pack_tiles`` against a CPU emulation of what ``tg_rc_linear`` does with the stream: MFMA A fragment of
+    block (chunk c, tile u, k-step s) x B fragment (the wave's 32 token rows, input channel 64 (s >> 2) + 32 hi + 8 (s & 3) + j), accumulator
+    register rho of lane half hi = output channel 64 c + 32 hi + 16 u + rho (32x32 C/D layout: row = (rho & 3) + 8 (rho >> 2) + 4 hi)."""
+    import torch
+    from theatergen_amd.weights_pack import rc_pack, rc_pack_tiles
+    torch.manual_seed(0)
+    N, K, M = 128, 320, 32
+    W = torch.randn(N, K).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    v = torch.randn(N)
+    KS = K // 16
+
+    def emulate(get_block, get_v):
+        out = torch.zeros(M, N)
+        for c in range(N // 64):
+            for u in range(2):
+                D = torch.zeros(32, M)
+                for s in range(KS):
+                    frag = get_block(c, u, s)                     # [hi, r, j]
+                    A = torch.zeros(32, 16)
+                    Bm = torch.zeros(16, M)
+                    for hi in range(2):
+                        A[:, 8 * hi:8 * hi + 8] = frag[hi]
+                        ch = 64 * (s >> 2) + 32 * hi + 8 * (s & 3)
+                        Bm[8 * hi:8 * hi + 8] = x[:, ch:ch + 8].float().T
+                    D += A @ Bm
+                for hi in range(2):
+                    for rho in range(16):
+                        r = (rho & 3) + 8 * (rho >> 2) + 4 * hi
+                        out[:, 64 * c + 32 * hi + 16 * u + rho] = D[r] + get_v(c, u, hi, rho)
+        return out
+    ref = x.float() @ W.float().T + v
+    pk = rc_pack(W, v)
+    CB = 128 * K + 1024
+    assert pk.numel() == (N // 64) * CB
+    frag = lambda c, u, s: pk[c * CB:c * CB + 128 * K].view(torch.bfloat16).float().reshape(2, KS, 2, 32, 8)[u, s]
+    vec = lambda c, u, hi, rho: pk[c * CB + 128 * K:(c + 1) * CB].view(torch.float32)[32 * hi + 16 * u + rho]
+    assert (emulate(frag, vec) - ref).abs().max() < 1e-4
+    pt = rc_pack_tiles(W, v)
+    TB = 64 * K + 1024
+    assert pt.numel() == (N // 32) * TB + 3072
+    fragt = lambda c, u, s: pt[(2 * c + u) * TB:(2 * c + u) * TB + 64 * K].view(torch.bfloat16).float().reshape(KS, 2, 32, 8)[s]
+    vect = lambda c, u, hi, rho: pt[(2 * c + u) * TB + 64 * K:(2 * c + u + 1) * TB].view(torch.float32)[16 * hi + rho]
+    assert (emulate(fragt, vect) - ref).abs().max() < 1e-4
+
+
+def test_rc_xattn_slot_maps_are_permutations():
+    from theatergen_amd import rowchain
+    q, o = rowchain._q_slot_channels(), rowchain._o_slot_channels()
+    assert sorted(q.tolist()) == list(range(320)) and sorted(o.tolist()) == list(range(320))
+    # a head pair owns exactly five q k-steps (80 slots) and five O k-steps
+    for m in range(4):
+        for perm in (q, o):
+            slots = [n for n in range(320) if perm[n] // 80 == m]
+            ksteps = sorted({4 * (n // 64) + ((n // 8) & 3) for n in slots})
+            assert ksteps == list(range(5 * m, 5 * m + 5))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 302          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 303          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -39,6 +39,20 @@ class AttnDesc(C.Structure):
         ("k1", vp), ("k1_ld", i64), ("k1_bs", i64), ("vt1", vp), ("vt1_ld", i64), ("vt1_bs", i64), ("len1", i32),
         ("scale", f32), ("w1", f32), ("out", vp), ("out_ld", i64), ("out_bs", i64), ("causal", i32), ("w1_dev", vp),
         ("mask", vp), ("mask_bs", i64), ("mask_hs", i64), ("mask_qs", i64),
+    ]
+
+
+class RcLinearDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("x", vp), ("ldx", i64), ("wpk", vp), ("res", vp), ("ldres", i64),
+        ("out", vp), ("ldc", i64), ("M", i64), ("N", i32), ("K", i32), ("ln", i32), ("ln_eps", f32), ("variant", i32),
+    ]
+
+
+class RcXattnDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("h", vp), ("ldh", i64), ("wq", vp), ("kv", vp), ("wo", vp), ("out", vp), ("ldc", i64), ("M", i64),
+        ("rows_per_batch", i32), ("text_len", i32), ("ip_tokens", i32), ("ln_eps", f32), ("ip_scale", vp),
     ]
 
 
@@ -102,6 +116,9 @@ SIGNATURES = {
     "tg_geglu_bwd": (i32, [i32, vp, vp, i64, i64, vp, vp]),
     "tg_softmax_bwd_rows": (i32, [i32, vp, i32, i64, vp, i64, vp, i64, i64, i32, f32, vp, vp, i64, vp]),
     "tg_sumpool2x2": (i32, [i32, vp, i32, i32, i32, i32, vp, vp]),
+    "tg_rc_linear": (i32, [C.POINTER(RcLinearDesc), vp]),
+    "tg_rc_xattn": (i32, [C.POINTER(RcXattnDesc), vp]),
+    "tg_rc_kv_pack": (i32, [i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

@@ -29,7 +29,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, rowchain
 
 
 def _round8(n):
@@ -278,7 +278,11 @@ def _finish(attn, o2d, B, N, C, shape4, x_tokens, fused_residual):
     res = fused_residual
     if res is None and attn.residual_connection:
         res = x_tokens
-    out = ops.linear(o2d, attn.to_out[0].weight, attn.to_out[0].bias, res=res, out_scale=1.0 / attn.rescale_output_factor)
+    out = None
+    if attn.rescale_output_factor == 1.0:
+        out = rowchain.linear320(o2d, attn.to_out[0].weight, attn.to_out[0].bias, res, attn, "to_out", _cached)
+    if out is None:
+        out = ops.linear(o2d, attn.to_out[0].weight, attn.to_out[0].bias, res=res, out_scale=1.0 / attn.rescale_output_factor)
     if shape4 is not None:
         b, c, h, w = shape4
         return ops.transpose(out, b, h * w, c).reshape(b, c, h, w)
@@ -315,6 +319,52 @@ def _save_probs(attn, q, q_ld, k, k_ld, B, N, L, save_attn_to_dict, save_keys, a
     if save_attn_to_dict is not None and (save_keys is None or (tuple(attn_key) in save_keys)):
         save_attn_to_dict[tuple(attn_key)] = probs
     return probs
+
+
+def fused_cross_block(attn, norm, x2d, B, N, enc, kwargs):
+    """norm2 + attn2 + residual of a first-level ``BasicTransformerBlock`` in ONE launch (``tg_rc_xattn``): returns the new stream
+    [B*N, 320], or None when the block is not eligible (other geometry, a foreign processor, attention-map capture, masks, ...) and the
+    caller runs the processor as usual.  Same arithmetic contract as the three-launch path: LayerNorm statistics in fp32 on the stored
+    rows, q rounded to the storage dtype, two independent fp32 softmaxes, O rounded once, fp32 accumulation of to_out + bias + residual."""
+    proc = attn.processor
+    if type(proc) not in (AttnProcessor, IPAttnProcessor) or enc is None or enc.ndim != 3:
+        rowchain.trace("xattn no: processor / enc", type(proc).__name__, None if enc is None else tuple(enc.shape))
+        return None
+    for k in ("save_attn_to_dict", "attention_mask", "attn_process_fn"):
+        if kwargs.get(k) is not None:
+            return None
+    if kwargs.get("return_attntion_probs") or attn.rescale_output_factor != 1.0 or attn.residual_connection:
+        return None
+    if getattr(attn, "group_norm", None) is not None or getattr(attn, "norm_cross", None) or getattr(attn, "spatial_norm", None) is not None:
+        return None
+    is_ip = type(proc) is IPAttnProcessor
+    T = int(proc.num_tokens) if is_ip else 0
+    L = enc.shape[1] - T
+    C = x2d.shape[1]
+    if enc.shape[0] != B or not rowchain.xattn_eligible(attn, C, B, N, L, T, x2d.dtype) or x2d.stride(0) != C:
+        rowchain.trace("xattn no", tuple(enc.shape), B, N, C, L, T)
+        return None
+    rowchain.trace("xattn yes", B, N, T)
+    inner = 320
+    if is_ip:
+        enc_c = enc.contiguous()
+        kvpk = proc.project_kv_frags(attn, enc_c)
+        scale_dev = proc.scale_device(x2d.device)
+    else:
+        e, Lr, enc_bs = _enc_rows(enc)
+        ldt = _round8(L)
+        k = torch.empty((B * L, inner), dtype=x2d.dtype, device=x2d.device)
+        vt = torch.zeros((B, inner, ldt), dtype=x2d.dtype, device=x2d.device)
+        w2, b2 = kv_weight(attn)
+        ops.gemm(e, w2, B * L, 2 * inner, e.shape[2], bias=b2, rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt,
+                 a_rows_per_batch=L, a_batch_stride=enc_bs)
+        kvpk = ops.rc_kv_pack(k, vt, ldt, L, None, None, 0, 0, B)
+        scale_dev = None
+    tq = [attn.to_q.weight, norm.weight, norm.bias] + ([attn.to_q.bias] if attn.to_q.bias is not None else [])
+    wq = _cached(attn, "rc_xq", tq, lambda: rowchain.pack_xattn_q(attn.to_q.weight, attn.to_q.bias, norm.weight, norm.bias, attn.scale))
+    to = [attn.to_out[0].weight] + ([attn.to_out[0].bias] if attn.to_out[0].bias is not None else [])
+    wo = _cached(attn, "rc_xo", to, lambda: rowchain.pack_xattn_out(attn.to_out[0].weight, attn.to_out[0].bias))
+    return ops.rc_xattn(x2d, wq, kvpk, wo, N, norm.eps, T, ip_scale=scale_dev, text_len=L)
 
 
 class AttnProcessor(nn.Module):
@@ -466,7 +516,25 @@ class IPAttnProcessor(nn.Module):
             slot = self._kv.put(enc, {"bkey": bkey, "attn": weakref.ref(attn), "bufs": self._alloc(attn, enc)})
         slot["kv"] = self._project_into(attn, enc, slot["bufs"])
         slot["key"] = (tensor_version(enc), self._weights_key(attn))
+        if slot.get("kvpk") is not None:
+            self._pack_frags(slot["kv"], enc.shape[0], slot["kvpk"])     # refreshed IN PLACE with the projections (graph-stable pointer)
         return slot["kv"]
+
+    @staticmethod
+    def _pack_frags(kv, B, out=None):
+        k, vt, ldt, kip, vtip, ldi, L, T = kv
+        return ops.rc_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, B, out=out)
+
+    def project_kv_frags(self, attn, enc):
+        """K / V^T of ``enc`` as the fragment blocks of the fused first-level cross-attention (``tg_rc_xattn``): for a REGISTERED
+        tensor they live in the tensor's slot and are re-packed whenever the projections are; any other tensor is packed per call."""
+        kv = self.project_kv(attn, enc)
+        slot = self._kv.get(enc)
+        if slot is not None and slot["attn"]() is attn and slot.get("kv") is kv:
+            if slot.get("kvpk") is None:
+                slot["kvpk"] = self._pack_frags(kv, enc.shape[0])
+            return slot["kvpk"]
+        return self._pack_frags(kv, enc.shape[0])
 
     def project_kv(self, attn, enc):
         """Text and image K / V^T of ``encoder_hidden_states``.  Step-invariant, but only a REGISTERED tensor (see

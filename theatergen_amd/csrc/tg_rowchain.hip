@@ -1,0 +1,796 @@
+// Row-chain kernels (round 4): the ROW-LOCAL layers of a transformer block at K = C <= 640 — every projection, the decoupled
+// text + image cross-attention against its short key set, the GEGLU feed-forward, the residual adds — with the token on the LANE.
+//
+// Why: at the UNet's first level (65536 tokens x 320 channels at CFG batch 16) the 128 x 128 LDS-tiled GEMM spends 34-39 us on a
+// 320 -> 320 projection whose operands cross HBM in 14-21 us and whose MFMAs take 6 us (profiles/r4_per_shape_eager.txt): the K loop is
+// five tiles long and the tile's fixed costs (operand fetch round trip, LDS bounce epilogue) are not amortised.  Here a WAVE owns 32
+// tokens for the whole layer (or chain of layers):
+//   * activations live in REGISTERS in MFMA B-operand form (lane & 31 = token, lane >> 5 = which half of a 64-channel group, 8
+//     consecutive channels per k-step): loaded once from HBM with 16-byte accesses (a token pair covers whole 128-byte lines);
+//   * weights are the A operand, packed ONCE on the host in fragment order (1 KiB per (32 output rows, 16 k) block, lane-linear), so a
+//     64-row chunk is one contiguous 128 K-byte piece of memory: it goes L2 -> LDS by straight LDS-DMA and every fragment read is a
+//     conflict-free linear ds_read_b128 shared by all waves of the workgroup;
+//   * the weight rows of a chunk are PERMUTED (pi below) so that the fp32 accumulators of two 32-row MFMA tiles, rounded to the storage
+//     dtype, ARE the next layer's B operand for four k-steps (and 64 contiguous bytes of the output row): a chain of row-local layers
+//     never leaves the registers, and a store is four 16-byte pieces per lane.
+// Index maps (c = 64-row chunk, u = MFMA tile of the chunk, r = MFMA row, s = k-step, hi = lane >> 5, j = element of the fragment):
+//   output channel of (c, u, r)      = 64 c + 32 ((r >> 2) & 1) + 16 u + 4 (r >> 3) + (r & 3)     (accumulator register rho of lane half
+//                                       hi holds channel 64 c + 32 hi + 16 u + rho)
+//   input channel of (s, hi, j)      = 64 (s >> 2) + 32 hi + 8 (s & 3) + j                         (lane half hi owns channels [32 hi, 32 hi + 32)
+//                                       of every 64-channel group: 64 contiguous bytes per lane and group)
+// Reference layers: `Attention.to_q / to_out[0]` (ip_adapter/attention_processor.py:113-128), `Transformer2DModel.proj_in / proj_out`
+// (models/transformer_2d.py:150-163, 286-327), `BasicTransformerBlock.norm1/2/3` folded as in tg_gemm_glds.h, `FeedForward`
+// (models/attention.py:226-236, 337-338).
+#include "tg_common.h"
+
+namespace {
+
+struct RcLinearParams {
+  const void* x;      // [M, K] storage dtype, row pitch ldx
+  long ldx;
+  const void* wpk;    // packed weights: N / 64 chunks of (128 K + 1024) bytes (rc_pack in theatergen_amd/weights_pack.py)
+  const void* res;    // [M, N] residual or NULL
+  long ldres;
+  void* out;          // [M, N]
+  long ldc;
+  long M;
+  int N, K;
+  float ln_eps;
+  int dbg;            // dev timing experiments (variant >> 8): 1 no stores, 2 no chunk DMA after the first, 4 no barrier, 8 no MFMA loop
+};
+
+// Workgroup -> row block, XCD-aware (speed only): the dispatcher places block b on XCD b % 8 and every XCD has a private L2.  The LDS-tiled
+// GEMM / conv kernels give XCD x a CONTIGUOUS eighth of the token rows (tg_gemm_common.h), so a row-chain kernel that sits between them must
+// use the same partition — with the natural order its output is striped over the eight L2s and the next kernel finds none of its rows in
+// its own L2 (measured: the rc_linear swaps alone made the graph-replayed step 1.4 % SLOWER although each launch is 20 % shorter).
+__device__ __forceinline__ int rc_block_id(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + (bid >> 3);
+}
+
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 pack8(const float* f) {
+  typename Vec<T>::v8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(f[e]);
+  return o;
+}
+
+// 4 x 4 transpose of 16-byte pieces inside every quad of lanes: in  = lane b holds piece i of ITS row in p[i];
+//                                                              out = lane b holds piece b of row i (of the quad) in p[i]   (an involution).
+// Why: a lane owns a token ROW, so a naive load / store instruction touches 64 different rows with 16 bytes each — measured 2 TB/s on
+// this chip (the vector-memory path processes one 16-byte request per lane and row).  Transposed, the quad's four lanes cover 64
+// contiguous bytes of ONE row and lane ^ 32 the other half of the 128-byte line: every instruction moves 8 whole lines.
+// Two butterfly stages of quad-permute DPP selects (v_cndmask_b32_dpp: 2 instructions per dword pair and stage = 32 per 64-byte group).
+// d[k] = mask[lane] ? y[k] : x[k] of the quad-permuted lane, four dwords per statement (VOP2-DPP selects; hipcc does not fold a DPP move
+// into a select that has two uses, and VOP2 takes its condition from VCC only).  The two s_mov in front are also the two wait states a
+// DPP read needs behind a VALU write of its source (nothing pads an asm statement).
+#define TG_SEL4_DPP(QP, MASK, D, X, Y)                                                                          \
+  asm volatile("s_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\t"                                    \
+               "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"               \
+               "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"               \
+               "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"              \
+               "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf"                   \
+               : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3])                                             \
+               : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(Y[0]), "v"(Y[1]), "v"(Y[2]), "v"(Y[3])         \
+               : "vcc")
+template <typename V8> __device__ __forceinline__ void quad_transpose(V8& p0, V8& p1, V8& p2, V8& p3) {
+  unsigned x[4][4], y[4][4];
+  {
+    const u32x4 t0 = __builtin_bit_cast(u32x4, p0), t1 = __builtin_bit_cast(u32x4, p1), t2 = __builtin_bit_cast(u32x4, p2), t3 = __builtin_bit_cast(u32x4, p3);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { x[0][d] = t0[d]; x[1][d] = t1[d]; x[2][d] = t2[d]; x[3][d] = t3[d]; }
+  }
+  // stage 1 (lane bit 0 <-> piece bit 0): y[pr] = odd lane ? partner's x[pr + 1] : x[pr];  y[pr + 1] = odd lane ? x[pr + 1] : partner's x[pr]
+  TG_SEL4_DPP("[1,0,3,2]", "0x55555555", y[0], x[1], x[0]);
+  TG_SEL4_DPP("[1,0,3,2]", "0x55555555", y[2], x[3], x[2]);
+  TG_SEL4_DPP("[1,0,3,2]", "0xaaaaaaaa", y[1], x[0], x[1]);
+  TG_SEL4_DPP("[1,0,3,2]", "0xaaaaaaaa", y[3], x[2], x[3]);
+  // stage 2 (lane bit 1 <-> piece bit 1)
+  TG_SEL4_DPP("[2,3,0,1]", "0x33333333", x[0], y[2], y[0]);
+  TG_SEL4_DPP("[2,3,0,1]", "0x33333333", x[1], y[3], y[1]);
+  TG_SEL4_DPP("[2,3,0,1]", "0xcccccccc", x[2], y[0], y[2]);
+  TG_SEL4_DPP("[2,3,0,1]", "0xcccccccc", x[3], y[1], y[3]);
+  u32x4 o0, o1, o2, o3;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { o0[d] = x[0][d]; o1[d] = x[1][d]; o2[d] = x[2][d]; o3[d] = x[3][d]; }
+  p0 = __builtin_bit_cast(V8, o0); p1 = __builtin_bit_cast(V8, o1); p2 = __builtin_bit_cast(V8, o2); p3 = __builtin_bit_cast(V8, o3);
+}
+
+// KS = K / 16 k-steps (20: K = 320), NW waves per workgroup, NBUF chunk buffers in LDS, PD = fragment read-ahead in k-steps (0: the
+// compiler's own schedule).  A chunk in memory = 2 KS KiB of weight fragments + one 1-KiB vector page (v[64] fp32, u[64] fp32, pad).
+template <typename T, int KS, int NW, int NBUF, bool LN, int PD>
+__global__ __launch_bounds__(NW * 64) void rc_linear_kernel(RcLinearParams p) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int NP = 2 * KS + 1;        // 1-KiB DMA pieces per chunk
+  constexpr int CB = NP * 1024;         // bytes of a chunk
+  constexpr int PPW = (NP + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lbid = rc_block_id((int)blockIdx.x, (int)gridDim.x);
+  const long tok0 = ((long)lbid * NW + wave) * 32;             // the wave's first token; lane (t, hi) computes token tok0 + t
+  // memory instruction i of a 4-piece group: this lane moves piece (lane & 3) of row tok0 + (t & ~3) + i (quad_transpose)
+  const int qb = lane & 3;
+  long mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = tok0 + (l31 & ~3) + i;
+    mok[i] = r < p.M;
+    mrow[i] = mok[i] ? r : p.M - 1;
+  }
+  const int NC = p.N >> 6;
+  const char* wpk = reinterpret_cast<const char*>(p.wpk);
+
+  auto issue_chunk = [&](int c, int buf) {
+    const char* src = wpk + (long)c * CB + lane * 16;
+    char* dst = smem + buf * CB;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int i = j * NW + wave;
+      if (i < NP)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b)
+    if (b < NC) issue_chunk(b, b);
+
+  // the wave's 32 token rows as B operands: B[4 q + i] = channels [64 q + 32 hi + 8 i, + 8)
+  V8 B[KS];
+  {
+    const T* xp = reinterpret_cast<const T*>(p.x) + 32 * hi + 8 * qb;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) B[s] = *reinterpret_cast<const V8*>(xp + mrow[s & 3] * p.ldx + 64 * (s >> 2));
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) quad_transpose(B[4 * q], B[4 * q + 1], B[4 * q + 2], B[4 * q + 3]);
+  }
+  float ln_rstd = 1.f, ln_std = 1.f, ln_nmean = 0.f;
+  if constexpr (LN) {
+    // two-pass row statistics on the stored values (what nn.LayerNorm reads), the token's other 160 channels sit in lane ^ 32
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += to_f32<T>(B[s][e]);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv_k = 1.0f / (float)p.K;
+    const float mean = sum * inv_k;
+    float c2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      asm volatile("" : "+v"(B[s]));      // second pass converts again: 160 fp32 copies of the row must not stay live
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = to_f32<T>(B[s][e]) - mean; c2 = __builtin_fmaf(d, d, c2); }
+    }
+    c2 += __shfl_xor(c2, 32, 64);
+    const float var = c2 * inv_k + p.ln_eps;
+    ln_rstd = __builtin_amdgcn_rsqf(var);
+    ln_std = var * ln_rstd;
+    ln_nmean = -mean;
+  } else {
+    // the compiler must see the row loads consumed BEFORE the loop, or it waits vmcnt(0) in front of the first MFMA of every iteration
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(B[s]));
+  }
+
+  const T* resp = reinterpret_cast<const T*>(p.res);
+  T* outp = reinterpret_cast<T*>(p.out);
+  // the stores of chunk c are issued at the top of iteration c + 1, BEHIND the wait for chunk c + 1's DMA: the only vmcnt(0) of the loop
+  // then waits for operations that were issued a whole MFMA block earlier (stores are vector-memory operations on gfx9: they count)
+  V8 pend[4];
+  long pend_ch = -1;
+  for (int c = 0; c < NC; ++c) {
+    const int buf = c % NBUF;
+    // chunk c has landed (this wave's pieces; the barrier covers the other waves') and every wave is done with chunk c - 1's buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
+    if (c + NBUF - 1 < NC && !(p.dbg & 2)) issue_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
+    if (pend_ch >= 0 && !(p.dbg & 1)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + pend_ch + 8 * qb) = pend[i];
+    }
+    const long ch0 = 64 * (long)c + 32 * hi;
+    V8 r8[4];
+    if (resp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(resp + mrow[i] * p.ldres + ch0 + 8 * qb);
+    }
+    const char* cbase = smem + buf * CB;
+    // accumulators start from the layer's vector terms (fp32, broadcast reads of the chunk's vector page):
+    //   plain: v;   LayerNorm fold: std * v - mean * u, scaled by rstd at the end = rstd * (x W'^T - mean u) + v
+    f32x16 acc[2];
+    {
+      const float* vec = reinterpret_cast<const float*>(cbase + 2 * KS * 1024) + 32 * hi;
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(vec + 16 * uu + 4 * g);
+          if constexpr (LN) {
+            const f32x4 u4 = *reinterpret_cast<const f32x4*>(vec + 64 + 16 * uu + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[uu][4 * g + e] = __builtin_fmaf(ln_nmean, u4[e], ln_std * v4[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[uu][4 * g + e] = v4[e];
+          }
+        }
+    }
+    const char* cb = cbase + lane * 16;
+    if (p.dbg & 8) {
+    } else if constexpr (PD == 0) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const V8 a0 = *reinterpret_cast<const V8*>(cb + s * 1024);
+        const V8 a1 = *reinterpret_cast<const V8*>(cb + (KS + s) * 1024);
+        acc[0] = mfma32(a0, B[s], acc[0]);
+        acc[1] = mfma32(a1, B[s], acc[1]);
+      }
+    } else {
+      V8 a0[KS], a1[KS];
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        a0[s] = *reinterpret_cast<const V8*>(cb + s * 1024);
+        a1[s] = *reinterpret_cast<const V8*>(cb + (KS + s) * 1024);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + PD < KS) {
+          a0[s + PD] = *reinterpret_cast<const V8*>(cb + (s + PD) * 1024);
+          a1[s + PD] = *reinterpret_cast<const V8*>(cb + (KS + s + PD) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma32(a0[s], B[s], acc[0]);
+        acc[1] = mfma32(a1[s], B[s], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // epilogue: accumulator register rho of tile uu = channel ch0 + 16 uu + rho
+    float o[32];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * uu + r] = LN ? acc[uu][r] * ln_rstd : acc[uu][r];
+    if (resp != nullptr) {
+      quad_transpose(r8[0], r8[1], r8[2], r8[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[8 * i + e] += to_f32<T>(r8[i][e]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pend[i] = pack8<T>(o + 8 * i);
+    quad_transpose(pend[0], pend[1], pend[2], pend[3]);
+    pend_ch = ch0;
+  }
+  if (pend_ch >= 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + pend_ch + 8 * qb) = pend[i];
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// rc_xattn_kernel: the whole cross-attention sub-block of a first-level BasicTransformerBlock in ONE launch, for SD-1.5's geometry
+// (C = 320 = 8 heads x 40, 77 text keys + IPT image keys):
+//     h2 = to_out( softmax(q Kt^T) Vt + w_ip softmax(q Kip^T) Vip ) + bias + h1,      q = to_q(LayerNorm(h1))
+// (models/attention.py:206-224 norm2 + attn2 + residual; IPAttnProcessor, ip_adapter/attention_processor.py:445-529: two independent
+// softmaxes; AttnProcessor :282-393 with IPT = 0).  Today that is three launches (LayerNorm-folded q GEMM 37 us, attention 53 us,
+// to_out GEMM 39 us at 65536 tokens) and 7 HBM passes over the [tokens, 320] tensor; here q, the scores, the probabilities and the
+// attention output never leave the registers of the wave that owns the 32 tokens: 2 HBM passes (+ the residual re-read).
+// A wave's life:  load h1 rows -> row statistics -> 5 weight chunks of to_q (LayerNorm folded; softmax scale * log2 e folded) -> per
+// head: S^T = K q^T (MFMA, keys on the accumulator rows), softmax over the registers (+ one lane ^ 32 exchange), P^T straight from the
+// accumulator registers as the next MFMA's B operand, O^T = V^T P^T with V^T's spare rows fed with ones (row 40 / 44 of the second
+// tile = the softmax denominator), the image keys as one more k-step -> O^T rounded = B operand of to_out -> 5 chunks -> + h1 -> store.
+// Slot layout of q / O inside the 20 k-steps (a head pair = 80 channels = 5 k-steps; m = pair):
+//   q:  k-step 5m, 5m+1: head 2m, d = 16 w + 8 hi + j;   5m+2: hi = 0 -> head 2m, d = 32 + j;  hi = 1 -> head 2m+1, d = j;
+//       k-step 5m+3, 5m+4: head 2m+1, d = 8 + 16 (w-1) + 8 hi + j (w = 1, 2).   K fragments hold zeros in the other head's half.
+//   O:  k-step 5m + 3 hh + gg (gg = 0, 1): head 2m+hh, d = 16 gg + 8 (j >> 2) + 4 hi + (j & 3)   (accumulator registers 8 gg .. 8 gg + 7);
+//       k-step 5m+2: j < 4 -> head 2m, d = 32 + 4 hi + j;  j >= 4 -> head 2m+1, d = 32 + 4 hi + j - 4.
+// Both are absorbed by the host-side row / column permutations of the packed weights (theatergen_amd/rowchain.py).
+// LDS: a ring of two 48-KiB slots fed by LDS-DMA: 5 to_q chunks (41 KiB), 4 head-PAIR K / V^T fragment sets of the wave's batch item
+// (48 KiB, packed by rc_kv_pack_kernel when the conditioning is projected), 5 to_out chunks (41 KiB).
+struct RcXattnParams {
+  const void* h;        // [M, 320] the stream before norm2 (= residual)
+  long ldh;
+  const void* wq;       // 5 chunks (rc_pack of the permuted, LayerNorm-folded, scaled to_q)
+  const void* kv;       // [batch][8 heads][24 KiB] K / V^T fragments (rc_kv_pack_kernel)
+  const void* wo;       // 5 chunks (rc_pack of the column-permuted to_out[0] + bias)
+  void* out;            // [M, 320]
+  long ldc;
+  long M;
+  int rows_per_batch;   // tokens per batch item (multiple of 32 * NW)
+  float ln_eps;
+  const float* ip_scale;  // device scalar (IPAttnProcessor.scale) or NULL (1.0)
+  int dbg;                // dev timing switches (text_len >> 8): 1 no to_q MFMAs, 2 no attention, 4 no to_out MFMAs, 8 no stage DMA, 16 no barriers
+};
+
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 pack8r(const f32x16& a, int r0) {
+  typename Vec<T>::v8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(a[r0 + e]);
+  return o;
+}
+
+template <typename T, int NW, int TEXT, int IPT>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void rc_xattn_kernel(RcXattnParams p) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int KS = 20;
+  constexpr int TBW = (KS + 1) * 1024;         // weight TILE: 20 fragment blocks + one vector page (v[32], u[32] fp32 in accumulator order)
+  constexpr int KVH = 24 * 1024;               // K (12 KiB) + V^T (12 KiB) fragments of one head
+  constexpr int SLOT = 24 * 1024;
+  static_assert(TEXT > 64 && TEXT <= 80, "text keys: three 32-key tiles, five 16-key PV steps");
+  static_assert(IPT == 0 || IPT == 4 || IPT == 16, "image tokens");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lbid = rc_block_id((int)blockIdx.x, (int)gridDim.x);
+  const long tok0 = ((long)lbid * NW + wave) * 32;
+  const int qb = lane & 3;
+  long mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = tok0 + (l31 & ~3) + i;
+    mok[i] = r < p.M;
+    mrow[i] = mok[i] ? r : p.M - 1;
+  }
+  const long bi = ((long)lbid * NW * 32) / p.rows_per_batch;            // the workgroup's batch item (uniform)
+  const char* kvb = reinterpret_cast<const char*>(p.kv) + bi * (8 * KVH);
+
+  // every stage is 24 KiB = 6 pieces per wave, unconditionally (a 21-KiB weight tile drags the next 3 KiB along: the packed streams are
+  // padded by 3 KiB): the same number of vector-memory operations per wave and stage, so the stage waits below can be COUNTED.
+  // FOUR waves per workgroup and 72 KiB of LDS: two workgroups share a CU and drift apart, so one's memory phases (row loads, residual
+  // re-read, stores: 26 of the first version's 57 us with one 8-wave workgroup per CU) run under the other's MFMA phases.
+  static_assert(NW == 4, "six 1-KiB pieces per wave and stage");
+  auto issue = [&](const char* src, int slot) {
+    const char* s0 = src + lane * 16 + wave * 1024;
+    char* dst = smem + slot * SLOT + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + j * NW * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
+  };
+  // stage st (0..27): 0-9 to_q tiles, 10-17 K / V^T of the heads, 18-27 to_out tiles; slot = st % 3, fetched TWO stages ahead
+  auto issue_stage = [&](int st) {
+    if (st < 10) issue(reinterpret_cast<const char*>(p.wq) + (long)st * TBW, st % 3);
+    else if (st < 18) issue(kvb + (long)(st - 10) * KVH, st % 3);
+    else if (st < 28) issue(reinterpret_cast<const char*>(p.wo) + (long)(st - 18) * TBW, st % 3);
+  };
+  // dev: phase stagger of the two co-resident workgroups of a CU (dbg 32: odd blocks, 64: second half of the grid; delay = dbg >> 8 x ~3.5 us)
+  if (((p.dbg & 32) && (blockIdx.x & 1)) || ((p.dbg & 64) && blockIdx.x >= gridDim.x / 2)) {
+    for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  issue_stage(0);
+  issue_stage(1);
+
+  // rows -> B operands
+  V8 H[KS];
+  {
+    const T* xp = reinterpret_cast<const T*>(p.h) + 32 * hi + 8 * qb;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) H[s] = *reinterpret_cast<const V8*>(xp + mrow[s & 3] * p.ldh + 64 * (s >> 2));
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) quad_transpose(H[4 * q], H[4 * q + 1], H[4 * q + 2], H[4 * q + 3]);
+  }
+  float ln_rstd, ln_std, ln_nmean;
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += to_f32<T>(H[s][e]);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / 320.0f);
+    float c2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      asm volatile("" : "+v"(H[s]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = to_f32<T>(H[s][e]) - mean; c2 = __builtin_fmaf(d, d, c2); }
+    }
+    c2 += __shfl_xor(c2, 32, 64);
+    const float var = c2 * (1.0f / 320.0f) + p.ln_eps;
+    ln_rstd = __builtin_amdgcn_rsqf(var);
+    ln_std = var * ln_rstd;
+    ln_nmean = -mean;
+  }
+
+  // stage st's pieces have landed when at most `younger` vector-memory operations of this wave are outstanding (they complete in
+  // issue order): the 6 pieces of stage st + 1, and in the to_out phase the previous stage's 4 residual loads and 4 deferred stores
+  auto stage_begin = [&](int st, int younger) {
+    if (younger >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if (younger >= 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (younger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (younger >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (younger >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(p.dbg & 8)) issue_stage(st + 2);
+  };
+  // One 32-row weight tile = a stream of 20 fragments consumed by 20 MFMAs on one accumulator, read PD steps ahead of their MFMA with the
+  // order PINNED (hipcc otherwise sinks every ds_read next to its MFMA: ~150 exposed cycles per MFMA).  The accumulator is seeded from
+  // the tile's vector page: v (plain) or std * v - mean * u (LayerNorm fold; times rstd at the end).
+  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold) -> f32x16 {
+    constexpr int PD = 4;
+    const char* cb = cbase + lane * 16;
+    const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
+    V8 a[KS];
+#pragma unroll
+    for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(vec + 4 * g);
+      if (fold) {
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(vec + 32 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = __builtin_fmaf(ln_nmean, u4[e], ln_std * v4[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < KS; ++x) {
+      if (x + PD < KS) a[x + PD] = *reinterpret_cast<const V8*>(cb + (x + PD) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma32(a[x], Bop[x], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+  };
+
+  // ---- to_q (LayerNorm folded): tile t = 2 c + u of chunk c gives Q[2 t], Q[2 t + 1] = B operands of the score MFMAs
+  V8 Q[KS];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    stage_begin(t, 6);
+    if (p.dbg & 1) continue;
+    f32x16 acc = tile_stream(smem + (t % 3) * SLOT, H, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
+    Q[2 * t] = pack8r<T>(acc, 0);
+    Q[2 * t + 1] = pack8r<T>(acc, 8);
+  }
+
+  // ---- attention, one head per stage; O pieces overwrite the head's dead q pieces.  Per head a stream of 12 K fragments (key tile
+  // major) and 12 V^T fragments (PV step major), each read 6 ahead of its MFMA; the V^T reads are issued before the softmax arithmetic.
+  float w_ip = 1.0f;
+  if (IPT > 0 && p.ip_scale != nullptr) w_ip = *p.ip_scale;
+  const float NEG = -1.0e30f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    typename Vec<T>::v4 third0;        // head 2m's O, d = 32 .. 39 (held until head 2m+1 has read its q from the shared k-step)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      stage_begin(10 + 2 * m + hh, 6);
+      if (p.dbg & 2) continue;
+      const char* kb = smem + ((10 + 2 * m + hh) % 3) * SLOT + lane * 16;
+      const char* vb = kb + 12 * 1024;
+      const int s0 = 5 * m + 2 * hh;          // the head's three q k-steps: s0, s0 + 1, s0 + 2
+      constexpr int NKF = 9;                  // text K fragments: (key tile, w)
+      constexpr int WN = 6;
+      V8 kf[NKF];
+#pragma unroll
+      for (int x = 0; x < WN; ++x) kf[x] = *reinterpret_cast<const V8*>(kb + x * 1024);
+      f32x16 S[3];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; S[2][r] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < NKF; ++x) {
+        if (x + WN < NKF) kf[x + WN] = *reinterpret_cast<const V8*>(kb + (x + WN) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        S[x / 3] = mfma32(kf[x], Q[s0 + x % 3], S[x / 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // V^T fragments in PV order: (step kk, tile u) -> block u * 6 + kk; the first six are in flight during the softmax
+      constexpr int NVF = 10;
+      V8 vf[NVF];
+#pragma unroll
+      for (int x = 0; x < WN; ++x) vf[x] = *reinterpret_cast<const V8*>(vb + ((x & 1) * 6 + (x >> 1)) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      // text softmax over the registers that can hold a real key: tiles 0, 1 whole, tile 2 registers with 64 + (r & 3) + 8 (r >> 2) < TEXT
+      // (hi = 1 adds 4: masked per lane half where that crosses TEXT)
+      constexpr int R2 = ((TEXT - 64 + 7) / 8) * 4;          // registers of tile 2 in use (multiple of 4; <= 8 by the static_assert)
+#pragma unroll
+      for (int r = 0; r < R2; ++r) {
+        const int k0 = 64 + (r & 3) + 8 * (r >> 2);
+        if (k0 >= TEXT) S[2][r] = NEG;
+        else if (k0 + 4 >= TEXT) S[2][r] = hi ? NEG : S[2][r];
+      }
+      float mx = NEG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(S[0][r], S[1][r]));
+#pragma unroll
+      for (int r = 0; r < R2; ++r) mx = fmaxf(mx, S[2][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[0][r] = __builtin_amdgcn_exp2f(S[0][r] - mx); S[1][r] = __builtin_amdgcn_exp2f(S[1][r] - mx); }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) S[2][r] = r < R2 ? __builtin_amdgcn_exp2f(S[2][r] - mx) : 0.f;
+      V8 pk[5];
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) pk[kk] = pack8r<T>(S[kk >> 1], 8 * (kk & 1));
+      f32x16 O[2];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[uu][r] = 0.f;
+      V8 kfi[3], vfi[2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < NVF; ++x) {
+        if (x + WN < NVF) vf[x + WN] = *reinterpret_cast<const V8*>(vb + (((x + WN) & 1) * 6 + ((x + WN) >> 1)) * 1024);
+        if constexpr (IPT > 0) {
+          // the image tile's K fragments (blocks 9..11) and V^T fragments (step 5 of both tiles) ride behind the text stream
+          if (x >= 4 && x < 7) kfi[x - 4] = *reinterpret_cast<const V8*>(kb + (9 + x - 4) * 1024);
+          if (x >= 7 && x < 9) vfi[x - 7] = *reinterpret_cast<const V8*>(vb + ((x - 7) * 6 + 5) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        O[x & 1] = mfma32(vf[x], pk[x >> 1], O[x & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (IPT > 0) {
+        // image keys: their own softmax (second segment of the decoupled cross-attention), weight w_ip, accumulated into the same O
+        f32x16 Si;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Si[r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) Si = mfma32(kfi[w], Q[s0 + w], Si);
+        __builtin_amdgcn_sched_barrier(0);
+      // rows 8 / 12 of the second tile (accumulator register 4 of both lane halves) carry sum_j p_j  (text part: scaled while the image
+      // scores are in the matrix pipe)
+        const float inv_t = __builtin_amdgcn_rcpf(O[1][4]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[0][r] *= inv_t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) O[1][r] *= inv_t;
+        constexpr int RI = IPT >= 8 ? (IPT / 8) * 4 : 4;       // registers in use: keys (r & 3) + 8 (r >> 2) (+ 4 in the upper lane half)
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+          const int k0 = (r & 3) + 8 * (r >> 2);
+          if (k0 + 4 >= IPT) Si[r] = hi ? NEG : Si[r];
+        }
+        float mi = NEG;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) mi = fmaxf(mi, Si[r]);
+        mi = fmaxf(mi, __shfl_xor(mi, 32, 64));
+        float si = 0.f;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) { Si[r] = __builtin_amdgcn_exp2f(Si[r] - mi); si += Si[r]; }
+        si += __shfl_xor(si, 32, 64);
+        const float wi = w_ip * __builtin_amdgcn_rcpf(si);
+        f32x16 pi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pi[r] = r < RI ? Si[r] * wi : 0.f;
+        const V8 pk5 = pack8r<T>(pi, 0);
+        O[0] = mfma32(vfi[0], pk5, O[0]);
+        O[1] = mfma32(vfi[1], pk5, O[1]);
+      } else {
+        const float inv_t = __builtin_amdgcn_rcpf(O[1][4]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[0][r] *= inv_t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) O[1][r] *= inv_t;
+      }
+      // O^T -> to_out's B operands, in place of the head's q pieces
+      Q[5 * m + 3 * hh] = pack8r<T>(O[0], 0);
+      Q[5 * m + 3 * hh + 1] = pack8r<T>(O[0], 8);
+      typename Vec<T>::v4 th;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) th[e] = from_f32<T>(O[1][e]);
+      if (hh == 0) third0 = th;
+      else {
+        V8 mg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mg[e] = third0[e]; mg[4 + e] = th[e]; }
+        Q[5 * m + 2] = mg;
+      }
+    }
+  }
+
+  // ---- to_out + bias + residual
+  V8 pend[4], r8[4];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const int st = 18 + 2 * c + uu;
+      stage_begin(st, st == 18 ? 6 : st <= 20 ? 10 : st == 27 ? 8 : 14);
+      if (uu == 0) {
+        // (opaque copies of the base pointers: hipcc otherwise forms all forty row addresses of this phase in the prologue and spills them)
+        const T* hp = reinterpret_cast<const T*>(p.h);
+        T* outp = reinterpret_cast<T*>(p.out);
+        asm volatile("" : "+s"(hp), "+s"(outp));
+        const long ch0 = 64 * (long)c + 32 * hi;
+        if (c > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb) = pend[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(hp + mrow[i] * p.ldh + ch0 + 8 * qb);
+      }
+      f32x16 acc;
+      if (!(p.dbg & 4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false);
+      if (uu == 0) quad_transpose(r8[0], r8[1], r8[2], r8[3]);
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = acc[r] + to_f32<T>(r8[2 * uu + (r >> 3)][r & 7]);
+      pend[2 * uu] = pack8<T>(o);
+      pend[2 * uu + 1] = pack8<T>(o + 8);
+      if (uu == 1) quad_transpose(pend[0], pend[1], pend[2], pend[3]);
+    }
+  }
+  {
+    T* outp = reinterpret_cast<T*>(p.out);
+    const long ch0 = 64 * 4 + 32 * hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + ch0 + 8 * qb) = pend[i];
+  }
+}
+
+// K / V^T of one conditioning -> the fragment blocks rc_xattn_kernel streams: per (batch item, head) 24 blocks of 1 KiB:
+//   blocks 0..11  K:   (key tile kt = blk / 3: 0..2 text keys 32 kt + r, 3 image keys r;  w = blk % 3 = the head's w-th q k-step)
+//   blocks 12..23 V^T: (tile u = (blk - 12) / 6: rows d = 32 u + r;  step kk = (blk - 12) % 6: 0..4 text keys 16 kk + 8 (j >> 2) + 4 hi + (j & 3),
+//                       5 image keys 8 (j >> 2) + 4 hi + (j & 3));  rows d = 40, 44 of the TEXT steps hold 1.0 for real keys (denominator)
+template <typename T>
+__global__ __launch_bounds__(64) void rc_kv_pack_kernel(const T* k, const T* vt, long ldt, const T* kip, const T* vtip, long ldi,
+                                                      int L, int Tn, T* out) {
+  typedef typename Vec<T>::v8 V8;
+  const int blk = blockIdx.x % 24, h = (blockIdx.x / 24) % 8, b = blockIdx.x / (24 * 8);
+  const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+  const int inner = 320;
+  V8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(0.f);
+  if (blk < 12) {
+    const int kt = blk / 3, w = blk % 3;
+    const bool ip = kt == 3;
+    const int key = ip ? r : 32 * kt + r;
+    const int len = ip ? Tn : L;
+    int d0 = -1;                                   // d of element j = 0 (8 consecutive d), -1: the other head's half / nothing
+    if ((h & 1) == 0) d0 = w < 2 ? 16 * w + 8 * hi : (hi == 0 ? 32 : -1);
+    else d0 = w == 0 ? (hi == 1 ? 0 : -1) : 8 + 16 * (w - 1) + 8 * hi;
+    if (key < len && d0 >= 0) {
+      const T* src = (ip ? kip + ((long)b * Tn + key) * inner : k + ((long)b * L + key) * inner) + 40 * h + d0;
+      o = *reinterpret_cast<const V8*>(src);
+    }
+  } else {
+    const int u = (blk - 12) / 6, kk = (blk - 12) % 6;
+    const bool ip = kk == 5;
+    const int d = 32 * u + r;
+    const int len = ip ? Tn : L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = (ip ? 0 : 16 * kk) + 8 * (j >> 2) + 4 * hi + (j & 3);
+      if (key >= len) continue;
+      if (d < 40) o[j] = ip ? vtip[((long)b * inner + 40 * h + d) * ldi + key] : vt[((long)b * inner + 40 * h + d) * ldt + key];
+      else if (!ip && (d == 40 || d == 44)) o[j] = from_f32<T>(1.0f);
+    }
+  }
+  *reinterpret_cast<V8*>(out + (((long)b * 8 + h) * 24 + blk) * 512 + lane * 8) = o;
+}
+
+template <typename T, int IPT>
+int launch_rc_xattn(const tg_rc_xattn_desc* d, const RcXattnParams& p, hipStream_t st) {
+  constexpr int NW = 4;
+  const size_t lds = 3 * 24 * 1024;
+  const long grid = (d->M + NW * 32 - 1) / (NW * 32);
+  auto k = rc_xattn_kernel<T, NW, 77, IPT>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NW * 64), lds, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+template <typename T>
+int dispatch_rc_xattn(const tg_rc_xattn_desc* d, const RcXattnParams& p, hipStream_t st) {
+  if (d->ip_tokens == 0) return launch_rc_xattn<T, 0>(d, p, st);
+  if (d->ip_tokens == 4) return launch_rc_xattn<T, 4>(d, p, st);
+  return launch_rc_xattn<T, 16>(d, p, st);
+}
+
+template <typename T, int KS, int NW, int NBUF, int PD>
+int launch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipStream_t st) {
+  const size_t lds = (size_t)NBUF * (2 * KS + 1) * 1024;
+  const long grid = (d->M + NW * 32 - 1) / (NW * 32);
+  if (d->ln) {
+    auto k = rc_linear_kernel<T, KS, NW, NBUF, true, PD>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NW * 64), lds, st, p);
+  } else {
+    auto k = rc_linear_kernel<T, KS, NW, NBUF, false, PD>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NW * 64), lds, st, p);
+  }
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+template <typename T>
+int dispatch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipStream_t st) {
+  switch (d->variant & 255) {
+    case 1: return launch_rc_linear<T, 20, 8, 2, 4>(d, p, st);       // pinned fragment read-ahead of 4 k-steps
+    case 2: return launch_rc_linear<T, 20, 8, 3, 0>(d, p, st);       // three chunk buffers
+    case 3: return launch_rc_linear<T, 20, 8, 3, 4>(d, p, st);
+    case 4: return launch_rc_linear<T, 20, 12, 3, 4>(d, p, st);      // 12 waves (three per SIMD)
+    case 5: return launch_rc_linear<T, 20, 4, 3, 4>(d, p, st);       // 4-wave workgroups
+    default: return launch_rc_linear<T, 20, 8, 2, 0>(d, p, st);      // one 8-wave workgroup per CU, the compiler's schedule
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_rc_linear(const tg_rc_linear_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_linear: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_linear: dtype %d", d->dtype);
+  TG_CHECK(d->K == 320, TG_ERR_ARG, "tg_rc_linear: K = %d (320: the token row lives in registers)", d->K);
+  TG_CHECK(d->N > 0 && d->N % 64 == 0, TG_ERR_ARG, "tg_rc_linear: N = %d must be a positive multiple of 64", d->N);
+  TG_CHECK(d->M > 0 && d->x && d->wpk && d->out, TG_ERR_ARG, "tg_rc_linear: null operand or M <= 0");
+  TG_CHECK(d->ldx >= d->K && d->ldx % 8 == 0 && d->ldc >= d->N && d->ldc % 8 == 0, TG_ERR_ARG, "tg_rc_linear: row pitches must be multiples of 8 elements");
+  TG_CHECK(!d->res || (d->ldres >= d->N && d->ldres % 8 == 0), TG_ERR_ARG, "tg_rc_linear: residual pitch");
+    RcLinearParams p;
+  p.x = d->x; p.ldx = d->ldx; p.wpk = d->wpk; p.res = d->res; p.ldres = d->ldres;
+  p.out = d->out; p.ldc = d->ldc; p.M = d->M; p.N = d->N; p.K = d->K; p.ln_eps = d->ln_eps; p.dbg = d->variant >> 8;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return dispatch_rc_linear<bf16_t>(d, p, st);
+  return dispatch_rc_linear<f16_t>(d, p, st);
+}
+
+extern "C" int tg_rc_xattn(const tg_rc_xattn_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_xattn: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_xattn: dtype %d", d->dtype);
+  TG_CHECK(d->h && d->wq && d->kv && d->wo && d->out && d->M > 0, TG_ERR_ARG, "tg_rc_xattn: null operand or M <= 0");
+  TG_CHECK((d->text_len & 255) == 77, TG_ERR_ARG, "tg_rc_xattn: %d text keys (built for CLIP's 77)", d->text_len & 255);
+  TG_CHECK(d->ip_tokens == 0 || d->ip_tokens == 4 || d->ip_tokens == 16, TG_ERR_ARG, "tg_rc_xattn: %d image tokens (0, 4 or 16)", d->ip_tokens);
+  TG_CHECK(d->rows_per_batch > 0 && d->rows_per_batch % 128 == 0 && d->M % d->rows_per_batch == 0, TG_ERR_ARG,
+           "tg_rc_xattn: rows_per_batch = %d must be a multiple of 128 that divides M (a workgroup's 128 tokens share one key set)", d->rows_per_batch);
+  TG_CHECK(d->ldh >= 320 && d->ldh % 8 == 0 && d->ldc >= 320 && d->ldc % 8 == 0, TG_ERR_ARG, "tg_rc_xattn: row pitches");
+  RcXattnParams p;
+  p.h = d->h; p.ldh = d->ldh; p.wq = d->wq; p.kv = d->kv; p.wo = d->wo; p.out = d->out; p.ldc = d->ldc; p.M = d->M;
+  p.rows_per_batch = d->rows_per_batch; p.ln_eps = d->ln_eps; p.ip_scale = d->ip_scale; p.dbg = d->text_len >> 8;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return dispatch_rc_xattn<bf16_t>(d, p, st);
+  return dispatch_rc_xattn<f16_t>(d, p, st);
+}
+
+extern "C" int tg_rc_kv_pack(int32_t dtype, int32_t batch, const void* k, const void* vt, int64_t ldt, int32_t text_len, const void* kip,
+                             const void* vtip, int64_t ldi, int32_t ip_tokens, void* out, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_rc_kv_pack: dtype %d", dtype);
+  TG_CHECK(batch > 0 && k && vt && out, TG_ERR_ARG, "tg_rc_kv_pack: null operand");
+  TG_CHECK(text_len > 0 && text_len <= 80 && ip_tokens >= 0 && ip_tokens <= 16 && (ip_tokens == 0 || (kip && vtip)), TG_ERR_ARG,
+           "tg_rc_kv_pack: %d text keys (<= 80), %d image keys (<= 16)", text_len, ip_tokens);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)batch * 8 * 24;
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(rc_kv_pack_kernel<bf16_t>, dim3(grid), dim3(64), 0, st, (const bf16_t*)k, (const bf16_t*)vt, (long)ldt,
+                       (const bf16_t*)kip, (const bf16_t*)vtip, (long)ldi, text_len, ip_tokens, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(rc_kv_pack_kernel<f16_t>, dim3(grid), dim3(64), 0, st, (const f16_t*)k, (const f16_t*)vt, (long)ldt,
+                       (const f16_t*)kip, (const f16_t*)vtip, (long)ldi, text_len, ip_tokens, (f16_t*)out);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}

@@ -177,6 +177,59 @@ def linear(x, w, bias=None, **kw):
     return gemm(x, w, M, N, K, bias=bias, **kw)
 
 
+def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0):
+    """Row-chain projection (csrc/tg_rowchain.hip): out = [LayerNorm-folded] x @ W^T + v (+ res) with the token rows in registers;
+    ``wpk`` = ``weights_pack.rc_pack(W, v, u)`` (uint8 chunk stream), x [M, 320]."""
+    from ._lib import RcLinearDesc
+    _need_cuda(x)
+    M, K = x.shape
+    assert x.stride(1) == 1 and wpk.dtype == torch.uint8 and wpk.numel() == (N // 64) * (128 * K + 1024)
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    d = RcLinearDesc()
+    d.dtype = _dt(x)
+    d.x, d.ldx, d.wpk = _ptr(x), int(x.stride(0)), _ptr(wpk)
+    d.res, d.ldres = (_ptr(res), int(res.stride(0))) if res is not None else (None, 0)
+    d.out, d.ldc = _ptr(out), int(out.stride(0))
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.ln, d.ln_eps = (1, float(ln_eps)) if ln_eps is not None else (0, 0.0)
+    d.variant = int(variant)
+    _lib.check(_lib.lib().tg_rc_linear(C.byref(d), _stream()))
+    return out
+
+
+def rc_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, batch, out=None):
+    """text K [batch * L, 320] / V^T [batch, 320, ldt] (+ image K / V^T) -> the fragment blocks ``rc_xattn`` streams: uint8-free view
+    [batch, 8, 24 * 512] of the storage dtype"""
+    _need_cuda(k)
+    if out is None:
+        out = torch.empty((batch, 8, 24 * 512), dtype=k.dtype, device=k.device)
+    _lib.check(_lib.lib().tg_rc_kv_pack(_dt(k), int(batch), _ptr(k), _ptr(vt), int(ldt), int(L), _ptr(kip), _ptr(vtip), int(ldi), int(T),
+                                       _ptr(out), _stream()))
+    return out
+
+
+def rc_xattn(h, wq, kv, wo, rows_per_batch, ln_eps, ip_tokens, ip_scale=None, out=None, text_len=77):
+    """norm2 + cross-attention (+ decoupled image keys) + to_out + residual in one launch; see tg_rc_xattn"""
+    from ._lib import RcXattnDesc
+    _need_cuda(h)
+    M, Cc = h.shape
+    assert Cc == 320 and h.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, 320, dtype=h.dtype, device=h.device)
+    d = RcXattnDesc()
+    d.dtype = _dt(h)
+    d.h, d.ldh = _ptr(h), int(h.stride(0))
+    d.wq, d.kv, d.wo = _ptr(wq), _ptr(kv), _ptr(wo)
+    d.out, d.ldc = _ptr(out), int(out.stride(0))
+    d.M, d.rows_per_batch = int(M), int(rows_per_batch)
+    d.text_len, d.ip_tokens = int(text_len), int(ip_tokens)
+    d.ln_eps = float(ln_eps)
+    d.ip_scale = _ptr(ip_scale)
+    _lib.check(_lib.lib().tg_rc_xattn(C.byref(d), _stream()))
+    return out
+
+
 def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, pad_mode=0, **kw):
     """3x3 pad-1 convolution as implicit GEMM over token-major x [batch*in_h*in_w, cin] (+ optional concat x1).
     w_packed: [cout, 9*(cin+c1)] tap-major.  ``pad_mode=1``: zero padding on the bottom / right edge only (the VAE

@@ -27,7 +27,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor
+from . import rowchain
+from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, fused_cross_block
 from .config import UNetConfig
 from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear
 
@@ -241,7 +242,9 @@ class BasicTransformerBlock(nn.Module):
                 return (norm, ops.layernorm_stats(t, norm.eps) if _LN_MODE & 4 else None)
             if _LN_MODE & 1:
                 x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d))
-                x2d = self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=folded(self.norm2, x2d))
+                # first level of SD-1.5: norm2 + attn2 + residual as ONE row-chain launch (q, scores and O stay in registers)
+                h2 = fused_cross_block(self.attn2, self.norm2, x2d, b, n, enc, ca_kwargs)
+                x2d = h2 if h2 is not None else self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=folded(self.norm2, x2d))
             else:
                 h = ops.layernorm(x2d, self.norm1.weight, self.norm1.bias, self.norm1.eps)
                 x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
@@ -286,13 +289,18 @@ class Transformer2DModel(nn.Module):
 
     def run(self, x: _Act, enc, ca_kwargs):
         y = ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False)
-        y = ops.linear(y, self._w("in", self.proj_in), self.proj_in.bias)
+        w_in = self._w("in", self.proj_in)
+        y_in = rowchain.linear320(y, w_in, self.proj_in.bias, None, self, "proj_in", _cached)
+        y = y_in if y_in is not None else ops.linear(y, w_in, self.proj_in.bias)
         base_key = list(ca_kwargs.get("attn_key", [])) if "attn_key" in ca_kwargs else None
         for i, blk in enumerate(self.transformer_blocks):
             if base_key is not None:
                 ca_kwargs["attn_key"] = base_key + [i]           # transformer_2d.py:299-304
             y = blk.run(y, x.b, x.hw, enc, ca_kwargs)
-        out = ops.linear(y, self._w("out", self.proj_out), self.proj_out.bias, res=x.t)
+        w_out = self._w("out", self.proj_out)
+        out = rowchain.linear320(y, w_out, self.proj_out.bias, x.t, self, "proj_out", _cached)
+        if out is None:
+            out = ops.linear(y, w_out, self.proj_out.bias, res=x.t)
         return _Act(out, x.b, x.h, x.w, x.c)
 
 

@@ -45,3 +45,59 @@ def pack_ln_linear(w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tenso
     if bias is not None:
         v = v + bias.detach().float()
     return wp, u, v.contiguous()
+
+
+def _rc_maps(K: int):
+    """index maps of the row-chain kernels (csrc/tg_rowchain.hip): output-row permutation of a 64-row chunk and the k order"""
+    r = torch.arange(32)
+    pi = torch.stack([32 * ((r >> 2) & 1) + 16 * u + 4 * (r >> 3) + (r & 3) for u in range(2)])      # [u, r] -> row within the chunk
+    s = torch.arange(K // 16)[:, None, None]
+    hi = torch.arange(2)[None, :, None]
+    j = torch.arange(8)[None, None, :]
+    kap = 64 * (s >> 2) + 32 * hi + 8 * (s & 3) + j                                                   # [s, hi, j] -> input channel
+    return pi, kap
+
+
+def rc_pack(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = None) -> torch.Tensor:
+    """Linear weight [N, K] (N % 64 == 0, K % 64 == 0) -> the row-chain kernels' chunk stream (uint8): per 64-row chunk c
+      * 2 MFMA tiles x K / 16 k-steps x (64 lanes x 8 elements) of weight fragments: block (u, s), lane (hi, r), element j =
+        W[64 c + pi(u, r), kappa(s, hi, j)]  (straight LDS-DMA, linear conflict-free fragment reads), then
+      * one 1-KiB vector page: fp32 v[64 c : 64 c + 64] (bias, or W beta + bias under the LayerNorm fold), fp32 u[64 c : 64 c + 64]
+        (fold: row sums of the ROUNDED W gamma), zero padding."""
+    n, k = w.shape
+    assert n % 64 == 0 and k % 64 == 0, (n, k)
+    pi, kap = _rc_maps(k)
+    rows = (64 * torch.arange(n // 64)[:, None, None] + pi[None]).to(w.device)          # [c, u, r]
+    kap = kap.to(w.device)
+    # frag[c, u, s, hi, r, j]
+    frag = w.detach()[rows[:, :, None, None, :, None], kap[None, None, :, :, None, :]].contiguous()
+    fb = frag.reshape(n // 64, -1).view(torch.uint8)                                      # [c, 128 K bytes]
+    page = torch.zeros(n // 64, 256, dtype=torch.float32, device=w.device)
+    if v is not None:
+        page[:, :64] = v.detach().float().reshape(n // 64, 64)
+    if u is not None:
+        page[:, 64:128] = u.detach().float().reshape(n // 64, 64)
+    return torch.cat([fb, page.view(torch.uint8)], dim=1).contiguous().reshape(-1)
+
+
+def rc_pack_tiles(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = None) -> torch.Tensor:
+    """As ``rc_pack`` but one stream element per 32-row MFMA TILE (tile t = 2 c + u of chunk c): K / 16 fragment blocks, then a 1-KiB
+    vector page with fp32 v[32] and u[32] in the tile's accumulator order (index 16 hi + rho <-> channel 64 c + 32 hi + 16 u + rho);
+    3 KiB of zero padding behind the last tile (the consumer fetches every (K / 16 + 1)-KiB tile as a 24-KiB stage)."""
+    n, k = w.shape
+    assert n % 64 == 0 and k % 64 == 0, (n, k)
+    pi, kap = _rc_maps(k)
+    rows = (64 * torch.arange(n // 64)[:, None, None] + pi[None]).to(w.device)          # [c, u, r]
+    kap = kap.to(w.device)
+    frag = w.detach()[rows[:, :, None, None, :, None], kap[None, None, :, :, None, :]].contiguous()   # [c, u, s, hi, r, j]
+    fb = frag.reshape(n // 32, -1).view(torch.uint8)                                      # [tile, 64 K bytes]
+    page = torch.zeros(n // 32, 256, dtype=torch.float32, device=w.device)
+
+    def tile_order(x):      # [N] -> [tile = 2 c + u, 16 hi + rho]
+        return x.detach().float().reshape(n // 64, 2, 2, 16).permute(0, 2, 1, 3).reshape(n // 32, 32)
+    if v is not None:
+        page[:, :32] = tile_order(v)
+    if u is not None:
+        page[:, 32:64] = tile_order(u)
+    out = torch.cat([fb, page.view(torch.uint8)], dim=1).contiguous().reshape(-1)
+    return torch.cat([out, torch.zeros(3 * 1024, dtype=torch.uint8, device=w.device)])
