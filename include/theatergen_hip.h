@@ -418,6 +418,27 @@ int tg_rc_xattn(const tg_rc_xattn_desc* d, void* stream);
 int tg_rc_kv_pack(int32_t dtype, int32_t batch, const void* k, const void* vt, int64_t ldt, int32_t text_len, const void* kip,
                   const void* vtip, int64_t ldi, int32_t ip_tokens, void* out, void* stream);
 
+/* tg_rc_ff: norm3 + FeedForward(GEGLU) + residual of a first-level BasicTransformerBlock (models/attention.py:226-236, 328-338), and with
+ * `wpo` != NULL also Transformer2DModel.proj_out + its residual (models/transformer_2d.py:316-327), in one launch:
+ *     h3 = net2(a * gelu(g)) + b2 + h,  [a | g] = proj(LayerNorm(h)) + b1;      out = wpo ? proj_out(h3) + b + res0 : h3
+ * `w1` / `w2` / `b2`: theatergen_amd/rowchain.py::pack_ff (LayerNorm gamma / beta folded into proj; the kernel normalises the rows);
+ * `wpo`: rc_pack_tiles stream of proj_out (+ bias).  `inner` = the hidden width (1280).  `dbg`: dev timing switches, 0. */
+typedef struct {
+  int32_t dtype;
+  const void* h; int64_t ldh;
+  const void* w1;
+  const void* w2;
+  const float* b2;
+  const void* wpo;
+  const void* res0; int64_t ldres;
+  void* out; int64_t ldc;
+  int64_t M;
+  int32_t inner;
+  float ln_eps;
+  int32_t dbg;
+} tg_rc_ff_desc;
+int tg_rc_ff(const tg_rc_ff_desc* d, void* stream);
+
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);
 

@@ -168,3 +168,60 @@ def test_first_level_block_row_chain_on_vs_off(dtype, ip, monkeypatch):
         got0 = blk.run(x, B, N, enc, {})
         check(got0, ref0, f"first-level block row-chain scale 0 {dtype}", 1.5 * l2, 1.5 * mx)
         assert (ref0.float() - ref.float()).abs().max() > 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,inner,proj", [(256, 128, False), (1000, 256, True), (8192, 1280, True), (4096, 1280, False)])
+def test_rc_ff_vs_fp32_reference(dtype, M, inner, proj):
+    """norm3 + GEGLU feed-forward + residual (+ proj_out + residual) in one launch vs the fp32 restatement of models/attention.py:226-236,
+    328-338 (erf GELU) and models/transformer_2d.py:316-327"""
+    from theatergen_amd import ops, rowchain
+    from theatergen_amd.weights_pack import rc_pack_tiles
+    g = torch.Generator().manual_seed(M + inner)
+    C = 320
+    t = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    h = (t(M, C, sc=1.2) + 0.2).to(dtype).to(DEV)
+    x0 = t(M, C).to(dtype).to(DEV)
+    w1 = t(2 * inner, C, sc=C ** -0.5).to(dtype).to(DEV); b1 = t(2 * inner, sc=0.2).to(dtype).to(DEV)
+    w2 = t(C, inner, sc=inner ** -0.5).to(dtype).to(DEV); b2 = t(C, sc=0.1).to(dtype).to(DEV)
+    wp = t(C, C, sc=C ** -0.5).to(dtype).to(DEV); bp = t(C, sc=0.1).to(dtype).to(DEV)
+    gamma = (1 + 0.2 * t(C)).to(dtype).to(DEV); beta = t(C, sc=0.1).to(dtype).to(DEV)
+    x = F.layer_norm(h.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    pr = x @ w1.float().T + b1.float()
+    h3 = (pr[:, :inner] * F.gelu(pr[:, inner:])) @ w2.float().T + b2.float() + h.float()
+    ref = h3 @ wp.float().T + bp.float() + x0.float() if proj else h3
+    s1, s2, bb2 = rowchain.pack_ff(w1, b1, gamma, beta, w2, b2)
+    got = ops.rc_ff(h, s1, s2, bb2, inner, 1e-5, wpo=rc_pack_tiles(wp, bp.float()) if proj else None, res0=x0 if proj else None)
+    l2, mx = tols(dtype)
+    # three storage roundings on the way (normalised rows, hidden activations, h3 before proj_out): 1.5x the single-op tolerance
+    check(got, ref, f"rc_ff M{M} inner{inner} proj{proj} {dtype}", 1.5 * l2, 1.5 * mx)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_first_level_transformer_row_chain_on_vs_off(dtype, monkeypatch):
+    """Transformer2DModel of SD-1.5's first level (GroupNorm -> proj_in -> block -> proj_out + residual) with every row-chain launch ON
+    (rc_linear, rc_xattn, rc_ff incl. proj_out) vs OFF on the same weights / inputs; then modes one at a time."""
+    from theatergen_amd import rowchain
+    from theatergen_amd.attention_processor import IPAttnProcessor
+    from theatergen_amd.unet import Transformer2DModel, _Act
+    torch.manual_seed(5)
+    C, B, Hh, ctx = 320, 2, 64, 768
+    tf = Transformer2DModel(8, 40, C, 1, ctx, 32, False)
+    for prm in tf.parameters():
+        if prm.ndim == 1:
+            prm.data.normal_(0, 0.1)
+    for nrm in (tf.norm, tf.transformer_blocks[0].norm1, tf.transformer_blocks[0].norm2, tf.transformer_blocks[0].norm3):
+        nrm.weight.data.add_(1.0)
+    tf.transformer_blocks[0].attn2.set_processor(IPAttnProcessor(C, ctx, scale=0.4, num_tokens=4))
+    tf = tf.to(DEV, dtype)
+    x = _Act((torch.randn(B * Hh * Hh, C) * 1.1).to(DEV, dtype), B, Hh, Hh, C)
+    enc = (torch.randn(B, 81, ctx) * 0.5).to(DEV, dtype)
+    monkeypatch.setattr(rowchain, "ENABLED", False)
+    ref = tf.run(x, enc, {}).t
+    monkeypatch.setattr(rowchain, "ENABLED", True)
+    monkeypatch.setattr(rowchain, "MIN_ROWS", 1024)
+    l2, mx = tols(dtype)
+    for mode in (7, 1, 2, 4):
+        monkeypatch.setattr(rowchain, "MODE", mode)
+        got = tf.run(x, enc, {}).t
+        check(got, ref, f"first-level Transformer2DModel row-chain mode {mode} {dtype}", 2 * l2, 2 * mx)

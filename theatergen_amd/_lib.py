@@ -56,6 +56,13 @@ class RcXattnDesc(C.Structure):
     ]
 
 
+class RcFfDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("h", vp), ("ldh", i64), ("w1", vp), ("w2", vp), ("b2", vp), ("wpo", vp), ("res0", vp), ("ldres", i64),
+        ("out", vp), ("ldc", i64), ("M", i64), ("inner", i32), ("ln_eps", f32), ("dbg", i32),
+    ]
+
+
 class GuidanceItem(C.Structure):
     _fields_ = [
         ("attn", vp), ("grad", vp), ("mask", vp), ("ref", vp),
@@ -119,6 +126,7 @@ SIGNATURES = {
     "tg_rc_linear": (i32, [C.POINTER(RcLinearDesc), vp]),
     "tg_rc_xattn": (i32, [C.POINTER(RcXattnDesc), vp]),
     "tg_rc_kv_pack": (i32, [i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp]),
+    "tg_rc_ff": (i32, [C.POINTER(RcFfDesc), vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

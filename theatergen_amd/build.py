@@ -20,6 +20,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result"]
 
 
+# per-file flags: the row-chain kernels are ONE straight-line instruction stream per phase (60-MFMA software-pipelined loops with
+# compile-time register indices); `#pragma unroll` must not fall back to a partial unroll (register arrays would go to scratch)
+EXTRA_FLAGS = {"tg_rowchain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+
 BUILD_INFO = os.path.join(LIBDIR, "build_info.json")
 
 
@@ -52,6 +56,8 @@ def _digest(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    for p_ in paths:
+        h.update(" ".join(EXTRA_FLAGS.get(os.path.basename(p_), [])).encode())
     return h.hexdigest()
 
 
@@ -77,7 +83,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o, stamp, dg = job
-        cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -23,6 +23,9 @@
 // (models/attention.py:226-236, 337-338).
 #include "tg_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 struct RcLinearParams {
@@ -711,6 +714,403 @@ int dispatch_rc_xattn(const tg_rc_xattn_desc* d, const RcXattnParams& p, hipStre
   return launch_rc_xattn<T, 16>(d, p, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// rc_ff_kernel: norm3 + FeedForward (GEGLU) + residual, and optionally Transformer2DModel.proj_out + its residual, of a first-level block
+// in ONE launch (reference models/attention.py:226-236 `ff(norm3(x)) + x`, :328-338 GEGLU; models/transformer_2d.py:316-327 proj_out):
+//     h3 = net2( a * gelu(g) ) + b2 + h,   [a | g] = proj(LayerNorm(h)) + b1;        out = proj_out(h3) + b + res0
+// Today: layernorm (16 us) + 256 x 256 GEGLU GEMM (148 us at 65536 tokens: K = 320 is five K-tiles long) + net.2 GEMM (92 us) + proj_out
+// (27-39 us), and the [tokens, 1280] hidden tensor (168 MB) written and read back.  Here the hidden activations exist 32 channels at a
+// time, in the registers of the wave that owns the 32 tokens: per 32-channel SLICE j the wave runs 40 MFMAs of proj (value tile + gate tile
+// over the normalised rows), GEGLU on the 16 + 16 accumulator registers, and 20 MFMAs of net.2 (10 output tiles x 2 k-steps) into 160
+// accumulator registers that live for the whole kernel.  ONE wave per SIMD (the 160 + 64 accumulators, the rows and the normalised rows need
+// ~420 registers), so nothing else fills the matrix pipe while the wave does arithmetic: the stream is software-pipelined by hand —
+// iteration j issues, interleaved 2 : 1,  proj(j)'s 40 MFMAs and net.2(j - 2)'s 20 MFMAs, and between consecutive MFMAs one quarter of one
+// element of GEGLU(j - 1) (~6 VALU instructions = the issue slots one 32-cycle MFMA leaves free).
+// LDS: two 44-KiB proj slots + two 20-KiB net.2 slots (LDS-DMA, fetched one iteration ahead); the proj_out phase reuses them as three
+// 24-KiB tile stages.
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})  (asm immediates need constants)
+template <int... X, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, X...>, F&& f) {
+  (f(std::integral_constant<int, X>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+// fragment read / counted wait as asm: hipcc waits lgkmcnt(0) in front of most MFMAs of a long read-ahead stream (every such wait exposes a
+// full LDS round trip when ONE wave runs on the SIMD); the wait is tied to the fragment register so the MFMA cannot be moved above it
+template <int OFF, typename V8> __device__ __forceinline__ void lds_read16(V8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N, typename V8> __device__ __forceinline__ void lds_wait(V8& frag) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+
+struct RcFfParams {
+  const void* h;        // [M, 320] the stream before norm3 (= the residual)
+  long ldh;
+  const void* w1;       // rowchain.pack_ff: n_slices x 41 KiB (+ 3 KiB pad)
+  const void* w2;       // n_slices x 20 KiB
+  const float* b2;      // fp32 [320]
+  const void* wpo;      // proj_out as rc_pack_tiles stream, or NULL (then `out` = h3)
+  const void* res0;     // [M, 320] residual of proj_out
+  long ldres;
+  void* out;
+  long ldc;
+  long M;
+  int n_slices;         // inner / 32, even, >= 2
+  float ln_eps;
+  int dbg;              // dev timing switches: 1 no proj MFMAs, 2 no GEGLU arithmetic, 4 no net.2 MFMAs
+};
+
+template <typename T, bool PROJ, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rc_ff_kernel(RcFfParams p) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int KS = 20, NW = 4;
+  constexpr int W1B = 41 * 1024, W1SLOT = 44 * 1024, W2B = 20 * 1024;
+  constexpr int W2OFF = 2 * W1SLOT;
+  constexpr int TBW = (KS + 1) * 1024, SLOT = 24 * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lbid = rc_block_id((int)blockIdx.x, (int)gridDim.x);
+  const long tok0 = ((long)lbid * NW + wave) * 32;
+  const int qb = lane & 3;
+  long mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = tok0 + (l31 & ~3) + i;
+    mok[i] = r < p.M;
+    mrow[i] = mok[i] ? r : p.M - 1;
+  }
+  const int NS = p.n_slices;
+  const char* w1g = reinterpret_cast<const char*>(p.w1) + lane * 16 + wave * 1024;
+  const char* w2g = reinterpret_cast<const char*>(p.w2) + lane * 16 + wave * 1024;
+  auto issue_w1 = [&](int j) __attribute__((always_inline)) {      // slice j -> proj slot j & 1: 11 pieces per wave (41 KiB + 3 KiB of the next slice / the pad)
+    const char* s0 = w1g + (long)j * W1B;
+    char* dst = smem + (j & 1) * W1SLOT + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 11; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + q * NW * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + q * NW * 1024), 16, 0, 0);
+  };
+  auto issue_w2 = [&](int j) __attribute__((always_inline)) {      // slice j -> net.2 slot j & 1: 5 pieces per wave
+    const char* s0 = w2g + (long)j * W2B;
+    char* dst = smem + W2OFF + (j & 1) * W2B + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + q * NW * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + q * NW * 1024), 16, 0, 0);
+  };
+  issue_w1(0);
+
+  // rows -> B operands (H: as stored, the residual; HN: normalised, what norm3 hands to the feed-forward)
+  V8 H[KS], HN[KS];
+  {
+    const T* xp = reinterpret_cast<const T*>(p.h) + 32 * hi + 8 * qb;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) H[s] = *reinterpret_cast<const V8*>(xp + mrow[s & 3] * p.ldh + 64 * (s >> 2));
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) quad_transpose(H[4 * q], H[4 * q + 1], H[4 * q + 2], H[4 * q + 3]);
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += to_f32<T>(H[s][e]);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / 320.0f);
+    float c2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      asm volatile("" : "+v"(H[s]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = to_f32<T>(H[s][e]) - mean; c2 = __builtin_fmaf(d, d, c2); }
+    }
+    c2 += __shfl_xor(c2, 32, 64);
+    const float rstd = __builtin_amdgcn_rsqf(c2 * (1.0f / 320.0f) + p.ln_eps);
+    const float nm = -mean * rstd;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      asm volatile("" : "+v"(H[s]));
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf(to_f32<T>(H[s][e]), rstd, nm);
+      HN[s] = pack8<T>(f);
+    }
+  }
+  // net.2's accumulators for the whole kernel: tile t = 2 c + u, register rho <-> channel 64 c + 32 hi + 16 u + rho; seeded with b2
+  f32x16 out[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b2 + 64 * (t >> 1) + 32 * hi + 16 * (t & 1) + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[t][4 * g + e] = b4[e];
+    }
+
+  f32x16 acc_a[2], acc_g[2];
+  V8 hid[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hid[q][0][e] = from_f32<T>(0.f); hid[q][1][e] = from_f32<T>(0.f); }
+
+  // one pipeline iteration: proj(j) [F1], GEGLU(j - 1) [GG], net.2(j - 2) [F2]; PAR = j & 1 selects slots / accumulator sets
+  auto iteration = [&](int j, auto par_c, auto f1_c, auto gg_c, auto f2_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool F1 = decltype(f1_c)::value, GG = decltype(gg_c)::value, F2 = decltype(f2_c)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (j + 1 < NS && !(p.dbg & 8)) issue_w1(j + 1);
+    if (j >= 1 && j - 1 < NS && !(p.dbg & 8)) issue_w2(j - 1);
+    const char* w1b = smem + PAR * W1SLOT + lane * 16;
+    const char* w2b = smem + W2OFF + PAR * W2B + lane * 16;
+    if constexpr (F1) {
+      const float* page = reinterpret_cast<const float*>(smem + PAR * W1SLOT + 40 * 1024) + 16 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(page + 4 * g);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(page + 32 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc_a[PAR][4 * g + e] = a4[e]; acc_g[PAR][4 * g + e] = g4[e]; }
+      }
+    }
+    // slot x = 3 k + {0: value tile, 1: gate tile, 2: net.2 (tile k % 10, k-step k / 10)}; the fragment of slot x is read LA slots ahead of
+    // its MFMA (asm reads, counted waits: see lds_read16)
+    constexpr int LA = 9;
+    const unsigned lbase = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem);
+    const unsigned a1 = lbase + PAR * W1SLOT + lane * 16, a2 = lbase + W2OFF + PAR * W2B + lane * 16;
+    V8 fr[60];
+    auto rd = [&](auto xc) __attribute__((always_inline)) {
+      constexpr int x = decltype(xc)::value;
+      constexpr int k = x / 3, w = x % 3;
+      if constexpr (w == 0) { if constexpr (F1) lds_read16<k * 1024>(fr[x], a1); }
+      else if constexpr (w == 1) { if constexpr (F1) lds_read16<(20 + k) * 1024>(fr[x], a1); }
+      else { if constexpr (F2) lds_read16<((k % 10) * 2 + k / 10) * 1024>(fr[x], a2); }
+    };
+    static_for<LA>([&](auto xc) __attribute__((always_inline)) { rd(xc); });
+    // GEGLU micro-step state (one element in flight).  gelu(g) = g (0.5 + 0.5 erf(g / sqrt 2)) with erf(z) = z P(z^2) on |z| <= 3 (degree-7
+    // minimax fit in z^2, |error| <= 8.1e-5, clamped beyond: erf(3) = 1 - 2.2e-5): fourteen plain VALU instructions per element and no
+    // transcendental — the quarter-rate rcp + exp2 of the Abramowitz-Stegun form cost this single-wave stream more than their issue time
+    float ge_z = 0.f, ge_t = 0.f, ge_p = 0.f;
+    float hv[8];
+    auto geglu_micro = [&](int mstep) __attribute__((always_inline)) {
+      const int e = mstep >> 2, part = mstep & 3;
+      const float a = acc_a[PAR ^ 1][e], g = acc_g[PAR ^ 1][e];
+      if (part == 0) {
+        ge_z = __builtin_amdgcn_fmed3f(g * 0.70710678118654752440f, -3.0f, 3.0f);
+        ge_t = ge_z * ge_z;
+      } else if (part == 1) {
+        float q = __builtin_fmaf(-4.0553346e-07f, ge_t, 1.7159753e-05f);
+        q = __builtin_fmaf(q, ge_t, -3.1459445e-04f);
+        q = __builtin_fmaf(q, ge_t, 3.3187051e-03f);
+        ge_p = __builtin_fmaf(q, ge_t, -2.2685785e-02f);
+      } else if (part == 2) {
+        float q = __builtin_fmaf(ge_p, ge_t, 1.0771781e-01f);
+        q = __builtin_fmaf(q, ge_t, -3.7323141e-01f);
+        q = __builtin_fmaf(q, ge_t, 1.1278958f);
+        ge_p = q * ge_z;                                     // erf(g / sqrt 2)
+      } else {
+        hv[e & 7] = a * g * __builtin_fmaf(0.5f, ge_p, 0.5f);
+        if ((e & 7) == 7) hid[PAR ^ 1][e >> 3] = pack8<T>(hv);
+      }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<60>([&](auto xc) __attribute__((always_inline)) {
+      constexpr int x = decltype(xc)::value;
+      constexpr int k = x / 3, w = x % 3;
+      constexpr bool act = (w == 2) ? F2 : F1;
+      if constexpr (x + LA < 60) rd(std::integral_constant<int, (x + LA < 60 ? x + LA : 59)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (act) {
+        // reads issued after this slot's: the active slots in (x, min(59, x + LA)]
+        constexpr int hi_x = x + LA < 60 ? x + LA : 59;
+        constexpr int n_f1 = ((hi_x / 3) * 2 + (hi_x % 3 >= 1 ? (hi_x % 3 == 1 ? 2 : 2) : 1)) - ((x / 3) * 2 + (x % 3 >= 1 ? 2 : 1));
+        constexpr int n_f2 = (hi_x + 1) / 3 - (x + 1) / 3;
+        constexpr int younger = (F1 ? n_f1 : 0) + (F2 ? n_f2 : 0);
+        lds_wait<(younger > 15 ? 15 : younger)>(fr[x]);
+        if constexpr (w == 0) acc_a[PAR] = mfma32(fr[x], HN[k], acc_a[PAR]);
+        else if constexpr (w == 1) acc_g[PAR] = mfma32(fr[x], HN[k], acc_g[PAR]);
+        else out[k % 10] = mfma32(fr[x], hid[PAR][k / 10], out[k % 10]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (GG) {
+        // 64 micro-steps in 60 slots, ONE element in flight (the micro-step state is a handful of scalars): the last four slots take two
+        if constexpr (x < 56) geglu_micro(x);
+        else { geglu_micro(56 + 2 * (x - 56)); geglu_micro(57 + 2 * (x - 56)); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    // anchor: the hidden pieces are consumed one iteration later, in another basic block — without a use HERE the compiler sinks the whole
+    // GEGLU arithmetic of this iteration down to that block (one lump of ~700 VALU instructions with the matrix pipe idle)
+    if constexpr (GG) asm volatile("" :: "v"(hid[PAR ^ 1][0]), "v"(hid[PAR ^ 1][1]));
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+  iteration(0, C0{}, Tt{}, Ff{}, Ff{});
+  iteration(1, C1{}, Tt{}, Tt{}, Ff{});
+  // (DBG: dev timing instantiations with one part of the steady-state stream compiled out: 1 no proj MFMAs, 2 no GEGLU, 4 no net.2 MFMAs)
+  using D1 = std::integral_constant<bool, !(DBG & 1)>;
+  using D2 = std::integral_constant<bool, !(DBG & 2)>;
+  using D4 = std::integral_constant<bool, !(DBG & 4)>;
+  for (int j = 2; j < NS; j += 2) {
+    iteration(j, C0{}, D1{}, D2{}, D4{});
+    iteration(j + 1, C1{}, D1{}, D2{}, D4{});
+  }
+  iteration(NS, C0{}, Ff{}, Tt{}, Tt{});
+  iteration(NS + 1, C1{}, Ff{}, Ff{}, Tt{});
+
+  // h3 = net.2 + b2 + h: the rows are read again (L2 / Infinity Cache; keeping them would cost 80 of the 512 registers for the whole
+  // pipeline); their B layout IS the accumulator layout: piece 2 t + (rho >> 3), element rho & 7
+  {
+    const T* hb = reinterpret_cast<const T*>(p.h);
+    asm volatile("" : "+s"(hb));
+    const T* xp = hb + 32 * hi + 8 * qb;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      V8 hr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hr[i] = *reinterpret_cast<const V8*>(xp + mrow[i] * p.ldh + 64 * c);
+      quad_transpose(hr[0], hr[1], hr[2], hr[3]);
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[2 * c + uu][r] += to_f32<T>(hr[2 * uu + (r >> 3)][r & 7]);
+    }
+  }
+
+  T* outp = reinterpret_cast<T*>(p.out);
+  if constexpr (!PROJ) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      V8 pc[4] = {pack8r<T>(out[2 * c], 0), pack8r<T>(out[2 * c], 8), pack8r<T>(out[2 * c + 1], 0), pack8r<T>(out[2 * c + 1], 8)};
+      quad_transpose(pc[0], pc[1], pc[2], pc[3]);
+      const long ch0 = 64 * (long)c + 32 * hi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + ch0 + 8 * qb) = pc[i];
+    }
+  } else {
+    // proj_out over the rounded h3 rows: 10 tile stages of 24 KiB in a ring of three (the feed-forward slots are dead behind this barrier)
+    V8 HB[KS];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) { HB[2 * t] = pack8r<T>(out[t], 0); HB[2 * t + 1] = pack8r<T>(out[t], 8); }
+    const char* wpg = reinterpret_cast<const char*>(p.wpo) + lane * 16 + wave * 1024;
+    auto issue_po = [&](int st) __attribute__((always_inline)) {
+      if (st >= 10) return;
+      const char* s0 = wpg + (long)st * TBW;
+      char* dst = smem + (st % 3) * SLOT + wave * 1024;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + q * NW * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + q * NW * 1024), 16, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();
+    issue_po(0);
+    issue_po(1);
+    V8 pend[4], r8[4];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int st = 2 * c + uu;
+        // stage st landed when at most `younger` operations are outstanding (see rc_xattn_kernel)
+        const int younger = st == 0 ? 6 : st <= 2 ? 10 : st == 9 ? 8 : 14;
+        if (younger == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_po(st + 2);
+        if (uu == 0) {
+          const T* rp = reinterpret_cast<const T*>(p.res0);
+          T* op = outp;
+          asm volatile("" : "+s"(rp), "+s"(op));
+          const long ch0 = 64 * (long)c + 32 * hi;
+          if (c > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (mok[i]) *reinterpret_cast<V8*>(op + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb) = pend[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(rp + mrow[i] * p.ldres + ch0 + 8 * qb);
+        }
+        const char* cbase = smem + (st % 3) * SLOT;
+        const char* cb = cbase + lane * 16;
+        const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
+        constexpr int PD = 4;
+        V8 a[KS];
+#pragma unroll
+        for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(vec + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < KS; ++x) {
+          if (x + PD < KS) a[x + PD] = *reinterpret_cast<const V8*>(cb + (x + PD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma32(a[x], HB[x], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (uu == 0) quad_transpose(r8[0], r8[1], r8[2], r8[3]);
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = acc[r] + to_f32<T>(r8[2 * uu + (r >> 3)][r & 7]);
+        pend[2 * uu] = pack8<T>(o);
+        pend[2 * uu + 1] = pack8<T>(o + 8);
+        if (uu == 1) quad_transpose(pend[0], pend[1], pend[2], pend[3]);
+      }
+    }
+    {
+      const long ch0 = 64 * 4 + 32 * hi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + ch0 + 8 * qb) = pend[i];
+    }
+  }
+}
+
+template <typename T>
+int launch_rc_ff(const tg_rc_ff_desc* d, const RcFfParams& p, hipStream_t st) {
+  const size_t lds = 2 * 44 * 1024 + 2 * 20 * 1024;
+  const long grid = (d->M + 127) / 128;
+  if (std::is_same<T, bf16_t>::value && d->wpo != nullptr && (d->dbg & 7)) {
+    auto launch = [&](auto k) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+    };
+    switch (d->dbg & 7) {
+      case 1: launch(rc_ff_kernel<bf16_t, true, 1>); break;
+      case 2: launch(rc_ff_kernel<bf16_t, true, 2>); break;
+      case 4: launch(rc_ff_kernel<bf16_t, true, 4>); break;
+      case 3: launch(rc_ff_kernel<bf16_t, true, 3>); break;
+      case 6: launch(rc_ff_kernel<bf16_t, true, 6>); break;
+      default: launch(rc_ff_kernel<bf16_t, true, 7>); break;
+    }
+  } else if (d->wpo != nullptr) {
+    auto k = rc_ff_kernel<T, true>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+  } else {
+    auto k = rc_ff_kernel<T, false>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+  }
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
 template <typename T, int KS, int NW, int NBUF, int PD>
 int launch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipStream_t st) {
   const size_t lds = (size_t)NBUF * (2 * KS + 1) * 1024;
@@ -793,4 +1193,19 @@ extern "C" int tg_rc_kv_pack(int32_t dtype, int32_t batch, const void* k, const 
                        (const f16_t*)kip, (const f16_t*)vtip, (long)ldi, text_len, ip_tokens, (f16_t*)out);
   TG_LAUNCH_CHECK();
   return TG_OK;
+}
+
+extern "C" int tg_rc_ff(const tg_rc_ff_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_ff: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_ff: dtype %d", d->dtype);
+  TG_CHECK(d->h && d->w1 && d->w2 && d->b2 && d->out && d->M > 0, TG_ERR_ARG, "tg_rc_ff: null operand or M <= 0");
+  TG_CHECK(d->inner >= 64 && d->inner % 64 == 0, TG_ERR_ARG, "tg_rc_ff: inner = %d must be a multiple of 64", d->inner);
+  TG_CHECK(d->ldh >= 320 && d->ldh % 8 == 0 && d->ldc >= 320 && d->ldc % 8 == 0, TG_ERR_ARG, "tg_rc_ff: row pitches");
+  TG_CHECK(!d->wpo || (d->res0 && d->ldres >= 320 && d->ldres % 8 == 0), TG_ERR_ARG, "tg_rc_ff: proj_out needs its residual");
+  RcFfParams p;
+  p.h = d->h; p.ldh = d->ldh; p.w1 = d->w1; p.w2 = d->w2; p.b2 = d->b2; p.wpo = d->wpo; p.res0 = d->res0; p.ldres = d->ldres;
+  p.out = d->out; p.ldc = d->ldc; p.M = d->M; p.n_slices = d->inner / 32; p.ln_eps = d->ln_eps; p.dbg = d->dbg;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return launch_rc_ff<bf16_t>(d, p, st);
+  return launch_rc_ff<f16_t>(d, p, st);
 }

@@ -230,6 +230,25 @@ def rc_xattn(h, wq, kv, wo, rows_per_batch, ln_eps, ip_tokens, ip_scale=None, ou
     return out
 
 
+def rc_ff(h, w1, w2, b2, inner, ln_eps, wpo=None, res0=None, out=None, dbg=0):
+    """norm3 + GEGLU feed-forward + residual (+ proj_out + its residual) in one launch; see tg_rc_ff"""
+    from ._lib import RcFfDesc
+    _need_cuda(h)
+    M, Cc = h.shape
+    assert Cc == 320 and h.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, 320, dtype=h.dtype, device=h.device)
+    d = RcFfDesc()
+    d.dtype = _dt(h)
+    d.h, d.ldh = _ptr(h), int(h.stride(0))
+    d.w1, d.w2, d.b2, d.wpo = _ptr(w1), _ptr(w2), _ptr(b2), _ptr(wpo)
+    d.res0, d.ldres = (_ptr(res0), int(res0.stride(0))) if res0 is not None else (None, 0)
+    d.out, d.ldc = _ptr(out), int(out.stride(0))
+    d.M, d.inner, d.ln_eps, d.dbg = int(M), int(inner), float(ln_eps), int(dbg)
+    _lib.check(_lib.lib().tg_rc_ff(C.byref(d), _stream()))
+    return out
+
+
 def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, pad_mode=0, **kw):
     """3x3 pad-1 convolution as implicit GEMM over token-major x [batch*in_h*in_w, cin] (+ optional concat x1).
     w_packed: [cout, 9*(cin+c1)] tap-major.  ``pad_mode=1``: zero padding on the bottom / right edge only (the VAE

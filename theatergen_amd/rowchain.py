@@ -14,7 +14,7 @@ from .weights_pack import rc_pack, rc_pack_tiles
 # TG_RC: 0 = the row-chain kernels are never selected (old-path A/B), 1 = default.  TG_RC_MIN_ROWS: below this many token rows the
 # LDS-tiled GEMMs / the three-launch cross-attention stay (a row-chain workgroup is a long serial chain: it needs a full chip of them)
 ENABLED = os.environ.get("TG_RC", "1") != "0"
-MODE = int(os.environ.get("TG_RC_MODE", "3"))      # dev A/B: bit 0 = tg_rc_linear swaps, bit 1 = tg_rc_xattn
+MODE = int(os.environ.get("TG_RC_MODE", "7"))      # dev A/B: bit 0 = tg_rc_linear swaps, bit 1 = tg_rc_xattn, bit 2 = tg_rc_ff
 MIN_ROWS = int(os.environ.get("TG_RC_MIN_ROWS", "8192"))
 TRACE = os.environ.get("TG_RC_TRACE") == "1"
 
@@ -116,3 +116,56 @@ def xattn_eligible(attn, C, B, N, L, T, dtype):
     inner = attn.to_q.weight.shape[0]
     return (ENABLED and (MODE & 2) and C == 320 and inner == 320 and int(attn.heads) == 8 and L == 77 and T in (0, 4, 16) and N % 128 == 0
             and B * N >= MIN_ROWS and dtype in (torch.bfloat16, torch.float16) and attn.to_out[0].weight.shape[0] == 320)
+
+
+# ---- tg_rc_ff: norm3 + FeedForward (GEGLU) + residual (+ proj_out + residual) of a first-level block in one launch --------------------
+def _ff_row_of():
+    """MFMA row r of an FF1 tile -> offset of its hidden channel inside the 32-channel slice: accumulator register rho of lane half hi
+    (row = (rho & 3) + 8 (rho >> 2) + 4 hi) holds hidden channel 16 hi + rho"""
+    r = torch.arange(32)
+    rho = (r & 3) + 4 * (r >> 3)
+    hi = (r >> 2) & 1
+    return 16 * hi + rho
+
+
+def pack_ff(w1, b1, gamma, beta, w2, b2):
+    """``GEGLU.proj`` [2 * inner, 320] (+ bias) behind LayerNorm(gamma, beta) and ``net.2`` [320, inner] (+ bias) -> the streams of
+    ``tg_rc_ff`` (reference models/attention.py:226-236, 328-338; inner = 1280):
+      * w1 stream: per 32-channel hidden slice j: 20 fragment blocks of the VALUE rows, 20 of the GATE rows (K order = the row layout of
+        ``rc_pack``), then one 1-KiB page: fp32 bias_a[32], bias_g[32] in accumulator order, W * gamma folded, bias + W beta folded;
+        the kernel normalises the rows itself ((x - mean) * rstd rounded to the storage dtype: what ``norm3`` hands to ``ff``), 3 KiB pad;
+      * w2 stream: per slice j: 10 output tiles x 2 k-steps of ``net.2`` columns [32 j, 32 j + 32) (20 KiB);
+      * b2: fp32 [320]."""
+    from .weights_pack import _rc_maps
+    inner = w2.shape[1]
+    assert w1.shape == (2 * inner, C) and w2.shape == (C, inner) and inner % 32 == 0
+    dev, dt = w1.device, w1.dtype
+    g32, be32 = gamma.detach().float(), beta.detach().float()
+    w1f = w1.detach().float()
+    w1g = (w1f * g32[None, :]).to(dt)                                   # rounded once, like pack_ln_linear
+    v1 = w1f @ be32 + (b1.detach().float() if b1 is not None else 0.0)   # [2 * inner]
+    pi, kap = _rc_maps(C)
+    kap = kap.to(dev)                                                   # [s, hi, j] -> input channel
+    rowoff = _ff_row_of().to(dev)                                       # [r] -> hidden offset in the slice
+    ns = inner // 32
+    hid = 32 * torch.arange(ns, device=dev)[:, None] + rowoff[None, :]  # [slice, r]
+    rows_a, rows_g = hid, inner + hid
+    # frag[slice, which(a / g), s, hi, r, j] = w1g[row(slice, which, r), kap[s, hi, j]]
+    rows = torch.stack([rows_a, rows_g], dim=1)                          # [slice, 2, r]
+    frag = w1g[rows[:, :, None, None, :, None], kap[None, None, :, :, None, :]].contiguous()
+    fb = frag.reshape(ns, -1).view(torch.uint8)                          # [slice, 40 KiB]
+    page = torch.zeros(ns, 256, dtype=torch.float32, device=dev)
+    acc_ch = (16 * torch.arange(2, device=dev)[:, None] + torch.arange(16, device=dev)[None, :]).reshape(-1)   # index 16 hi + rho -> hidden offset
+    page[:, :32] = v1[(32 * torch.arange(ns, device=dev)[:, None] + acc_ch[None, :])]
+    page[:, 32:64] = v1[inner + (32 * torch.arange(ns, device=dev)[:, None] + acc_ch[None, :])]
+    s1 = torch.cat([fb, page.view(torch.uint8)], dim=1).reshape(-1)
+    s1 = torch.cat([s1, torch.zeros(3 * 1024, dtype=torch.uint8, device=dev)])
+    # w2: block (slice, t = 2 c + u, kk): lane (hi, r), element j = w2[64 c + pi(u, r), 32 slice + 16 hi + 8 kk + j]
+    out_rows = (64 * torch.arange(C // 64)[:, None, None] + pi[None]).reshape(-1, 32).to(dev)      # [t, r]
+    kcol = (32 * torch.arange(ns, device=dev)[:, None, None, None] + 16 * torch.arange(2, device=dev)[None, None, :, None]
+            + 8 * torch.arange(2, device=dev)[None, :, None, None] + torch.arange(8, device=dev)[None, None, None, :])   # [slice, kk, hi, j]
+    w2d = w2.detach()
+    f2 = w2d[out_rows[None, :, None, None, :, None], kcol[:, None, :, :, None, :]].contiguous()    # [slice, t, kk, hi, r, j]
+    s2 = f2.reshape(-1).view(torch.uint8)
+    bb2 = (b2.detach().float() if b2 is not None else torch.zeros(C, device=dev)).contiguous()
+    return s1.contiguous(), s2.contiguous(), bb2

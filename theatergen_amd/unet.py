@@ -30,7 +30,7 @@ from . import ops
 from . import rowchain
 from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, fused_cross_block
 from .config import UNetConfig
-from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear
+from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear, rc_pack_tiles
 
 
 class DeviceSchedule:
@@ -178,6 +178,25 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
         self._p = _Packed()
 
+    def run_fused(self, x2d, norm, tail=None):
+        """norm3 + GEGLU feed-forward + residual — and with ``tail`` = (packed proj_out weight [C, C], bias, its residual) also
+        ``Transformer2DModel.proj_out`` + residual — as ONE row-chain launch (``tg_rc_ff``; first level of SD-1.5: 320 channels).
+        ``x2d`` is the un-normalised stream.  Returns None when the shape is not eligible."""
+        proj, lin2 = self.net[0].proj, self.net[2]
+        M, K = x2d.shape
+        inner = lin2.weight.shape[1]
+        if (not rowchain.ENABLED or not (rowchain.MODE & 4) or K != 320 or lin2.weight.shape[0] != 320 or inner % 64 or M < rowchain.MIN_ROWS
+                or x2d.stride(0) != K or proj.weight.shape[0] != 2 * inner):
+            return None
+        ts = [proj.weight, proj.bias, norm.weight, norm.bias, lin2.weight] + ([lin2.bias] if lin2.bias is not None else [])
+        s1, s2, b2 = self._p.get("rc_ff", ts, lambda: rowchain.pack_ff(proj.weight, proj.bias, norm.weight, norm.bias, lin2.weight, lin2.bias))
+        wpo = res0 = None
+        if tail is not None:
+            w_out, b_out, res0 = tail
+            wpo = self._p.get("rc_po", [w_out] + ([b_out] if b_out is not None else []),
+                              lambda: rc_pack_tiles(w_out.detach(), b_out.detach().float() if b_out is not None else None))
+        return ops.rc_ff(x2d, s1, s2, b2, inner, norm.eps, wpo=wpo, res0=res0)
+
     def run(self, x2d, residual, ln=None):
         """``ln`` = (nn.LayerNorm, row statistics or None): ``x2d`` is the un-normalised stream and the norm is folded into the GEGLU GEMM"""
         proj = self.net[0].proj
@@ -233,7 +252,9 @@ class BasicTransformerBlock(nn.Module):
             out = out[0]
         return ops.add(out.reshape(b * n, -1).contiguous(), residual)
 
-    def run(self, x2d, b, n, enc, ca_kwargs):
+    def run(self, x2d, b, n, enc, ca_kwargs, tail=None):
+        """``tail`` (optional, from ``Transformer2DModel``: (packed proj_out weight, bias, residual)) — when the fused feed-forward launch
+        takes it, the block returns ``(proj_out output, True)``; otherwise a plain tensor (the caller runs proj_out itself)."""
         M, C = x2d.shape
         if _LN_MODE and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
             # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor.  Row statistics: a
@@ -250,6 +271,9 @@ class BasicTransformerBlock(nn.Module):
                 x2d = self._call(self.attn1, h, b, n, None, x2d, ca_kwargs)
                 h = ops.layernorm(x2d, self.norm2.weight, self.norm2.bias, self.norm2.eps)
                 x2d = self._call(self.attn2, h, b, n, enc, x2d, ca_kwargs)
+            fused = self.ff.run_fused(x2d, self.norm3, tail)
+            if fused is not None:
+                return (fused, True) if tail is not None else fused
             if _LN_MODE & 2:
                 return self.ff.run(x2d, x2d, ln=folded(self.norm3, x2d))
             h = ops.layernorm(x2d, self.norm3.weight, self.norm3.bias, self.norm3.eps)
@@ -293,11 +317,14 @@ class Transformer2DModel(nn.Module):
         y_in = rowchain.linear320(y, w_in, self.proj_in.bias, None, self, "proj_in", _cached)
         y = y_in if y_in is not None else ops.linear(y, w_in, self.proj_in.bias)
         base_key = list(ca_kwargs.get("attn_key", [])) if "attn_key" in ca_kwargs else None
+        w_out = self._w("out", self.proj_out)
+        last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             if base_key is not None:
                 ca_kwargs["attn_key"] = base_key + [i]           # transformer_2d.py:299-304
-            y = blk.run(y, x.b, x.hw, enc, ca_kwargs)
-        w_out = self._w("out", self.proj_out)
+            y = blk.run(y, x.b, x.hw, enc, ca_kwargs, tail=(w_out, self.proj_out.bias, x.t) if i == last else None)
+            if isinstance(y, tuple):                             # the last block's fused feed-forward launch ran proj_out + residual too
+                return _Act(y[0], x.b, x.h, x.w, x.c)
         out = rowchain.linear320(y, w_out, self.proj_out.bias, x.t, self, "proj_out", _cached)
         if out is None:
             out = ops.linear(y, w_out, self.proj_out.bias, res=x.t)
