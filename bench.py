@@ -183,6 +183,8 @@ def roofline_leg(unet, engine):
     # algorithmic bytes per launch: operands once + result once + the residual tensor where the layer adds one; a 3x3 conv reads its
     # input ONCE (M x C, not the M x 9C of the implicit GEMM); the fused GEGLU writes N / 2 columns; attention reads Q, K, V and writes O
     def alg_bytes(r):
+        if "alg_bytes" in r:                                   # row-chain launches state theirs (several layers per launch)
+            return r["alg_bytes"]
         if r.get("attention"):
             return 2.0 * (2 * r["M"] * r["N"] + 2 * r["batch"] * r["K"] * r["N"])          # Q + O, K + V (once per batch item)
         a_elems = r["M"] * (r["K"] // 9 if "conv" in r["kernel"] else r["K"])
@@ -210,7 +212,7 @@ def roofline_leg(unet, engine):
             "flop_per_launch_avg": top["flops"] / top["launches"],
             "by_template": families,
             "all_timed_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
-                                  "flop_per_cfg_call": tot_fl, "launches": len(recs), "includes": "GEMM / conv / attention launches"},
+                                  "flop_per_cfg_call": tot_fl, "launches": len(recs), "includes": "GEMM / conv / attention / row-chain launches"},
             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                           for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
 

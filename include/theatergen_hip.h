@@ -439,6 +439,26 @@ typedef struct {
 } tg_rc_ff_desc;
 int tg_rc_ff(const tg_rc_ff_desc* d, void* stream);
 
+/* tg_rc_front: the front of a first-level Transformer2DModel in one launch (models/transformer_2d.py:285-296; models/attention.py:186-204):
+ *     y = proj_in(GroupNorm(x)) + b;   [Q | K | V] = [to_q ; to_k ; to_v](LayerNorm1(y))
+ * `coef`: tg_groupnorm_coef output fp32 [batch][2][320]; `win`: rc_pack_tiles(proj_in, bias); `wqkv`: rc_pack_tiles of the LayerNorm-folded
+ * q ; k ; v rows (pack_ln_linear: W', v, u).  Outputs: y [M, 320], Q | K token-major [M, 640] (row pitch ldqk), V transposed per batch item
+ * vt[b, c, token] (row pitch ldt) — the operands tg_attention takes. */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  const float* coef;
+  const void* win;
+  const void* wqkv;
+  void* y; int64_t ldy;
+  void* qk; int64_t ldqk;
+  void* vt; int64_t ldt;
+  int64_t M;
+  int32_t rows_per_batch;
+  float ln_eps;
+} tg_rc_front_desc;
+int tg_rc_front(const tg_rc_front_desc* d, void* stream);
+
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);
 

@@ -70,7 +70,7 @@ def case(M, N, K, res, ln, dtype, variants, out):
 
 
 if __name__ == "__main__":
-    variants = [0, 1, 2, 3, 5]
+    variants = [0, 1, 2, 3]
     res = []
     bf = torch.bfloat16
     case(65536, 320, 320, True, False, bf, variants, res)

@@ -63,6 +63,13 @@ class RcFfDesc(C.Structure):
     ]
 
 
+class RcFrontDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("x", vp), ("ldx", i64), ("coef", vp), ("win", vp), ("wqkv", vp), ("y", vp), ("ldy", i64), ("qk", vp), ("ldqk", i64),
+        ("vt", vp), ("ldt", i64), ("M", i64), ("rows_per_batch", i32), ("ln_eps", f32),
+    ]
+
+
 class GuidanceItem(C.Structure):
     _fields_ = [
         ("attn", vp), ("grad", vp), ("mask", vp), ("ref", vp),
@@ -127,6 +134,7 @@ SIGNATURES = {
     "tg_rc_xattn": (i32, [C.POINTER(RcXattnDesc), vp]),
     "tg_rc_kv_pack": (i32, [i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp]),
     "tg_rc_ff": (i32, [C.POINTER(RcFfDesc), vp]),
+    "tg_rc_front": (i32, [C.POINTER(RcFrontDesc), vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

@@ -321,6 +321,27 @@ def _save_probs(attn, q, q_ld, k, k_ld, B, N, L, save_attn_to_dict, save_keys, a
     return probs
 
 
+def front_eligible(attn, kwargs):
+    """attn1 of a first-level block can take its Q | K | V^T from ``tg_rc_front`` (plain self-attention through our AttnProcessor)"""
+    if type(attn.processor) is not AttnProcessor or kwargs.get("attention_mask") is not None or kwargs.get("attn_process_fn") is not None:
+        return False
+    if getattr(attn, "group_norm", None) is not None or getattr(attn, "spatial_norm", None) is not None:
+        return False
+    if attn.rescale_output_factor != 1.0 or attn.residual_connection or kwargs.get("return_attntion_probs"):
+        return False
+    inner, heads, d = attn_dims(attn)
+    return inner == 320 and attn.to_q.weight.shape[1] == 320
+
+
+def self_attention_from_qkv(attn, qk, vt, ldt, B, N, residual):
+    """attn1 with its projections already computed (``tg_rc_front``): flash attention over Q | K [B*N, 2 * inner] / V^T + to_out + residual"""
+    inner, heads, d = attn_dims(attn)
+    o = torch.empty((B * N, inner), dtype=qk.dtype, device=qk.device)
+    ops.attention(qk, 2 * inner, N * 2 * inner, qk[:, inner:], 2 * inner, N * 2 * inner, vt, ldt, inner * ldt, N,
+                  B, heads, d, N, attn.scale, o, inner, N * inner)
+    return _finish(attn, o, B, N, inner, None, None, residual).reshape(B * N, -1)
+
+
 def fused_cross_block(attn, norm, x2d, B, N, enc, kwargs):
     """norm2 + attn2 + residual of a first-level ``BasicTransformerBlock`` in ONE launch (``tg_rc_xattn``): returns the new stream
     [B*N, 320], or None when the block is not eligible (other geometry, a foreign processor, attention-map capture, masks, ...) and the

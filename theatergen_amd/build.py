@@ -129,6 +129,10 @@ HOT_GATES = [
     ("conv_slab_kernel<", 320, 256),
     ("bt_gemm_kernel<", 132, 256),
     ("lc_gemm_kernel<", 100, 256),
+    # row-chain kernels (round 4): straight-line register-array code — any scratch means an array fell out of the registers
+    ("rc_xattn_kernel<", 0, 256),
+    ("rc_ff_kernel<", 0, 256),
+    ("rc_linear_kernel<bf16,20,8,2,false,0>", 0, 256),             # the instance the UNet launches (plain / + residual)
 ]
 
 

@@ -729,6 +729,241 @@ int dispatch_rc_xattn(const tg_rc_xattn_desc* d, const RcXattnParams& p, hipStre
 // element of GEGLU(j - 1) (~6 VALU instructions = the issue slots one 32-cycle MFMA leaves free).
 // LDS: two 44-KiB proj slots + two 20-KiB net.2 slots (LDS-DMA, fetched one iteration ahead); the proj_out phase reuses them as three
 // 24-KiB tile stages.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// rc_front_kernel: the FRONT of a first-level Transformer2DModel in one launch (SD-1.5 geometry, 320 channels):
+//     y = proj_in(GroupNorm(x)) + b;      [Q | K | V] = to_qkv(LayerNorm1(y))      (Q | K token-major [M, 640], V TRANSPOSED per batch item)
+// (models/transformer_2d.py:285-296 norm + proj_in; models/attention.py:186-204 norm1 + attn1's projections; today: GroupNorm apply pass,
+// proj_in launch, LayerNorm-folded q|k|v GEMM with its V^T epilogue).  GroupNorm arrives as per-(image, channel) coefficients (a, d) from
+// tg_groupnorm_coef — the statistics pass stays a launch, the normalised tensor never exists: x * a + d is applied to the row registers
+// (fp32, one rounding: what the apply pass stores).  40 weight tiles through the 3 x 24-KiB ring: 10 of proj_in, 30 of the LayerNorm-folded
+// q|k|v; y, Q | K leave through quad-transposed 128-byte-line stores (deferred by one stage), V^T through 2-byte stores (lane = token is the
+// contiguous direction of V^T: 64 bytes per channel and wave).
+struct RcFrontParams {
+  const void* x;          // [M, 320] block input (token-major)
+  long ldx;
+  const float* coef;      // fp32 [batch][2][320]: a, d of tg_groupnorm_coef
+  const void* win;        // proj_in: rc_pack_tiles stream (10 tiles)
+  const void* wqkv;       // LayerNorm-folded to_q ; to_k ; to_v: rc_pack_tiles stream (30 tiles, v / u pages)
+  void* y;                // [M, 320]
+  long ldy;
+  void* qk;               // [M, 640]
+  long ldqk;
+  void* vt;               // [batch, 320, ldt]
+  long ldt;
+  long M;
+  int rows_per_batch;
+  float ln_eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rc_front_kernel(RcFrontParams p) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int KS = 20, NW = 4, NST = 40;
+  constexpr int TBW = (KS + 1) * 1024, SLOT = 24 * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lbid = rc_block_id((int)blockIdx.x, (int)gridDim.x);
+  const long tok0 = ((long)lbid * NW + wave) * 32;
+  const int qb = lane & 3;
+  long mrow[4];
+  bool mok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = tok0 + (l31 & ~3) + i;
+    mok[i] = r < p.M;
+    mrow[i] = mok[i] ? r : p.M - 1;
+  }
+  const long bi = ((long)lbid * NW * 32) / p.rows_per_batch;            // the workgroup's batch item (uniform)
+  auto issue_stage = [&](int st) __attribute__((always_inline)) {
+    if (st >= NST) return;
+    const char* src = (st < 10 ? reinterpret_cast<const char*>(p.win) + (long)st * TBW
+                               : reinterpret_cast<const char*>(p.wqkv) + (long)(st - 10) * TBW) + lane * 16 + wave * 1024;
+    char* dst = smem + (st % 3) * SLOT + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * NW * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
+  };
+  issue_stage(0);
+  issue_stage(1);
+
+  // rows -> registers, GroupNorm applied in place (fp32 x * a + d, one rounding), B-operand layout
+  V8 X[KS];
+  {
+    const T* xp = reinterpret_cast<const T*>(p.x) + 32 * hi + 8 * qb;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) X[s] = *reinterpret_cast<const V8*>(xp + mrow[s & 3] * p.ldx + 64 * (s >> 2));
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) quad_transpose(X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
+    // the batch item's 2 x 320 coefficients through LDS (behind the ring): one coalesced 2.5-KiB load per workgroup, broadcast reads
+    float* cl = reinterpret_cast<float*>(smem + 3 * SLOT);
+    if (tid < 160) *reinterpret_cast<f32x4*>(cl + 4 * tid) = *reinterpret_cast<const f32x4*>(p.coef + bi * 640 + 4 * tid);
+    __syncthreads();
+    const float* ca = cl + 32 * hi;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float* c0 = ca + 64 * (s >> 2) + 8 * (s & 3);
+      float f[8];
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(c0 + 4 * h4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(c0 + 320 + 4 * h4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[4 * h4 + e] = __builtin_fmaf(to_f32<T>(X[s][4 * h4 + e]), a4[e], d4[e]);
+      }
+      X[s] = pack8<T>(f);
+    }
+  }
+
+  float ln_rstd = 1.f, ln_std = 1.f, ln_nmean = 0.f;
+  // stores produced by stage k (issued at the top of stage k + 1): a finished 64-channel chunk = 4 x 16 bytes, a V tile = 16 x 2 bytes
+  auto n_stores = [](int k) { return k < 0 ? 0 : k < 30 ? ((k & 1) ? 4 : 0) : k < NST ? 16 : 0; };
+  V8 pend[4];
+  auto flush = [&](int k) __attribute__((always_inline)) {      // the stores of stage k
+    if (k < 0 || n_stores(k) == 0) return;
+    if (k < 30) {
+      T* base = reinterpret_cast<T*>(k < 10 ? p.y : p.qk);
+      asm volatile("" : "+s"(base));
+      const long ld = k < 10 ? p.ldy : p.ldqk;
+      const long ch0 = 64 * (long)((k < 10 ? k : k - 10) >> 1) + 32 * hi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (mok[i]) *reinterpret_cast<V8*>(base + mrow[i] * ld + ch0 + 8 * qb) = pend[i];
+    } else {
+      // V tile t = k - 30 (chunk c = t >> 1, tile u = t & 1): register rho = channel 64 c + 32 hi + 16 u + rho, lane = token
+      T* vb = reinterpret_cast<T*>(p.vt);
+      asm volatile("" : "+s"(vb));
+      const int t = k - 30;
+      const long tok = tok0 + l31;
+      const long tin = tok - bi * p.rows_per_batch;
+      T* vrow = vb + (bi * 320 + 64 * (t >> 1) + 32 * hi + 16 * (t & 1)) * p.ldt + tin;
+      if (tok < p.M) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vrow[(long)r * p.ldt] = pend[r >> 3][r & 7];
+      }
+    }
+  };
+  auto stage_begin = [&](int st) __attribute__((always_inline)) {
+    const int younger = n_stores(st - 3) + (st + 1 < NST ? 6 : 0) + n_stores(st - 2);
+    switch (younger) {
+      case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+      case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+      case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+      case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    issue_stage(st + 2);
+    flush(st - 1);
+  };
+  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold) __attribute__((always_inline)) -> f32x16 {
+    constexpr int PD = 4;
+    const char* cb = cbase + lane * 16;
+    const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
+    V8 a[KS];
+#pragma unroll
+    for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(vec + 4 * g);
+      if (fold) {
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(vec + 32 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = __builtin_fmaf(ln_nmean, u4[e], ln_std * v4[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < KS; ++x) {
+      if (x + PD < KS) a[x + PD] = *reinterpret_cast<const V8*>(cb + (x + PD) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma32(a[x], Bop[x], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+  };
+
+  // ---- proj_in: Y = B operands of the q|k|v phase, and the stream the block's residual adds read back
+  V8 Y[KS];
+  V8 half[2];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    stage_begin(t);
+    const f32x16 acc = tile_stream(smem + (t % 3) * SLOT, X, false);
+    Y[2 * t] = pack8r<T>(acc, 0);
+    Y[2 * t + 1] = pack8r<T>(acc, 8);
+    if (t & 1) {
+      pend[0] = Y[2 * t - 2]; pend[1] = Y[2 * t - 1]; pend[2] = Y[2 * t]; pend[3] = Y[2 * t + 1];
+      quad_transpose(pend[0], pend[1], pend[2], pend[3]);
+    }
+  }
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += to_f32<T>(Y[s][e]);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / 320.0f);
+    float c2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      asm volatile("" : "+v"(Y[s]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = to_f32<T>(Y[s][e]) - mean; c2 = __builtin_fmaf(d, d, c2); }
+    }
+    c2 += __shfl_xor(c2, 32, 64);
+    const float var = c2 * (1.0f / 320.0f) + p.ln_eps;
+    ln_rstd = __builtin_amdgcn_rsqf(var);
+    ln_std = var * ln_rstd;
+    ln_nmean = -mean;
+  }
+  // ---- q | k | v (LayerNorm folded)
+#pragma unroll
+  for (int t = 0; t < 30; ++t) {
+    stage_begin(10 + t);
+    f32x16 acc = tile_stream(smem + ((10 + t) % 3) * SLOT, Y, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
+    if (t < 20) {
+      if (t & 1) {
+        pend[0] = half[0]; pend[1] = half[1]; pend[2] = pack8r<T>(acc, 0); pend[3] = pack8r<T>(acc, 8);
+        quad_transpose(pend[0], pend[1], pend[2], pend[3]);
+      } else {
+        half[0] = pack8r<T>(acc, 0); half[1] = pack8r<T>(acc, 8);
+      }
+    } else {
+      pend[0] = pack8r<T>(acc, 0); pend[1] = pack8r<T>(acc, 8);
+    }
+  }
+  flush(NST - 1);
+}
+
+template <typename T>
+int launch_rc_front(const tg_rc_front_desc* d, const RcFrontParams& p, hipStream_t st) {
+  const size_t lds = 3 * 24 * 1024 + 2560;
+  const long grid = (d->M + 127) / 128;
+  auto k = rc_front_kernel<T>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})  (asm immediates need constants)
 template <int... X, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, X...>, F&& f) {
   (f(std::integral_constant<int, X>{}), ...);
@@ -1083,20 +1318,9 @@ template <typename T>
 int launch_rc_ff(const tg_rc_ff_desc* d, const RcFfParams& p, hipStream_t st) {
   const size_t lds = 2 * 44 * 1024 + 2 * 20 * 1024;
   const long grid = (d->M + 127) / 128;
-  if (std::is_same<T, bf16_t>::value && d->wpo != nullptr && (d->dbg & 7)) {
-    auto launch = [&](auto k) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
-    };
-    switch (d->dbg & 7) {
-      case 1: launch(rc_ff_kernel<bf16_t, true, 1>); break;
-      case 2: launch(rc_ff_kernel<bf16_t, true, 2>); break;
-      case 4: launch(rc_ff_kernel<bf16_t, true, 4>); break;
-      case 3: launch(rc_ff_kernel<bf16_t, true, 3>); break;
-      case 6: launch(rc_ff_kernel<bf16_t, true, 6>); break;
-      default: launch(rc_ff_kernel<bf16_t, true, 7>); break;
-    }
-  } else if (d->wpo != nullptr) {
+  // (the DBG instantiations of rc_ff_kernel — parts of the steady-state stream compiled out — were dev timing aids: numbers in
+  // profiles/r4_rowchain_findings.md)
+  if (d->wpo != nullptr) {
     auto k = rc_ff_kernel<T, true>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
@@ -1136,8 +1360,6 @@ int dispatch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipS
     case 1: return launch_rc_linear<T, 20, 8, 2, 4>(d, p, st);       // pinned fragment read-ahead of 4 k-steps
     case 2: return launch_rc_linear<T, 20, 8, 3, 0>(d, p, st);       // three chunk buffers
     case 3: return launch_rc_linear<T, 20, 8, 3, 4>(d, p, st);
-    case 4: return launch_rc_linear<T, 20, 12, 3, 4>(d, p, st);      // 12 waves (three per SIMD)
-    case 5: return launch_rc_linear<T, 20, 4, 3, 4>(d, p, st);       // 4-wave workgroups
     default: return launch_rc_linear<T, 20, 8, 2, 0>(d, p, st);      // one 8-wave workgroup per CU, the compiler's schedule
   }
 }
@@ -1208,4 +1430,20 @@ extern "C" int tg_rc_ff(const tg_rc_ff_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return launch_rc_ff<bf16_t>(d, p, st);
   return launch_rc_ff<f16_t>(d, p, st);
+}
+
+extern "C" int tg_rc_front(const tg_rc_front_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_front: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_front: dtype %d", d->dtype);
+  TG_CHECK(d->x && d->coef && d->win && d->wqkv && d->y && d->qk && d->vt && d->M > 0, TG_ERR_ARG, "tg_rc_front: null operand or M <= 0");
+  TG_CHECK(d->rows_per_batch > 0 && d->rows_per_batch % 128 == 0 && d->M % d->rows_per_batch == 0, TG_ERR_ARG,
+           "tg_rc_front: rows_per_batch = %d must be a multiple of 128 that divides M", d->rows_per_batch);
+  TG_CHECK(d->ldx >= 320 && d->ldx % 8 == 0 && d->ldy >= 320 && d->ldy % 8 == 0 && d->ldqk >= 640 && d->ldqk % 8 == 0 && d->ldt >= d->rows_per_batch,
+           TG_ERR_ARG, "tg_rc_front: row pitches");
+  RcFrontParams p;
+  p.x = d->x; p.ldx = d->ldx; p.coef = d->coef; p.win = d->win; p.wqkv = d->wqkv; p.y = d->y; p.ldy = d->ldy; p.qk = d->qk; p.ldqk = d->ldqk;
+  p.vt = d->vt; p.ldt = d->ldt; p.M = d->M; p.rows_per_batch = d->rows_per_batch; p.ln_eps = d->ln_eps;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return launch_rc_front<bf16_t>(d, p, st);
+  return launch_rc_front<f16_t>(d, p, st);
 }

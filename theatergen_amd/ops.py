@@ -154,6 +154,19 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
 _gemm_profile = None
 
 
+def _profiled(launch, kernel, M, N, K, flops, has_res=False, alg_bytes=None):
+    """run ``launch()``; in profiling mode (bench.py roofline leg) bracket it with HIP events on the launch stream and record it"""
+    if _gemm_profile is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    _gemm_profile.append(dict(kernel=kernel, splits=1, M=int(M), N=int(N), K=int(K), flops=float(flops), events=(e0, e1),
+                              has_res=bool(has_res), n_out=int(N), **({"alg_bytes": float(alg_bytes)} if alg_bytes is not None else {})))
+
+
 def gemm_profile_start():
     global _gemm_profile
     _gemm_profile = []
@@ -194,7 +207,8 @@ def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0):
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.ln, d.ln_eps = (1, float(ln_eps)) if ln_eps is not None else (0, 0.0)
     d.variant = int(variant)
-    _lib.check(_lib.lib().tg_rc_linear(C.byref(d), _stream()))
+    _profiled(lambda: _lib.check(_lib.lib().tg_rc_linear(C.byref(d), _stream())), "rc_linear_kernel<320>" + ("+ln" if ln_eps is not None else ""),
+              M, N, K, 2.0 * M * N * K, res is not None)
     return out
 
 
@@ -226,7 +240,10 @@ def rc_xattn(h, wq, kv, wo, rows_per_batch, ln_eps, ip_tokens, ip_scale=None, ou
     d.text_len, d.ip_tokens = int(text_len), int(ip_tokens)
     d.ln_eps = float(ln_eps)
     d.ip_scale = _ptr(ip_scale)
-    _lib.check(_lib.lib().tg_rc_xattn(C.byref(d), _stream()))
+    # algorithmic work: to_q + to_out (2 x 2 M 320^2) + scores and PV over the real keys (4 M 320 (L + T))
+    _profiled(lambda: _lib.check(_lib.lib().tg_rc_xattn(C.byref(d), _stream())), f"rc_xattn_kernel<77+{int(ip_tokens)}>",
+              M, 320, 320, 4.0 * M * 320 * 320 + 4.0 * M * 320 * (int(text_len) + int(ip_tokens)), True,
+              alg_bytes=2.0 * (3 * M * 320 + 2 * 320 * 320) + 2.0 * kv.numel())     # rows in, residual re-read, rows out; to_q, to_out; K / V^T fragments
     return out
 
 
@@ -245,8 +262,36 @@ def rc_ff(h, w1, w2, b2, inner, ln_eps, wpo=None, res0=None, out=None, dbg=0):
     d.res0, d.ldres = (_ptr(res0), int(res0.stride(0))) if res0 is not None else (None, 0)
     d.out, d.ldc = _ptr(out), int(out.stride(0))
     d.M, d.inner, d.ln_eps, d.dbg = int(M), int(inner), float(ln_eps), int(dbg)
-    _lib.check(_lib.lib().tg_rc_ff(C.byref(d), _stream()))
+    fl = 2.0 * M * 320 * (3 * int(inner)) + (2.0 * M * 320 * 320 if wpo is not None else 0.0)
+    _profiled(lambda: _lib.check(_lib.lib().tg_rc_ff(C.byref(d), _stream())), "rc_ff_kernel<320>" + ("+proj_out" if wpo is not None else ""),
+              M, 320, 3 * int(inner), fl, True,
+              alg_bytes=2.0 * ((4 if wpo is not None else 3) * M * 320 + 3 * 320 * int(inner) + (320 * 320 if wpo is not None else 0)))
     return out
+
+
+def rc_front(x, coef, win, wqkv, rows_per_batch, ln_eps, y=None, qk=None, vt=None):
+    """GroupNorm (coefficients) + proj_in + LayerNorm1 + q | k | v in one launch; see tg_rc_front.  Returns (y, qk, vt, ldt)."""
+    from ._lib import RcFrontDesc
+    _need_cuda(x)
+    M, Cc = x.shape
+    assert Cc == 320 and x.stride(1) == 1 and coef.dtype == torch.float32
+    B = M // rows_per_batch
+    ldt = (rows_per_batch + 7) // 8 * 8
+    if y is None:
+        y = torch.empty(M, 320, dtype=x.dtype, device=x.device)
+    if qk is None:
+        qk = torch.empty(M, 640, dtype=x.dtype, device=x.device)
+    if vt is None:
+        vt = torch.empty(B, 320, ldt, dtype=x.dtype, device=x.device)
+    d = RcFrontDesc()
+    d.dtype = _dt(x)
+    d.x, d.ldx, d.coef, d.win, d.wqkv = _ptr(x), int(x.stride(0)), _ptr(coef), _ptr(win), _ptr(wqkv)
+    d.y, d.ldy, d.qk, d.ldqk, d.vt, d.ldt = _ptr(y), int(y.stride(0)), _ptr(qk), int(qk.stride(0)), _ptr(vt), int(vt.stride(1))
+    d.M, d.rows_per_batch, d.ln_eps = int(M), int(rows_per_batch), float(ln_eps)
+    fl = 2.0 * M * 320 * (320 + 960)
+    _profiled(lambda: _lib.check(_lib.lib().tg_rc_front(C.byref(d), _stream())), "rc_front_kernel<320>", M, 960, 320, fl, False,
+              alg_bytes=2.0 * (5 * M * 320 + 4 * 320 * 320))
+    return y, qk, vt, int(vt.stride(1))
 
 
 def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, pad_mode=0, **kw):

@@ -14,7 +14,7 @@ from .weights_pack import rc_pack, rc_pack_tiles
 # TG_RC: 0 = the row-chain kernels are never selected (old-path A/B), 1 = default.  TG_RC_MIN_ROWS: below this many token rows the
 # LDS-tiled GEMMs / the three-launch cross-attention stay (a row-chain workgroup is a long serial chain: it needs a full chip of them)
 ENABLED = os.environ.get("TG_RC", "1") != "0"
-MODE = int(os.environ.get("TG_RC_MODE", "7"))      # dev A/B: bit 0 = tg_rc_linear swaps, bit 1 = tg_rc_xattn, bit 2 = tg_rc_ff
+MODE = int(os.environ.get("TG_RC_MODE", "15"))     # dev A/B: bit 0 = tg_rc_linear swaps, bit 1 = tg_rc_xattn, bit 2 = tg_rc_ff, bit 3 = tg_rc_front
 MIN_ROWS = int(os.environ.get("TG_RC_MIN_ROWS", "8192"))
 TRACE = os.environ.get("TG_RC_TRACE") == "1"
 

@@ -28,7 +28,8 @@ import torch.nn as nn
 
 from . import ops
 from . import rowchain
-from .attention_processor import Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, fused_cross_block
+from .attention_processor import (Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, front_eligible, fused_cross_block,
+                                  ln_weight, self_attention_from_qkv)
 from .config import UNetConfig
 from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear, rc_pack_tiles
 
@@ -252,9 +253,10 @@ class BasicTransformerBlock(nn.Module):
             out = out[0]
         return ops.add(out.reshape(b * n, -1).contiguous(), residual)
 
-    def run(self, x2d, b, n, enc, ca_kwargs, tail=None):
+    def run(self, x2d, b, n, enc, ca_kwargs, tail=None, pre_qkv=None):
         """``tail`` (optional, from ``Transformer2DModel``: (packed proj_out weight, bias, residual)) — when the fused feed-forward launch
-        takes it, the block returns ``(proj_out output, True)``; otherwise a plain tensor (the caller runs proj_out itself)."""
+        takes it, the block returns ``(proj_out output, True)``; otherwise a plain tensor (the caller runs proj_out itself).
+        ``pre_qkv`` = (Q | K, V^T, ldt) of norm1(x2d) already projected by ``tg_rc_front``."""
         M, C = x2d.shape
         if _LN_MODE and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
             # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor.  Row statistics: a
@@ -262,7 +264,10 @@ class BasicTransformerBlock(nn.Module):
             def folded(norm, t):
                 return (norm, ops.layernorm_stats(t, norm.eps) if _LN_MODE & 4 else None)
             if _LN_MODE & 1:
-                x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d))
+                if pre_qkv is not None:
+                    x2d = self_attention_from_qkv(self.attn1, pre_qkv[0], pre_qkv[1], pre_qkv[2], b, n, x2d)
+                else:
+                    x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d))
                 # first level of SD-1.5: norm2 + attn2 + residual as ONE row-chain launch (q, scores and O stay in registers)
                 h2 = fused_cross_block(self.attn2, self.norm2, x2d, b, n, enc, ca_kwargs)
                 x2d = h2 if h2 is not None else self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=folded(self.norm2, x2d))
@@ -311,18 +316,39 @@ class Transformer2DModel(nn.Module):
             return mod.weight
         return self._p.get(name, [mod.weight], lambda: pack_conv1x1(mod.weight.detach()))
 
+    def _front(self, x, w_in, ca_kwargs):
+        """GroupNorm (statistics launch + coefficients) + proj_in + the first block's norm1 + q | k | v as ONE row-chain launch
+        (``tg_rc_front``; first level of SD-1.5) -> (y, Q | K, V^T, ldt), or None when the shapes / processors are not eligible."""
+        blk = self.transformer_blocks[0]
+        M, C = x.t.shape
+        if (not rowchain.ENABLED or not (rowchain.MODE & 8) or not _LN_MODE & 1 or C != 320 or w_in.shape != (320, 320) or M < rowchain.MIN_ROWS
+                or x.hw % 128 or x.t.stride(0) != C or x.c != 320 or not front_eligible(blk.attn1, ca_kwargs)):
+            return None
+        coef = ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias)
+        bin_ = self.proj_in.bias
+        win = self._p.get("rc_front_in", [w_in] + ([bin_] if bin_ is not None else []),
+                          lambda: rc_pack_tiles(w_in.detach(), bin_.detach().float() if bin_ is not None else None))
+        wl, ul, vl = ln_weight(blk.attn1, "qkv", blk.norm1)
+        wqkv = self._p.get("rc_front_qkv", [wl, ul, vl], lambda: rc_pack_tiles(wl, vl, ul))
+        return ops.rc_front(x.t, coef, win, wqkv, x.hw, blk.norm1.eps)
+
     def run(self, x: _Act, enc, ca_kwargs):
-        y = ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False)
         w_in = self._w("in", self.proj_in)
-        y_in = rowchain.linear320(y, w_in, self.proj_in.bias, None, self, "proj_in", _cached)
-        y = y_in if y_in is not None else ops.linear(y, w_in, self.proj_in.bias)
+        pre = self._front(x, w_in, ca_kwargs)
+        if pre is not None:
+            y, pre = pre[0], pre[1:]
+        else:
+            y = ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False)
+            y_in = rowchain.linear320(y, w_in, self.proj_in.bias, None, self, "proj_in", _cached)
+            y = y_in if y_in is not None else ops.linear(y, w_in, self.proj_in.bias)
         base_key = list(ca_kwargs.get("attn_key", [])) if "attn_key" in ca_kwargs else None
         w_out = self._w("out", self.proj_out)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             if base_key is not None:
                 ca_kwargs["attn_key"] = base_key + [i]           # transformer_2d.py:299-304
-            y = blk.run(y, x.b, x.hw, enc, ca_kwargs, tail=(w_out, self.proj_out.bias, x.t) if i == last else None)
+            y = blk.run(y, x.b, x.hw, enc, ca_kwargs, tail=(w_out, self.proj_out.bias, x.t) if i == last else None,
+                        pre_qkv=pre if i == 0 else None)
             if isinstance(y, tuple):                             # the last block's fused feed-forward launch ran proj_out + residual too
                 return _Act(y[0], x.b, x.h, x.w, x.c)
         out = rowchain.linear320(y, w_out, self.proj_out.bias, x.t, self, "proj_out", _cached)
