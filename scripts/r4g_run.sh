@@ -3,8 +3,8 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4g; mkdir -p $O
 cd $R
-for i in 1 2; do
-  for v in 0 7 6 5 2; do
+for i in 1 2 3; do
+  for v in 7 15; do
     TG_RC_MODE=$v timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('TG_RC_MODE=$v', d['ms_per_step'], d['value'])" | tee -a $O/ab.txt
   done
 done

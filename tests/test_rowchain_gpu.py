@@ -221,7 +221,34 @@ def test_first_level_transformer_row_chain_on_vs_off(dtype, monkeypatch):
     monkeypatch.setattr(rowchain, "ENABLED", True)
     monkeypatch.setattr(rowchain, "MIN_ROWS", 1024)
     l2, mx = tols(dtype)
-    for mode in (7, 1, 2, 4):
+    for mode in (15, 1, 2, 4, 8):
         monkeypatch.setattr(rowchain, "MODE", mode)
         got = tf.run(x, enc, {}).t
         check(got, ref, f"first-level Transformer2DModel row-chain mode {mode} {dtype}", 2 * l2, 2 * mx)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 128), (2, 4096)])
+def test_rc_front_vs_fp32_reference(dtype, B, N):
+    """GroupNorm (coefficients) + proj_in + LayerNorm1 + q | k | v in one launch vs the fp32 restatement of models/transformer_2d.py:285-296
+    and models/attention.py:186-204; Q | K token-major, V transposed per batch item (what tg_attention reads)"""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear, rc_pack_tiles
+    g = torch.Generator().manual_seed(B * N)
+    C, M = 320, B * N
+    t = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = (t(M, C, sc=1.3) + 0.4).to(dtype).to(DEV)
+    gg = (1 + 0.2 * t(C)).to(dtype).to(DEV); gb = t(C, sc=0.1).to(dtype).to(DEV)
+    win = t(C, C, sc=C ** -0.5).to(dtype).to(DEV); bin_ = t(C, sc=0.1).to(dtype).to(DEV)
+    wq = t(3 * C, C, sc=C ** -0.5).to(dtype).to(DEV)
+    lg = (1 + 0.2 * t(C)).to(dtype).to(DEV); lb = t(C, sc=0.1).to(dtype).to(DEV)
+    xg = F.group_norm(x.float().reshape(B, N, C).permute(0, 2, 1), 32, gg.float(), gb.float(), 1e-6).permute(0, 2, 1).reshape(M, C)
+    y = xg @ win.float().T + bin_.float()
+    qkv = F.layer_norm(y, (C,), lg.float(), lb.float(), 1e-5) @ wq.float().T
+    coef = ops.groupnorm_coef(x, B, N, 32, 1e-6, gg, gb)
+    Wp, u, v = pack_ln_linear(wq, None, lg, lb)
+    gy, gqk, gvt, ldt = ops.rc_front(x, coef, rc_pack_tiles(win, bin_.float()), rc_pack_tiles(Wp, v, u), N, 1e-5)
+    l2, mx = tols(dtype)
+    check(gy, y, f"rc_front y B{B} N{N} {dtype}", 1.5 * l2, 1.5 * mx)
+    check(gqk, qkv[:, :640], f"rc_front qk B{B} N{N} {dtype}", 2 * l2, 2 * mx)
+    check(gvt[:, :, :N].permute(0, 2, 1).reshape(M, C), qkv[:, 640:], f"rc_front v^T B{B} N{N} {dtype}", 2 * l2, 2 * mx)
