@@ -456,6 +456,7 @@ typedef struct {
   int64_t M;
   int32_t rows_per_batch;
   float ln_eps;
+  int32_t dbg;     /* dev timing switches, 0 */
 } tg_rc_front_desc;
 int tg_rc_front(const tg_rc_front_desc* d, void* stream);
 

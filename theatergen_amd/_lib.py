@@ -66,7 +66,7 @@ class RcFfDesc(C.Structure):
 class RcFrontDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("x", vp), ("ldx", i64), ("coef", vp), ("win", vp), ("wqkv", vp), ("y", vp), ("ldy", i64), ("qk", vp), ("ldqk", i64),
-        ("vt", vp), ("ldt", i64), ("M", i64), ("rows_per_batch", i32), ("ln_eps", f32),
+        ("vt", vp), ("ldt", i64), ("M", i64), ("rows_per_batch", i32), ("ln_eps", f32), ("dbg", i32),
     ]
 
 

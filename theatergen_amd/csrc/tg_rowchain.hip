@@ -429,8 +429,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // One 32-row weight tile = a stream of 20 fragments consumed by 20 MFMAs on one accumulator, read PD steps ahead of their MFMA with the
   // order PINNED (hipcc otherwise sinks every ds_read next to its MFMA: ~150 exposed cycles per MFMA).  The accumulator is seeded from
   // the tile's vector page: v (plain) or std * v - mean * u (LayerNorm fold; times rstd at the end).
-  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold) -> f32x16 {
-    constexpr int PD = 4;
+  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold, auto pd_c) __attribute__((always_inline)) -> f32x16 {
+    constexpr int PD = decltype(pd_c)::value;
     const char* cb = cbase + lane * 16;
     const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
     V8 a[KS];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int t = 0; t < 10; ++t) {
     stage_begin(t, 6);
     if (p.dbg & 1) continue;
-    f32x16 acc = tile_stream(smem + (t % 3) * SLOT, H, true);
+    f32x16 acc = tile_stream(smem + (t % 3) * SLOT, H, true, std::integral_constant<int, 4>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
     Q[2 * t] = pack8r<T>(acc, 0);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(hp + mrow[i] * p.ldh + ch0 + 8 * qb);
       }
       f32x16 acc;
-      if (!(p.dbg & 4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false);
+      if (!(p.dbg & 4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false, std::integral_constant<int, 8>{});
       if (uu == 0) quad_transpose(r8[0], r8[1], r8[2], r8[3]);
       float o[16];
 #pragma unroll
@@ -753,6 +753,7 @@ struct RcFrontParams {
   long M;
   int rows_per_batch;
   float ln_eps;
+  int dbg;                // dev timing switches: 1 no V^T stores, 2 no Q | K stores, 4 no y stores
 };
 
 template <typename T>
@@ -825,6 +826,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   V8 pend[4];
   auto flush = [&](int k) __attribute__((always_inline)) {      // the stores of stage k
     if (k < 0 || n_stores(k) == 0) return;
+    if ((k >= 30 && (p.dbg & 1)) || (k >= 10 && k < 30 && (p.dbg & 2)) || (k < 10 && (p.dbg & 4))) return;
     if (k < 30) {
       T* base = reinterpret_cast<T*>(k < 10 ? p.y : p.qk);
       asm volatile("" : "+s"(base));
@@ -865,8 +867,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     issue_stage(st + 2);
     flush(st - 1);
   };
-  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold) __attribute__((always_inline)) -> f32x16 {
-    constexpr int PD = 4;
+  auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold, auto pd_c) __attribute__((always_inline)) -> f32x16 {
+    constexpr int PD = decltype(pd_c)::value;      // fragment read-ahead: 4 while the rows AND the growing outputs are live, 8 after
     const char* cb = cbase + lane * 16;
     const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
     V8 a[KS];
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < 10; ++t) {
     stage_begin(t);
-    const f32x16 acc = tile_stream(smem + (t % 3) * SLOT, X, false);
+    const f32x16 acc = tile_stream(smem + (t % 3) * SLOT, X, false, std::integral_constant<int, 4>{});
     Y[2 * t] = pack8r<T>(acc, 0);
     Y[2 * t + 1] = pack8r<T>(acc, 8);
     if (t & 1) {
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < 30; ++t) {
     stage_begin(10 + t);
-    f32x16 acc = tile_stream(smem + ((10 + t) % 3) * SLOT, Y, true);
+    f32x16 acc = tile_stream(smem + ((10 + t) % 3) * SLOT, Y, true, std::integral_constant<int, 8>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
     if (t < 20) {
@@ -1442,7 +1444,7 @@ extern "C" int tg_rc_front(const tg_rc_front_desc* d, void* stream) {
            TG_ERR_ARG, "tg_rc_front: row pitches");
   RcFrontParams p;
   p.x = d->x; p.ldx = d->ldx; p.coef = d->coef; p.win = d->win; p.wqkv = d->wqkv; p.y = d->y; p.ldy = d->ldy; p.qk = d->qk; p.ldqk = d->ldqk;
-  p.vt = d->vt; p.ldt = d->ldt; p.M = d->M; p.rows_per_batch = d->rows_per_batch; p.ln_eps = d->ln_eps;
+  p.vt = d->vt; p.ldt = d->ldt; p.M = d->M; p.rows_per_batch = d->rows_per_batch; p.ln_eps = d->ln_eps; p.dbg = d->dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return launch_rc_front<bf16_t>(d, p, st);
   return launch_rc_front<f16_t>(d, p, st);

@@ -269,7 +269,7 @@ def rc_ff(h, w1, w2, b2, inner, ln_eps, wpo=None, res0=None, out=None, dbg=0):
     return out
 
 
-def rc_front(x, coef, win, wqkv, rows_per_batch, ln_eps, y=None, qk=None, vt=None):
+def rc_front(x, coef, win, wqkv, rows_per_batch, ln_eps, y=None, qk=None, vt=None, dbg=0):
     """GroupNorm (coefficients) + proj_in + LayerNorm1 + q | k | v in one launch; see tg_rc_front.  Returns (y, qk, vt, ldt)."""
     from ._lib import RcFrontDesc
     _need_cuda(x)
@@ -287,7 +287,7 @@ def rc_front(x, coef, win, wqkv, rows_per_batch, ln_eps, y=None, qk=None, vt=Non
     d.dtype = _dt(x)
     d.x, d.ldx, d.coef, d.win, d.wqkv = _ptr(x), int(x.stride(0)), _ptr(coef), _ptr(win), _ptr(wqkv)
     d.y, d.ldy, d.qk, d.ldqk, d.vt, d.ldt = _ptr(y), int(y.stride(0)), _ptr(qk), int(qk.stride(0)), _ptr(vt), int(vt.stride(1))
-    d.M, d.rows_per_batch, d.ln_eps = int(M), int(rows_per_batch), float(ln_eps)
+    d.M, d.rows_per_batch, d.ln_eps, d.dbg = int(M), int(rows_per_batch), float(ln_eps), int(dbg)
     fl = 2.0 * M * 320 * (320 + 960)
     _profiled(lambda: _lib.check(_lib.lib().tg_rc_front(C.byref(d), _stream())), "rc_front_kernel<320>", M, 960, 320, fl, False,
               alg_bytes=2.0 * (5 * M * 320 + 4 * 320 * 320))
