@@ -16,6 +16,7 @@ PyTorch moves data only (concat, head split / merge, zero-stuffing, transposes):
 """
 import contextlib
 import math
+import contextvars
 import os
 
 import torch
@@ -78,11 +79,16 @@ def _dgrad_lin(g, wt):
 _SIDE = {}
 
 
+# per-context side-stream count for ``GraphedInputGrad`` (it used to mutate the process-global os.environ around the capture: not
+# thread-safe, and it leaked into eager ``loss_and_grad`` calls of other threads); 0 = fall back to TG_BWD_STREAMS
+_STREAMS_OVERRIDE = contextvars.ContextVar("tg_bwd_streams", default=0)
+
+
 def _side_streams(dev):
     """Side streams of the per-head loops (TG_BWD_STREAMS; default 1 = everything on the current stream: eager launches are bound by the
     host's Python and stream switches add to it — 44.9 -> 50.9 ms per iteration at 768^2 with 4; ``GraphedInputGrad`` captures with 8:
     35.7 -> 31.1 ms per replay)."""
-    n = int(os.environ.get("TG_BWD_STREAMS", "1"))
+    n = _STREAMS_OVERRIDE.get() or int(os.environ.get("TG_BWD_STREAMS", "1"))
     if n <= 1:
         return []
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
@@ -378,6 +384,7 @@ class UNetInputGrad:
             raise RuntimeError(f"guidance keys {sorted(missing)} do not name cross-attention layers of this UNet")
         # plain ``AttnProcessor`` on attn2 mirrors the reference's offload quirk (maps after the first are ``.cpu()`` tensors,
         # attention_processor.py:386-389); the loss kernels and the softmax backward read DEVICE memory: bring every map back
+        self._had_cpu_maps = any(not v.is_cuda for v in saved.values())
         saved = {k: (v if v.is_cuda else v.to(sample.device)) for k, v in saved.items()}
         loss, grads = loss_fn(saved)
         for k, gk in grads.items():
@@ -403,20 +410,21 @@ class GraphedInputGrad:
         self.timestep = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).to(sample.device).clone()
         self.enc = unet.register_conditioning(encoder_hidden_states)
         args = (self.sample, self.timestep, self.enc, loss_fn, save_keys)
-        prev = os.environ.get("TG_BWD_STREAMS")
-        os.environ["TG_BWD_STREAMS"] = str(int(streams))
+        token = _STREAMS_OVERRIDE.set(int(streams))
         try:
             with torch.no_grad():
                 self.engine.loss_and_grad(*args, **kw)            # eager once: allocator, packed weights, scratch, the loss plan
                 torch.cuda.synchronize()
+                if getattr(self.engine, "_had_cpu_maps", False):
+                    # the host -> device copy of such a map inside the capture fails with an opaque capture error
+                    raise RuntimeError("GraphedInputGrad: a guidance key's cross-attention layer runs the plain AttnProcessor, whose captured maps "
+                                       "live on the CPU (reference quirk, attention_processor.py:386-389); install IPAttnProcessor / CNAttnProcessor "
+                                       "on the guidance layers or use graphed=False")
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self.loss, self.grad = self.engine.loss_and_grad(*args, **kw)
         finally:
-            if prev is None:
-                del os.environ["TG_BWD_STREAMS"]
-            else:
-                os.environ["TG_BWD_STREAMS"] = prev
+            _STREAMS_OVERRIDE.reset(token)
 
     def run(self, sample=None, timestep=None):
         """-> (loss, grad): the graph's static output tensors (overwritten by the next ``run``)."""
