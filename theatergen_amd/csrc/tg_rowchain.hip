@@ -979,6 +979,10 @@ template <int OFF, typename V8> __device__ __forceinline__ void lds_read16(V8& d
 template <int N, typename V8> __device__ __forceinline__ void lds_wait(V8& frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
+// one wait for the three fragments of a slot group (every asm statement costs its own issue slot plus the s_nop hipcc puts behind it)
+template <int N, typename V8> __device__ __forceinline__ void lds_wait3(V8& f0, V8& f1, V8& f2) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f0), "+v"(f1), "+v"(f2) : "n"(N));
+}
 
 struct RcFfParams {
   const void* h;        // [M, 320] the stream before norm3 (= the residual)
@@ -1159,7 +1163,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       constexpr int x = decltype(xc)::value;
       constexpr int k = x / 3, w = x % 3;
       constexpr bool act = (w == 2) ? F2 : F1;
-      if constexpr (x + LA < 60) rd(std::integral_constant<int, (x + LA < 60 ? x + LA : 59)>{});
+      if constexpr (F1 && F2) {
+        if constexpr (w == 0) {      // the three reads of the group LA slots ahead, in one go
+          if constexpr (x + LA < 60) rd(std::integral_constant<int, (x + LA < 60 ? x + LA : 59)>{});
+          if constexpr (x + LA + 1 < 60) rd(std::integral_constant<int, (x + LA + 1 < 60 ? x + LA + 1 : 59)>{});
+          if constexpr (x + LA + 2 < 60) rd(std::integral_constant<int, (x + LA + 2 < 60 ? x + LA + 2 : 59)>{});
+        }
+      } else {
+        if constexpr (x + LA < 60) rd(std::integral_constant<int, (x + LA < 60 ? x + LA : 59)>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (act) {
         // reads issued after this slot's: the active slots in (x, min(59, x + LA)]
@@ -1167,7 +1179,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int n_f1 = ((hi_x / 3) * 2 + (hi_x % 3 >= 1 ? (hi_x % 3 == 1 ? 2 : 2) : 1)) - ((x / 3) * 2 + (x % 3 >= 1 ? 2 : 1));
         constexpr int n_f2 = (hi_x + 1) / 3 - (x + 1) / 3;
         constexpr int younger = (F1 ? n_f1 : 0) + (F2 ? n_f2 : 0);
-        lds_wait<(younger > 15 ? 15 : younger)>(fr[x]);
+        if constexpr (F1 && F2) {
+          // steady state: one wait per slot group (value, gate, net.2 fragments of k): counted for the group's LAST fragment
+          if constexpr (w == 0) {
+            constexpr int hi3 = x + 2 + LA < 60 ? x + 2 + LA : 59;
+            lds_wait3<(hi3 - (x + 2) > 15 ? 15 : hi3 - (x + 2))>(fr[x], fr[x + 1], fr[x + 2]);
+          }
+        } else {
+          lds_wait<(younger > 15 ? 15 : younger)>(fr[x]);
+        }
         if constexpr (w == 0) acc_a[PAR] = mfma32(fr[x], HN[k], acc_a[PAR]);
         else if constexpr (w == 1) acc_g[PAR] = mfma32(fr[x], HN[k], acc_g[PAR]);
         else out[k % 10] = mfma32(fr[x], hid[PAR][k / 10], out[k % 10]);
@@ -1279,7 +1299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* cbase = smem + (st % 3) * SLOT;
         const char* cb = cbase + lane * 16;
         const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
-        constexpr int PD = 4;
+        constexpr int PD = 10;          // one wave per SIMD: nothing else hides the LDS round trip, and the net.2 accumulators are dead by now
         V8 a[KS];
 #pragma unroll
         for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
