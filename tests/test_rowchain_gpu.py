@@ -157,6 +157,7 @@ def test_first_level_block_row_chain_on_vs_off(dtype, ip, monkeypatch):
     ref = blk.run(x, B, N, enc, {})
     monkeypatch.setattr(rowchain, "ENABLED", True)
     monkeypatch.setattr(rowchain, "MIN_ROWS", 1024)
+    monkeypatch.setattr(rowchain, "MIN_ROWS_CHAIN", 1024)
     got = blk.run(x, B, N, enc, {})
     l2, mx = tols(dtype)
     check(got, ref, f"first-level block row-chain on/off ip={ip} {dtype}", 1.5 * l2, 1.5 * mx)
@@ -220,6 +221,7 @@ def test_first_level_transformer_row_chain_on_vs_off(dtype, monkeypatch):
     ref = tf.run(x, enc, {}).t
     monkeypatch.setattr(rowchain, "ENABLED", True)
     monkeypatch.setattr(rowchain, "MIN_ROWS", 1024)
+    monkeypatch.setattr(rowchain, "MIN_ROWS_CHAIN", 1024)
     l2, mx = tols(dtype)
     for mode in (15, 1, 2, 4, 8):
         monkeypatch.setattr(rowchain, "MODE", mode)

@@ -933,11 +933,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ln_std = var * ln_rstd;
     ln_nmean = -mean;
   }
-  // ---- q | k | v (LayerNorm folded)
-#pragma unroll
-  for (int t = 0; t < 30; ++t) {
-    stage_begin(10 + t);
-    f32x16 acc = tile_stream(smem + ((10 + t) % 3) * SLOT, Y, true, std::integral_constant<int, 8>{});
+  // ---- q | k | v (LayerNorm folded).  The rounding / packing / transposing of tile t - 1 runs in stage t BEHIND the first fragment and seed
+  // reads of tile t (a lone wave otherwise sits out one LDS round trip per stage before its first MFMA), its stores right behind that.
+  auto qkv_epilogue = [&](int t, f32x16 acc) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
     if (t < 20) {
@@ -950,7 +948,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else {
       pend[0] = pack8r<T>(acc, 0); pend[1] = pack8r<T>(acc, 8);
     }
+  };
+  f32x16 acc_prev;
+#pragma unroll
+  for (int t = 0; t < 30; ++t) {
+    const int st = 10 + t;
+    {
+      const int younger = n_stores(st - 3) + (st + 1 < NST ? 6 : 0) + n_stores(st - 2);
+      switch (younger) {
+        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    issue_stage(st + 2);
+    constexpr int PD = 8;
+    const char* cbase = smem + (st % 3) * SLOT;
+    const char* cb = cbase + lane * 16;
+    const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
+    V8 a[KS];
+#pragma unroll
+    for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
+    f32x4 v4[4], u4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { v4[g] = *reinterpret_cast<const f32x4*>(vec + 4 * g); u4[g] = *reinterpret_cast<const f32x4*>(vec + 32 + 4 * g); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t > 0) qkv_epilogue(t - 1, acc_prev);
+    flush(st - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] = __builtin_fmaf(ln_nmean, u4[g][e], ln_std * v4[g][e]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < KS; ++x) {
+      if (x + PD < KS) a[x + PD] = *reinterpret_cast<const V8*>(cb + (x + PD) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma32(a[x], Y[x], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc_prev = acc;
   }
+  qkv_epilogue(29, acc_prev);
   flush(NST - 1);
 }
 

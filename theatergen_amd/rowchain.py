@@ -16,6 +16,9 @@ from .weights_pack import rc_pack, rc_pack_tiles
 ENABLED = os.environ.get("TG_RC", "1") != "0"
 MODE = int(os.environ.get("TG_RC_MODE", "15"))     # dev A/B: bit 0 = tg_rc_linear swaps, bit 1 = tg_rc_xattn, bit 2 = tg_rc_ff, bit 3 = tg_rc_front
 MIN_ROWS = int(os.environ.get("TG_RC_MIN_ROWS", "8192"))
+# rc_linear / rc_front / rc_ff are one long serial chain per workgroup (a lone rc_ff workgroup needs ~95 us): below one full round of 128-token
+# workgroups (256 CUs x 128 rows) the LDS-tiled launches are as fast or faster (8192 rows: rc_ff 95 us vs 64 us, rc_front 51 + 16 vs 59 us)
+MIN_ROWS_CHAIN = int(os.environ.get("TG_RC_MIN_ROWS_CHAIN", "32768"))
 TRACE = os.environ.get("TG_RC_TRACE") == "1"
 
 
@@ -103,7 +106,7 @@ def linear320(x2d, lin_weight, bias, res, owner, name, cached):
     ``cached(owner, name, tensors, build)`` is the caller's packed-weight cache."""
     M, K = x2d.shape
     N = lin_weight.shape[0]
-    if not ENABLED or not (MODE & 1) or K != 320 or N % 64 or M < MIN_ROWS or x2d.stride(1) != 1 or lin_weight.shape[1] != 320:
+    if not ENABLED or not (MODE & 1) or K != 320 or N % 64 or M < MIN_ROWS_CHAIN or x2d.stride(1) != 1 or lin_weight.shape[1] != 320:
         trace("linear320 no", name, M, K, N)
         return None
     trace("linear320 yes", name, M, N)

@@ -186,7 +186,7 @@ class FeedForward(nn.Module):
         proj, lin2 = self.net[0].proj, self.net[2]
         M, K = x2d.shape
         inner = lin2.weight.shape[1]
-        if (not rowchain.ENABLED or not (rowchain.MODE & 4) or K != 320 or lin2.weight.shape[0] != 320 or inner % 64 or M < rowchain.MIN_ROWS
+        if (not rowchain.ENABLED or not (rowchain.MODE & 4) or K != 320 or lin2.weight.shape[0] != 320 or inner % 64 or M < rowchain.MIN_ROWS_CHAIN
                 or x2d.stride(0) != K or proj.weight.shape[0] != 2 * inner):
             return None
         ts = [proj.weight, proj.bias, norm.weight, norm.bias, lin2.weight] + ([lin2.bias] if lin2.bias is not None else [])
@@ -321,7 +321,7 @@ class Transformer2DModel(nn.Module):
         (``tg_rc_front``; first level of SD-1.5) -> (y, Q | K, V^T, ldt), or None when the shapes / processors are not eligible."""
         blk = self.transformer_blocks[0]
         M, C = x.t.shape
-        if (not rowchain.ENABLED or not (rowchain.MODE & 8) or not _LN_MODE & 1 or C != 320 or w_in.shape != (320, 320) or M < rowchain.MIN_ROWS
+        if (not rowchain.ENABLED or not (rowchain.MODE & 8) or not _LN_MODE & 1 or C != 320 or w_in.shape != (320, 320) or M < rowchain.MIN_ROWS_CHAIN
                 or x.hw % 128 or x.t.stride(0) != C or x.c != 320 or not front_eligible(blk.attn1, ca_kwargs)):
             return None
         coef = ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias)
