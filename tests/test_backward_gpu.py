@@ -220,6 +220,16 @@ def test_unet_latent_gradient_and_guided_update(dtype, variant):
                                                          loss_threshold=0.0, max_iter=2, guidance_attn_keys=keys, graphed=True, **GUIDE_RATIO)
         assert torch.equal(eager_lat, graph_lat) and float(eager_loss) == float(graph_loss), tt
     assert len(unet.__dict__["_graphed_input_grad"]) == 1          # one capture served both timesteps
+    # a FRESH conditioning tensor of the same shape (a caller's per-step torch.cat) and other values must not re-capture: the embeddings
+    # are copied into the graph's static buffer and K / V^T re-projected in place — same bits as the eager loop on that tensor
+    gig0 = next(iter(unet.__dict__["_graphed_input_grad"].values()))
+    enc2 = (enc * 0.7 + 0.05).to(DEV, dtype)
+    eager_lat, eager_loss = latent_backward_guidance(None, sch, unet, enc2, 0, boxes, pos, t, lat.to(DEV, dtype), 1e6, loss_scale=loss_scale,
+                                                     loss_threshold=0.0, max_iter=2, guidance_attn_keys=keys, **GUIDE_RATIO)
+    graph_lat, graph_loss = latent_backward_guidance(None, sch, unet, enc2.clone(), 0, boxes, pos, t, lat.to(DEV, dtype), 1e6, loss_scale=loss_scale,
+                                                     loss_threshold=0.0, max_iter=2, guidance_attn_keys=keys, graphed=True, **GUIDE_RATIO)
+    assert torch.equal(eager_lat, graph_lat) and float(eager_loss) == float(graph_loss)
+    assert next(iter(unet.__dict__["_graphed_input_grad"].values())) is gig0
     unet.__dict__["_graphed_input_grad"].clear()
     # index >= max_index_step: untouched (reference :66)
     same, _ = latent_backward_guidance(None, sch, unet, enc.to(DEV, dtype), 10, boxes, pos, t, lat.to(DEV, dtype), 1e6, guidance_attn_keys=keys)

@@ -473,6 +473,10 @@ class IPAttnProcessor(nn.Module):
     # ip_adapter/ip_adapter.py:155-158; ``custom_pipelines.py:328-333`` toggles 0.0 <-> s per step), but the value the attention
     # kernel multiplies with lives in a DEVICE scalar: an assignment refreshes that scalar (one 4-byte fill on the current
     # stream), so a hipGraph captured with one scale replays with the next one — no re-capture, no host sync.
+    # STREAM CONTRACT: the fill is ordered against a replay only through the stream it is issued on.  ``DenoiseEngine.run`` replays on the
+    # CURRENT stream (the per-step gating of ``before_step`` is therefore ordered); ``run_concurrent`` replays on engine-owned streams that wait
+    # for the current stream once, at its start, and are joined before it returns: set the scale BEFORE calling it, never from another thread while
+    # it runs — and engines that share one UNet share this scalar (one IP scale per UNet at a time).
     @property
     def scale(self):
         return self._scale

@@ -22,7 +22,7 @@ import os
 import torch
 
 from . import ops
-from .attention_processor import AttnProcessor, IPAttnProcessor
+from .attention_processor import AttnProcessor, IPAttnProcessor, tensor_version
 from .unet import BasicTransformerBlock, DeviceSchedule, _Act  # noqa: F401
 from .weights_pack import pack_conv1x1, pack_conv3x3
 
@@ -408,7 +408,10 @@ class GraphedInputGrad:
         self.engine = UNetInputGrad(unet)
         self.sample = sample.detach().clone().contiguous()
         self.timestep = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).to(sample.device).clone()
-        self.enc = unet.register_conditioning(encoder_hidden_states)
+        self.unet = unet
+        self._enc_src = encoder_hidden_states
+        # a PRIVATE static copy of the conditioning (the caller's tensor may be a temporary): what the captured launches' K / V^T caches belong to
+        self.enc = unet.register_conditioning(encoder_hidden_states.detach().to(unet.dtype).clone().contiguous())
         args = (self.sample, self.timestep, self.enc, loss_fn, save_keys)
         token = _STREAMS_OVERRIDE.set(int(streams))
         try:
@@ -425,6 +428,18 @@ class GraphedInputGrad:
                     self.loss, self.grad = self.engine.loss_and_grad(*args, **kw)
         finally:
             _STREAMS_OVERRIDE.reset(token)
+
+    def set_conditioning(self, encoder_hidden_states):
+        """New embeddings of the captured shape: copied into the graph's static conditioning buffer, K / V^T re-projected IN PLACE (the buffers the
+        captured launches read); a no-op for the tensor the graph already holds."""
+        src = encoder_hidden_states
+        if src is self.enc or src is self._enc_src:
+            return
+        if tuple(src.shape) != tuple(self.enc.shape):
+            raise RuntimeError(f"GraphedInputGrad: conditioning of shape {tuple(src.shape)}, captured with {tuple(self.enc.shape)}")
+        self.enc.copy_(src.to(self.enc.dtype))
+        self.unet.register_conditioning(self.enc)
+        self._enc_src = src
 
     def run(self, sample=None, timestep=None):
         """-> (loss, grad): the graph's static output tensors (overwritten by the next ``run``)."""
@@ -458,7 +473,8 @@ def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, b
         max_iter = max_iter[index] if len(max_iter) > index else max_iter[-1]
     engine = UNetInputGrad(unet)
     lat32 = latents.detach().to(torch.float32).contiguous()
-    cond_embeddings = unet.register_conditioning(cond_embeddings)      # K / V^T of the conditioning projected once, not per iteration
+    if not graphed:
+        cond_embeddings = unet.register_conditioning(cond_embeddings)  # K / V^T of the conditioning projected once, not per iteration
 
     def loss_fn(saved):
         return G.compute_ca_lossv3(saved_attn=saved, bboxes=bboxes, object_positions=object_positions, guidance_attn_keys=keys,
@@ -473,12 +489,20 @@ def latent_backward_guidance(adapter, scheduler, unet, cond_embeddings, index, b
         if ref_ca_saved_attns is not None or cross_attention_kwargs:
             raise RuntimeError("latent_backward_guidance(graphed=True): ref_ca_saved_attns / cross_attention_kwargs need the eager loop")
         cache = unet.__dict__.setdefault("_graphed_input_grad", {})
-        gkey = (tuple(latents.shape), str(unet.dtype), repr(bboxes), repr(object_positions), repr(keys), float(loss_scale),
-                repr(sorted(kwargs.items())))
+        # the key is (shapes, dtypes, loss arguments, a weight / processor epoch) — NOT the identity of the conditioning tensor: a caller
+        # that builds a fresh ``torch.cat`` per step gets its embeddings COPIED into the graph's static buffer (K / V^T re-projected in place);
+        # an in-place weight update, a LoRA merge or ``set_attn_processor`` changes the epoch and re-captures (the graph bakes packed weights)
+        epoch = (sum(tensor_version(p_) or 0 for p_ in unet.parameters()), tuple(id(v) for v in unet.attn_processors.values()))
+        gkey = (tuple(latents.shape), str(unet.dtype), tuple(cond_embeddings.shape), str(cond_embeddings.dtype), repr(bboxes), repr(object_positions),
+                repr(keys), float(loss_scale), repr(sorted(kwargs.items())), epoch)
         gig = cache.get(gkey)
-        if gig is None or gig.enc is not cond_embeddings:
+        if gig is None:
+            if cache:
+                print("[theatergen_amd] latent_backward_guidance(graphed=True): re-capturing the iteration (shapes / loss arguments / weights changed)")
             cache.clear()                                              # one captured iteration at a time (its buffers are GB-scale at 768^2)
             gig = cache[gkey] = GraphedInputGrad(unet, scheduler.scale_model_input(lat32, t).to(unet.dtype), t, cond_embeddings, loss_fn, keys)
+        else:
+            gig.set_conditioning(cond_embeddings)
 
     while val(loss) / loss_scale > loss_threshold and iteration < max_iter and index < max_index_step:
         model_in = scheduler.scale_model_input(lat32, t).to(unet.dtype)

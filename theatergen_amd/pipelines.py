@@ -196,7 +196,9 @@ class DenoiseEngine:
         """Independent denoising chains (e.g. the two halves of a story's character batch) replayed CONCURRENTLY, one HIP
         stream per engine: the second chain's kernels fill the partially filled grid rounds, small-grid layers and
         launch gaps of the first (+4 % images/s for 2 x 4 images vs 1 x 8 on MI355X).  Engines may share one UNet; each
-        has its own conditioning buffers, K / V^T caches, kernel scratch slot and captured graph.  Returns the histories."""
+        has its own conditioning buffers, K / V^T caches, kernel scratch slot and captured graph.  Returns the histories.
+        The IP scale is ONE device scalar per processor (= per UNet): set it before this call (the engine streams wait for the current
+        stream once, here); per-step ``set_scale`` gating needs ``run(before_step=...)``."""
         dev = engines[0].dev
         with torch.no_grad():
             for e, lat in zip(engines, latents_list):
