@@ -756,10 +756,13 @@ struct RcFrontParams {
   int dbg;                // dev timing switches: 1 no V^T stores, 2 no Q | K stores, 4 no y stores
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rc_front_kernel(RcFrontParams p) {
+// NW = 4: two 128-token workgroups per CU, ring of 3 stages (fetched 2 ahead);  NW = 8 (dev A/B): one 256-token workgroup per CU — every fetched
+// weight byte serves twice the tokens (half the LDS-DMA issue work per wave) —, ring of 4 stages (fetched 3 ahead)
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void rc_front_kernel(RcFrontParams p) {
   typedef typename Vec<T>::v8 V8;
-  constexpr int KS = 20, NW = 4, NST = 40;
+  constexpr int KS = 20, NST = 40;
+  constexpr int DEPTH = NW == 8 ? 3 : 2, NSLOT = DEPTH + 1, PPW = 24 / NW;
   constexpr int TBW = (KS + 1) * 1024, SLOT = 24 * 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -783,14 +786,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (st >= NST) return;
     const char* src = (st < 10 ? reinterpret_cast<const char*>(p.win) + (long)st * TBW
                                : reinterpret_cast<const char*>(p.wqkv) + (long)(st - 10) * TBW) + lane * 16 + wave * 1024;
-    char* dst = smem + (st % 3) * SLOT + wave * 1024;
+    char* dst = smem + (st % NSLOT) * SLOT + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < PPW; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * NW * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
   };
   issue_stage(0);
   issue_stage(1);
+  if (DEPTH == 3) issue_stage(2);
 
   // rows -> registers, GroupNorm applied in place (fp32 x * a + d, one rounding), B-operand layout
   V8 X[KS];
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < KS / 4; ++q) quad_transpose(X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
     // the batch item's 2 x 320 coefficients through LDS (behind the ring): one coalesced 2.5-KiB load per workgroup, broadcast reads
-    float* cl = reinterpret_cast<float*>(smem + 3 * SLOT);
+    float* cl = reinterpret_cast<float*>(smem + NSLOT * SLOT);
     if (tid < 160) *reinterpret_cast<f32x4*>(cl + 4 * tid) = *reinterpret_cast<const f32x4*>(p.coef + bi * 640 + 4 * tid);
     __syncthreads();
     const float* ca = cl + 32 * hi;
@@ -823,6 +827,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float ln_rstd = 1.f, ln_std = 1.f, ln_nmean = 0.f;
   // stores produced by stage k (issued at the top of stage k + 1): a finished 64-channel chunk = 4 x 16 bytes, a V tile = 16 x 2 bytes
   auto n_stores = [](int k) { return k < 0 ? 0 : k < 30 ? ((k & 1) ? 4 : 0) : k < NST ? 16 : 0; };
+  // operations issued behind stage st's pieces when stage st begins: the deferred stores of stages st - DEPTH - 1 .. st - 2 and the pieces of the stages
+  // fetched since (st + 1 .. st + DEPTH - 1)
+  auto younger_of = [&](int st) __attribute__((always_inline)) {
+    int y = 0;
+    for (int k = st - DEPTH - 1; k <= st - 2; ++k) y += n_stores(k);
+    for (int j = st + 1; j <= st + DEPTH - 1; ++j) y += j < NST ? PPW : 0;
+    return y;
+  };
+  // counted wait (the value is a compile-time constant after unrolling; the cases cover every sum that occurs for NW = 4 and 8)
+  auto wait_vm = [&](int n) __attribute__((always_inline)) {
+    switch (n) {
+#define TG_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+      TG_VM_CASE(54) TG_VM_CASE(51) TG_VM_CASE(48) TG_VM_CASE(42) TG_VM_CASE(39) TG_VM_CASE(38) TG_VM_CASE(36) TG_VM_CASE(35) TG_VM_CASE(32)
+      TG_VM_CASE(30) TG_VM_CASE(26) TG_VM_CASE(23) TG_VM_CASE(22) TG_VM_CASE(20) TG_VM_CASE(19) TG_VM_CASE(16) TG_VM_CASE(14) TG_VM_CASE(12)
+      TG_VM_CASE(11) TG_VM_CASE(10) TG_VM_CASE(8) TG_VM_CASE(7) TG_VM_CASE(6) TG_VM_CASE(4) TG_VM_CASE(3)
+#undef TG_VM_CASE
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
   V8 pend[4];
   auto flush = [&](int k) __attribute__((always_inline)) {      // the stores of stage k
     if (k < 0 || n_stores(k) == 0) return;
@@ -850,21 +873,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   auto stage_begin = [&](int st) __attribute__((always_inline)) {
-    const int younger = n_stores(st - 3) + (st + 1 < NST ? 6 : 0) + n_stores(st - 2);
-    switch (younger) {
-      case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
-      case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-      case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-      case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-      case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+    wait_vm(younger_of(st));
     __builtin_amdgcn_s_barrier();
-    issue_stage(st + 2);
+    issue_stage(st + DEPTH);
     flush(st - 1);
   };
   auto tile_stream = [&](const char* cbase, const V8 (&Bop)[KS], bool fold, auto pd_c) __attribute__((always_inline)) -> f32x16 {
@@ -904,7 +915,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < 10; ++t) {
     stage_begin(t);
-    const f32x16 acc = tile_stream(smem + (t % 3) * SLOT, X, false, std::integral_constant<int, 4>{});
+    const f32x16 acc = tile_stream(smem + (t % NSLOT) * SLOT, X, false, std::integral_constant<int, 4>{});
     Y[2 * t] = pack8r<T>(acc, 0);
     Y[2 * t + 1] = pack8r<T>(acc, 8);
     if (t & 1) {
@@ -953,25 +964,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int t = 0; t < 30; ++t) {
     const int st = 10 + t;
-    {
-      const int younger = n_stores(st - 3) + (st + 1 < NST ? 6 : 0) + n_stores(st - 2);
-      switch (younger) {
-        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
-        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      }
-    }
+    wait_vm(younger_of(st));
     __builtin_amdgcn_s_barrier();
-    issue_stage(st + 2);
+    issue_stage(st + DEPTH);
     constexpr int PD = 8;
-    const char* cbase = smem + (st % 3) * SLOT;
+    const char* cbase = smem + (st % NSLOT) * SLOT;
     const char* cb = cbase + lane * 16;
     const float* vec = reinterpret_cast<const float*>(cbase + KS * 1024) + 16 * hi;
     V8 a[KS];
@@ -1005,12 +1002,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <typename T>
 int launch_rc_front(const tg_rc_front_desc* d, const RcFrontParams& p, hipStream_t st) {
-  const size_t lds = 3 * 24 * 1024 + 2560;
-  const long grid = (d->M + 127) / 128;
-  auto k = rc_front_kernel<T>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)attr;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+  if ((d->dbg & 256) && d->rows_per_batch % 256 == 0) {      // dev A/B: one 8-wave workgroup per CU
+    const size_t lds = 4 * 24 * 1024 + 2560;
+    auto k = rc_front_kernel<T, 8>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)((d->M + 255) / 256)), dim3(512), lds, st, p);
+  } else {
+    const size_t lds = 3 * 24 * 1024 + 2560;
+    auto k = rc_front_kernel<T, 4>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k, dim3((unsigned)((d->M + 127) / 128)), dim3(256), lds, st, p);
+  }
   TG_LAUNCH_CHECK();
   return TG_OK;
 }
