@@ -33,7 +33,7 @@ def run(B, N, dtype, time_it=True):
            "v": rel(gvt[:, :, :N].permute(0, 2, 1).reshape(M, C), qkv[:, 640:])}
     if time_it:
         row["rc_front_us"] = round(timeit(lambda i: ops.rc_front(x, coef, winp, wqp, N, 1e-5, y=gy, qk=gqk, vt=gvt), n=10), 1)
-        for dbg in (1, 2, 4, 3, 7):
+        for dbg in (256, 7, 256 | 7):
             row[f"dbg{dbg}"] = round(timeit(lambda i: ops.rc_front(x, coef, winp, wqp, N, 1e-5, y=gy, qk=gqk, vt=gvt, dbg=dbg), n=10), 1)
         qk2 = torch.empty(M, 640, device=dev, dtype=dtype); vt2 = torch.empty(B, C, ldt, device=dev, dtype=dtype)
         from theatergen_amd.weights_pack import rc_pack
