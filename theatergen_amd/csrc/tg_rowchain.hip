@@ -300,8 +300,9 @@ __global__ __launch_bounds__(NW * 64) void rc_linear_kernel(RcLinearParams p) {
 //   O:  k-step 5m + 3 hh + gg (gg = 0, 1): head 2m+hh, d = 16 gg + 8 (j >> 2) + 4 hi + (j & 3)   (accumulator registers 8 gg .. 8 gg + 7);
 //       k-step 5m+2: j < 4 -> head 2m, d = 32 + 4 hi + j;  j >= 4 -> head 2m+1, d = 32 + 4 hi + j - 4.
 // Both are absorbed by the host-side row / column permutations of the packed weights (theatergen_amd/rowchain.py).
-// LDS: a ring of two 48-KiB slots fed by LDS-DMA: 5 to_q chunks (41 KiB), 4 head-PAIR K / V^T fragment sets of the wave's batch item
-// (48 KiB, packed by rc_kv_pack_kernel when the conditioning is projected), 5 to_out chunks (41 KiB).
+// LDS: a ring of three 24-KiB slots fed by LDS-DMA two stages ahead: 10 to_q tiles (21 KiB each), 8 per-head K / V^T fragment sets of the
+// workgroup's batch item (24 KiB, packed by rc_kv_pack_kernel when the conditioning is projected), 10 to_out tiles.  4-wave workgroups of 128
+// tokens, 72 KiB: two per CU (the first version — one 8-wave workgroup, two 48-KiB slots — took 67 us against this one's 55).
 struct RcXattnParams {
   const void* h;        // [M, 320] the stream before norm2 (= residual)
   long ldh;
