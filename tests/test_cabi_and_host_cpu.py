@@ -609,3 +609,71 @@ def test_rc_xattn_slot_maps_are_permutations():
             slots = [n for n in range(320) if perm[n] // 80 == m]
             ksteps = sorted({4 * (n // 64) + ((n // 8) & 3) for n in slots})
             assert ksteps == list(range(5 * m, 5 * m + 5))
+
+
+def test_pack_ff_streams_emulated():
+    """``rowchain.pack_ff`` against a CPU emulation of ``tg_rc_ff``'s index maps (csrc/tg_rowchain.hip): per 32-channel hidden slice the value /
+    gate tiles over the normalised rows (K order of ``rc_pack``), accumulator register rho of lane half hi = hidden channel 32 j + 16 hi + rho,
+    GEGLU, then net.2's block (tile t, k-step kk) contracts hidden channels 32 j + 16 hi + 8 kk + [0, 8) into output channel
+    64 c + 32 hi' + 16 u + rho (t = 2 c + u)."""
+    import torch
+    import torch.nn.functional as F
+    from theatergen_amd import rowchain
+    torch.manual_seed(1)
+    C, inner, M = 320, 64, 32
+    w1 = (torch.randn(2 * inner, C) / C ** 0.5).bfloat16()
+    b1 = 0.2 * torch.randn(2 * inner)
+    w2 = (torch.randn(C, inner) / inner ** 0.5).bfloat16()
+    b2 = 0.1 * torch.randn(C)
+    gamma, beta = 1 + 0.2 * torch.randn(C), 0.1 * torch.randn(C)
+    xn = torch.randn(M, C)                                           # already normalised rows (what the kernel forms in registers)
+    s1, s2, bb2 = rowchain.pack_ff(w1, b1, gamma, beta, w2, b2)
+    KS, ns = C // 16, inner // 32
+    assert s1.numel() == ns * 41 * 1024 + 3072 and s2.numel() == ns * 20 * 1024
+    out = bb2[None, :].repeat(M, 1).clone()
+
+    def mfma_rows(frag, Bm):                                         # frag [s][hi][r][j], Bm(s) -> [16, M]; returns D [32, M]
+        D = torch.zeros(32, M)
+        for s in range(frag.shape[0]):
+            A = torch.zeros(32, 16)
+            for hi in range(2):
+                A[:, 8 * hi:8 * hi + 8] = frag[s, hi]
+            D += A @ Bm(s)
+        return D
+
+    def b_rows(s):                                                   # the rows' B operand of k-step s
+        Bm = torch.zeros(16, M)
+        for hi in range(2):
+            ch = 64 * (s >> 2) + 32 * hi + 8 * (s & 3)
+            Bm[8 * hi:8 * hi + 8] = xn[:, ch:ch + 8].T
+        return Bm
+    for j in range(ns):
+        blk = s1[j * 41 * 1024:(j + 1) * 41 * 1024]
+        frag = blk[:40 * 1024].view(torch.bfloat16).float().reshape(2, KS, 2, 32, 8)      # [value / gate][s][hi][r][j]
+        page = blk[40 * 1024:].view(torch.float32)
+        Da, Dg = mfma_rows(frag[0], b_rows), mfma_rows(frag[1], b_rows)
+        hid = torch.zeros(M, 2, 16)                                   # [token][hi][rho]
+        for hi in range(2):
+            for rho in range(16):
+                r = (rho & 3) + 8 * (rho >> 2) + 4 * hi
+                a = Da[r] + page[16 * hi + rho]
+                g = Dg[r] + page[32 + 16 * hi + rho]
+                hid[:, hi, rho] = a * F.gelu(g)
+        f2 = s2[j * 20 * 1024:(j + 1) * 20 * 1024].view(torch.bfloat16).float().reshape(10, 2, 2, 32, 8)     # [t][kk][hi][r][j]
+        for t in range(10):
+            D = torch.zeros(32, M)
+            for kk in range(2):
+                A = torch.zeros(32, 16)
+                Bm = torch.zeros(16, M)
+                for hi in range(2):
+                    A[:, 8 * hi:8 * hi + 8] = f2[t, kk, hi]
+                    Bm[8 * hi:8 * hi + 8] = hid[:, hi, 8 * kk:8 * kk + 8].T
+                D += A @ Bm
+            c, u = t >> 1, t & 1
+            for hi in range(2):
+                for rho in range(16):
+                    out[:, 64 * c + 32 * hi + 16 * u + rho] += D[(rho & 3) + 8 * (rho >> 2) + 4 * hi]
+    w1g = (w1.float() * gamma[None, :]).bfloat16().float()          # rounded once, as the stream holds it
+    pr = xn @ w1g.T + (w1.float() @ beta + b1)
+    ref = (pr[:, :inner] * F.gelu(pr[:, inner:])) @ w2.float().T + b2
+    assert (out - ref).abs().max() < 2e-4
