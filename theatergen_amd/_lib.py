@@ -45,7 +45,7 @@ class AttnDesc(C.Structure):
 class RcLinearDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("x", vp), ("ldx", i64), ("wpk", vp), ("res", vp), ("ldres", i64),
-        ("out", vp), ("ldc", i64), ("M", i64), ("N", i32), ("K", i32), ("ln", i32), ("ln_eps", f32), ("variant", i32),
+        ("out", vp), ("ldc", i64), ("M", i64), ("N", i32), ("K", i32), ("ln", i32), ("ln_eps", f32), ("variant", i32), ("v640", vp), ("u640", vp),
     ]
 
 

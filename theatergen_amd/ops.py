@@ -190,13 +190,14 @@ def linear(x, w, bias=None, **kw):
     return gemm(x, w, M, N, K, bias=bias, **kw)
 
 
-def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0):
+def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0, v=None, u=None):
     """Row-chain projection (csrc/tg_rowchain.hip): out = [LayerNorm-folded] x @ W^T + v (+ res) with the token rows in registers;
     ``wpk`` = ``weights_pack.rc_pack(W, v, u)`` (uint8 chunk stream), x [M, 320]."""
     from ._lib import RcLinearDesc
     _need_cuda(x)
     M, K = x.shape
-    assert x.stride(1) == 1 and wpk.dtype == torch.uint8 and wpk.numel() == (N // 64) * (128 * K + 1024)
+    assert x.stride(1) == 1 and wpk.dtype == torch.uint8
+    assert wpk.numel() == ((N // 64) * (128 * K + 1024) if K == 320 else (N // 32) * 64 * K), (wpk.numel(), N, K)
     if out is None:
         out = torch.empty(M, N, dtype=x.dtype, device=x.device)
     d = RcLinearDesc()
@@ -207,6 +208,7 @@ def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0):
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.ln, d.ln_eps = (1, float(ln_eps)) if ln_eps is not None else (0, 0.0)
     d.variant = int(variant)
+    d.v640, d.u640 = _ptr(v), _ptr(u)        # K = 640 only: fp32 vectors outside the tile stream
     _profiled(lambda: _lib.check(_lib.lib().tg_rc_linear(C.byref(d), _stream())), "rc_linear_kernel<320>" + ("+ln" if ln_eps is not None else ""),
               M, N, K, 2.0 * M * N * K, res is not None)
     return out

@@ -80,7 +80,7 @@ def rc_pack(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = None) -> 
     return torch.cat([fb, page.view(torch.uint8)], dim=1).contiguous().reshape(-1)
 
 
-def rc_pack_tiles(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = None) -> torch.Tensor:
+def rc_pack_tiles(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = None, page: bool = True) -> torch.Tensor:
     """As ``rc_pack`` but one stream element per 32-row MFMA TILE (tile t = 2 c + u of chunk c): K / 16 fragment blocks, then a 1-KiB
     vector page with fp32 v[32] and u[32] in the tile's accumulator order (index 16 hi + rho <-> channel 64 c + 32 hi + 16 u + rho);
     3 KiB of zero padding behind the last tile (the consumer fetches every (K / 16 + 1)-KiB tile as a 24-KiB stage)."""
@@ -91,6 +91,8 @@ def rc_pack_tiles(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = Non
     kap = kap.to(w.device)
     frag = w.detach()[rows[:, :, None, None, :, None], kap[None, None, :, :, None, :]].contiguous()   # [c, u, s, hi, r, j]
     fb = frag.reshape(n // 32, -1).view(torch.uint8)                                      # [tile, 64 K bytes]
+    if not page:                       # K = 640 streams (tg_rc_linear): four 40-KiB tiles fill the LDS, the vectors travel as plain fp32 arrays
+        return fb.contiguous().reshape(-1)
     page = torch.zeros(n // 32, 256, dtype=torch.float32, device=w.device)
 
     def tile_order(x):      # [N] -> [tile = 2 c + u, 16 hi + rho]
