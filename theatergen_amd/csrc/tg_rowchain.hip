@@ -827,22 +827,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   float ln_rstd = 1.f, ln_std = 1.f, ln_nmean = 0.f;
   // stores produced by stage k (issued at the top of stage k + 1): a finished 64-channel chunk = 4 x 16 bytes, a V tile = 16 x 2 bytes
-  auto n_stores = [](int k) { return k < 0 ? 0 : k < 30 ? ((k & 1) ? 4 : 0) : k < NST ? 16 : 0; };
+  auto n_stores = [](int k) { return k < 10 ? 0 : k < 30 ? ((k & 1) ? 4 : 0) : k < NST ? 16 : 0; };
+  // y stores issued IN stage k (right behind its weight pieces): chunk k - 10 of the finished proj_in output, once the rows' registers are free
+  auto y_stores = [](int k) { return k >= 10 && k < 15 ? 4 : 0; };
   // operations issued behind stage st's pieces when stage st begins: the deferred stores of stages st - DEPTH - 1 .. st - 2 and the pieces of the stages
   // fetched since (st + 1 .. st + DEPTH - 1)
   auto younger_of = [&](int st) __attribute__((always_inline)) {
     int y = 0;
     for (int k = st - DEPTH - 1; k <= st - 2; ++k) y += n_stores(k);
+    for (int k = st - DEPTH; k <= st - 1; ++k) y += y_stores(k);
     for (int j = st + 1; j <= st + DEPTH - 1; ++j) y += j < NST ? PPW : 0;
     return y;
   };
-  // counted wait (the value is a compile-time constant after unrolling; the cases cover every sum that occurs for NW = 4 and 8)
+  // counted wait (the value is a compile-time constant after unrolling)
   auto wait_vm = [&](int n) __attribute__((always_inline)) {
     switch (n) {
 #define TG_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-      TG_VM_CASE(54) TG_VM_CASE(51) TG_VM_CASE(48) TG_VM_CASE(42) TG_VM_CASE(39) TG_VM_CASE(38) TG_VM_CASE(36) TG_VM_CASE(35) TG_VM_CASE(32)
-      TG_VM_CASE(30) TG_VM_CASE(26) TG_VM_CASE(23) TG_VM_CASE(22) TG_VM_CASE(20) TG_VM_CASE(19) TG_VM_CASE(16) TG_VM_CASE(14) TG_VM_CASE(12)
-      TG_VM_CASE(11) TG_VM_CASE(10) TG_VM_CASE(8) TG_VM_CASE(7) TG_VM_CASE(6) TG_VM_CASE(4) TG_VM_CASE(3)
+      TG_VM_CASE(1) TG_VM_CASE(2) TG_VM_CASE(3) TG_VM_CASE(4) TG_VM_CASE(5) TG_VM_CASE(6) TG_VM_CASE(7) TG_VM_CASE(8) TG_VM_CASE(9) TG_VM_CASE(10) TG_VM_CASE(11) TG_VM_CASE(12) TG_VM_CASE(13) TG_VM_CASE(14) TG_VM_CASE(15)
+      TG_VM_CASE(16) TG_VM_CASE(17) TG_VM_CASE(18) TG_VM_CASE(19) TG_VM_CASE(20) TG_VM_CASE(21) TG_VM_CASE(22) TG_VM_CASE(23) TG_VM_CASE(24) TG_VM_CASE(25) TG_VM_CASE(26) TG_VM_CASE(27) TG_VM_CASE(28) TG_VM_CASE(29) TG_VM_CASE(30) TG_VM_CASE(31)
+      TG_VM_CASE(32) TG_VM_CASE(33) TG_VM_CASE(34) TG_VM_CASE(35) TG_VM_CASE(36) TG_VM_CASE(37) TG_VM_CASE(38) TG_VM_CASE(39) TG_VM_CASE(40) TG_VM_CASE(41) TG_VM_CASE(42) TG_VM_CASE(43) TG_VM_CASE(44) TG_VM_CASE(45) TG_VM_CASE(46) TG_VM_CASE(47)
+      TG_VM_CASE(48) TG_VM_CASE(49) TG_VM_CASE(50) TG_VM_CASE(51) TG_VM_CASE(52) TG_VM_CASE(53) TG_VM_CASE(54) TG_VM_CASE(55) TG_VM_CASE(56) TG_VM_CASE(57) TG_VM_CASE(58) TG_VM_CASE(59) TG_VM_CASE(60) TG_VM_CASE(61) TG_VM_CASE(62) TG_VM_CASE(63)
 #undef TG_VM_CASE
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -850,15 +854,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   V8 pend[4];
   auto flush = [&](int k) __attribute__((always_inline)) {      // the stores of stage k
     if (k < 0 || n_stores(k) == 0) return;
-    if ((k >= 30 && (p.dbg & 1)) || (k >= 10 && k < 30 && (p.dbg & 2)) || (k < 10 && (p.dbg & 4))) return;
+    if ((k >= 30 && (p.dbg & 1)) || (k < 30 && (p.dbg & 2))) return;
     if (k < 30) {
-      T* base = reinterpret_cast<T*>(k < 10 ? p.y : p.qk);
+      T* base = reinterpret_cast<T*>(p.qk);
       asm volatile("" : "+s"(base));
-      const long ld = k < 10 ? p.ldy : p.ldqk;
-      const long ch0 = 64 * (long)((k < 10 ? k : k - 10) >> 1) + 32 * hi;
+      const long ch0 = 64 * (long)((k - 10) >> 1) + 32 * hi;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (mok[i]) *reinterpret_cast<V8*>(base + mrow[i] * ld + ch0 + 8 * qb) = pend[i];
+        if (mok[i]) *reinterpret_cast<V8*>(base + mrow[i] * p.ldqk + ch0 + 8 * qb) = pend[i];
     } else {
       // V tile t = k - 30 (chunk c = t >> 1, tile u = t & 1): register rho = channel 64 c + 32 hi + 16 u + rho, lane = token
       T* vb = reinterpret_cast<T*>(p.vt);
@@ -911,18 +914,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   };
 
   // ---- proj_in: Y = B operands of the q|k|v phase, and the stream the block's residual adds read back
+  // (y itself is stored from the first five q | k | v stages: while the rows AND the growing Y are live there is no room for transposed copies)
   V8 Y[KS];
-  V8 half[2];
 #pragma unroll
   for (int t = 0; t < 10; ++t) {
     stage_begin(t);
     const f32x16 acc = tile_stream(smem + (t % NSLOT) * SLOT, X, false, std::integral_constant<int, 4>{});
     Y[2 * t] = pack8r<T>(acc, 0);
     Y[2 * t + 1] = pack8r<T>(acc, 8);
-    if (t & 1) {
-      pend[0] = Y[2 * t - 2]; pend[1] = Y[2 * t - 1]; pend[2] = Y[2 * t]; pend[3] = Y[2 * t + 1];
-      quad_transpose(pend[0], pend[1], pend[2], pend[3]);
-    }
+    // opaque: hipcc otherwise ALSO keeps the sixteen rounded values unpacked for the LayerNorm statistics below (160 registers, all spilled)
+    asm volatile("" : "+v"(Y[2 * t]), "+v"(Y[2 * t + 1]));
   }
   {
     float sum = 0.f;
@@ -947,6 +948,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   // ---- q | k | v (LayerNorm folded).  The rounding / packing / transposing of tile t - 1 runs in stage t BEHIND the first fragment and seed
   // reads of tile t (a lone wave otherwise sits out one LDS round trip per stage before its first MFMA), its stores right behind that.
+  V8 half[2];
   auto qkv_epilogue = [&](int t, f32x16 acc) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
@@ -961,6 +963,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       pend[0] = pack8r<T>(acc, 0); pend[1] = pack8r<T>(acc, 8);
     }
   };
+  auto y_chunk_store = [&](int c) __attribute__((always_inline)) {
+    if (p.dbg & 4) return;
+    V8 t0 = Y[4 * c], t1 = Y[4 * c + 1], t2 = Y[4 * c + 2], t3 = Y[4 * c + 3];
+    quad_transpose(t0, t1, t2, t3);
+    T* base = reinterpret_cast<T*>(p.y);
+    asm volatile("" : "+s"(base));
+    const long ch0 = 64 * (long)c + 32 * hi + 8 * qb;
+    if (mok[0]) *reinterpret_cast<V8*>(base + mrow[0] * p.ldy + ch0) = t0;
+    if (mok[1]) *reinterpret_cast<V8*>(base + mrow[1] * p.ldy + ch0) = t1;
+    if (mok[2]) *reinterpret_cast<V8*>(base + mrow[2] * p.ldy + ch0) = t2;
+    if (mok[3]) *reinterpret_cast<V8*>(base + mrow[3] * p.ldy + ch0) = t3;
+  };
   f32x16 acc_prev;
 #pragma unroll
   for (int t = 0; t < 30; ++t) {
@@ -968,6 +982,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     wait_vm(younger_of(st));
     __builtin_amdgcn_s_barrier();
     issue_stage(st + DEPTH);
+    if (y_stores(st)) { y_chunk_store(t); __builtin_amdgcn_sched_barrier(0); }
     constexpr int PD = 8;
     const char* cbase = smem + (st % NSLOT) * SLOT;
     const char* cb = cbase + lane * 16;
