@@ -46,6 +46,14 @@ struct RcLinearParams {
 // GEMM / conv kernels give XCD x a CONTIGUOUS eighth of the token rows (tg_gemm_common.h), so a row-chain kernel that sits between them must
 // use the same partition — with the natural order its output is striped over the eight L2s and the next kernel finds none of its rows in
 // its own L2 (measured: the rc_linear swaps alone made the graph-replayed step 1.4 % SLOWER although each launch is 20 % shorter).
+// Global-address-space accesses through a pointer whose provenance hipcc cannot see (the opaque `asm("" : "+s"(ptr))` copies below): a plain dereference
+// becomes a FLAT instruction, which counts in lgkmcnt as well as vmcnt — the next `s_waitcnt lgkmcnt(0)` in front of an LDS fragment's first MFMA then sits out a
+// whole global-memory round trip.
+template <typename V>
+__device__ __forceinline__ V gld(const void* ptr) { return *(const __attribute__((address_space(1))) V*)ptr; }
+template <typename V>
+__device__ __forceinline__ void gst(void* ptr, V v) { *(__attribute__((address_space(1))) V*)ptr = v; }
+
 __device__ __forceinline__ int rc_block_id(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7;
   const int xcd = bid & 7;
@@ -628,10 +636,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (c > 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb) = pend[i];
+            if (mok[i]) gst<V8>(outp + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb, pend[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(hp + mrow[i] * p.ldh + ch0 + 8 * qb);
+        for (int i = 0; i < 4; ++i) r8[i] = gld<V8>(hp + mrow[i] * p.ldh + ch0 + 8 * qb);
       }
       f32x16 acc;
       if (!(p.dbg & 4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false, std::integral_constant<int, 8>{});
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const long ch0 = 64 * (long)((k - 10) >> 1) + 32 * hi;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (mok[i]) *reinterpret_cast<V8*>(base + mrow[i] * p.ldqk + ch0 + 8 * qb) = pend[i];
+        if (mok[i]) gst<V8>(base + mrow[i] * p.ldqk + ch0 + 8 * qb, pend[i]);
     } else {
       // V tile t = k - 30 (chunk c = t >> 1, tile u = t & 1): register rho = channel 64 c + 32 hi + 16 u + rho, lane = token
       T* vb = reinterpret_cast<T*>(p.vt);
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       T* vrow = vb + (bi * 320 + 64 * (t >> 1) + 32 * hi + 16 * (t & 1)) * p.ldt + tin;
       if (tok < p.M) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vrow[(long)r * p.ldt] = pend[r >> 3][r & 7];
+        for (int r = 0; r < 16; ++r) gst<T>(vrow + (long)r * p.ldt, pend[r >> 3][r & 7]);
       }
     }
   };
@@ -970,10 +978,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     T* base = reinterpret_cast<T*>(p.y);
     asm volatile("" : "+s"(base));
     const long ch0 = 64 * (long)c + 32 * hi + 8 * qb;
-    if (mok[0]) *reinterpret_cast<V8*>(base + mrow[0] * p.ldy + ch0) = t0;
-    if (mok[1]) *reinterpret_cast<V8*>(base + mrow[1] * p.ldy + ch0) = t1;
-    if (mok[2]) *reinterpret_cast<V8*>(base + mrow[2] * p.ldy + ch0) = t2;
-    if (mok[3]) *reinterpret_cast<V8*>(base + mrow[3] * p.ldy + ch0) = t3;
+    if (mok[0]) gst<V8>(base + mrow[0] * p.ldy + ch0, t0);
+    if (mok[1]) gst<V8>(base + mrow[1] * p.ldy + ch0, t1);
+    if (mok[2]) gst<V8>(base + mrow[2] * p.ldy + ch0, t2);
+    if (mok[3]) gst<V8>(base + mrow[3] * p.ldy + ch0, t3);
   };
   f32x16 acc_prev;
 #pragma unroll
@@ -1495,7 +1503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int c = 0; c < 5; ++c) {
       V8 hr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hr[i] = *reinterpret_cast<const V8*>(xp + mrow[i] * p.ldh + 64 * c);
+      for (int i = 0; i < 4; ++i) hr[i] = gld<V8>(xp + mrow[i] * p.ldh + 64 * c);
       quad_transpose(hr[0], hr[1], hr[2], hr[3]);
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu)
@@ -1555,10 +1563,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (c > 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (mok[i]) *reinterpret_cast<V8*>(op + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb) = pend[i];
+              if (mok[i]) gst<V8>(op + mrow[i] * p.ldc + (ch0 - 64) + 8 * qb, pend[i]);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(rp + mrow[i] * p.ldres + ch0 + 8 * qb);
+          for (int i = 0; i < 4; ++i) r8[i] = gld<V8>(rp + mrow[i] * p.ldres + ch0 + 8 * qb);
         }
         const char* cbase = smem + (st % 3) * SLOT;
         const char* cb = cbase + lane * 16;
