@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 303
+#define TG_ABI_VERSION 304
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -463,6 +463,41 @@ typedef struct {
   int32_t dbg;     /* dev timing switches, 0 */
 } tg_rc_front_desc;
 int tg_rc_front(const tg_rc_front_desc* d, void* stream);
+
+/* tg_skinny_gemm (round 4, csrc/tg_skinny.hip): out[m, :] = act([LayerNorm-folded] x[m, :] W^T + bias) + res[m, :] for a handful of rows — the latent path of
+ * the Perceiver Resampler (ip_adapter/resampler.py:13-20 FeedForward, :45-47 to_q / to_kv / to_out, :62-78 forward, :94-97 proj_out: 16 latents x (cond, zero image))
+ * and other M <= 32 linears.  `wpk`: theatergen_amd.weights_pack.skinny_pack(W [N, K]) = N / 32 x K / 16 fragment blocks of 64 lanes x 8 elements; the 32 rows are
+ * the MFMA B operand in registers, weights go global -> registers in whole-KiB loads, a workgroup = one 32-column tile (8 or 4 waves split K), grid.y = row blocks of 32.
+ * Fold (`ln` != 0, K / 64 or K / 128 in {1, 2, 3, 5, 6, 8, 10, 12, 16, 20}): x is the un-normalised stream, W pre-multiplied by gamma, ln_u[n] = row sums of the ROUNDED W gamma,
+ * ln_v[n] = W beta (+ bias), statistics two-pass in fp32 (weights_pack.pack_ln_linear).  Epilogue order as tg_gemm: ((acc + bias) + res), act, one rounding.
+ * Output routing: `nseg` column segments [seg[i-1].n_end, seg[i].n_end) (multiples of 32), element (m, n) of segment i goes to
+ *     ptr + (m / rows_per_batch) * batch_stride + (transposed ? (n - n0) * ld + m % rows_per_batch : (m % rows_per_batch) * ld + (n - n0))
+ * — q, the latents' K rows behind the image tokens' rows, and their V^T columns from ONE launch (resampler.py:63-68 `cat((x, latents), dim=-2)` without a copy). */
+typedef struct {
+  void* ptr;
+  int64_t ld;
+  int64_t batch_stride;
+  int32_t n_end;
+  int32_t transposed;
+} tg_skinny_seg;
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  const void* wpk;
+  int64_t M;
+  int32_t N, K;
+  int32_t ln;
+  float ln_eps;
+  const float* ln_u;
+  const float* ln_v;
+  const void* bias;        /* storage dtype [N] or NULL */
+  int32_t act;             /* TG_ACT_* */
+  const void* res; int64_t ldres;
+  int32_t nseg;
+  int32_t rows_per_batch;
+  tg_skinny_seg seg[3];
+} tg_skinny_desc;
+int tg_skinny_gemm(const tg_skinny_desc* d, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

@@ -677,3 +677,27 @@ def test_pack_ff_streams_emulated():
     pr = xn @ w1g.T + (w1.float() @ beta + b1)
     ref = (pr[:, :inner] * F.gelu(pr[:, inner:])) @ w2.float().T + b2
     assert (out - ref).abs().max() < 2e-4
+
+
+def test_skinny_pack_layout():
+    """``weights_pack.skinny_pack``: block (nt, ks), lane (hi, l31), element j = W[32 nt + l31, 16 ks + 8 hi + j] — the A fragment of a 32x32x16 MFMA as one
+    contiguous KiB (csrc/tg_skinny.hip reads ``wpk + ((nt * K / 16 + ks) * 64 + lane) * 8``)."""
+    import torch
+    from theatergen_amd.weights_pack import skinny_pack
+    torch.manual_seed(1)
+    N, K = 96, 128
+    W = torch.randn(N, K).to(torch.bfloat16)
+    pk = skinny_pack(W).reshape(N // 32, K // 16, 64, 8)
+    for nt, ks, lane in [(0, 0, 0), (2, 7, 63), (1, 3, 37), (2, 0, 31), (0, 5, 32)]:
+        hi, l31 = lane >> 5, lane & 31
+        assert torch.equal(pk[nt, ks, lane], W[32 * nt + l31, 16 * ks + 8 * hi:16 * ks + 8 * hi + 8])
+    # the whole product through the emulated fragment order: sum over ks of A_frag^T B_frag
+    x = torch.randn(32, K).to(torch.bfloat16)
+    ref = x.float() @ W.float().t()
+    got = torch.zeros(32, N)
+    for nt in range(N // 32):
+        for ks in range(K // 16):
+            a = pk[nt, ks].reshape(2, 32, 8).float()                     # [hi, out row, j]
+            bfr = x[:, 16 * ks:16 * ks + 16].reshape(32, 2, 8).float()   # [token, hi, j]
+            got[:, 32 * nt:32 * nt + 32] += torch.einsum("hrj,thj->tr", a, bfr)
+    assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4)

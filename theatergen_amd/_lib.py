@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 303          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 304          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -60,6 +60,17 @@ class RcFfDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("h", vp), ("ldh", i64), ("w1", vp), ("w2", vp), ("b2", vp), ("wpo", vp), ("res0", vp), ("ldres", i64),
         ("out", vp), ("ldc", i64), ("M", i64), ("inner", i32), ("ln_eps", f32), ("dbg", i32),
+    ]
+
+
+class SkinnySeg(C.Structure):
+    _fields_ = [("ptr", vp), ("ld", i64), ("batch_stride", i64), ("n_end", i32), ("transposed", i32)]
+
+
+class SkinnyDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("x", vp), ("ldx", i64), ("wpk", vp), ("M", i64), ("N", i32), ("K", i32), ("ln", i32), ("ln_eps", f32), ("ln_u", vp), ("ln_v", vp),
+        ("bias", vp), ("act", i32), ("res", vp), ("ldres", i64), ("nseg", i32), ("rows_per_batch", i32), ("seg", SkinnySeg * 3),
     ]
 
 
@@ -135,6 +146,7 @@ SIGNATURES = {
     "tg_rc_kv_pack": (i32, [i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp]),
     "tg_rc_ff": (i32, [C.POINTER(RcFfDesc), vp]),
     "tg_rc_front": (i32, [C.POINTER(RcFrontDesc), vp]),
+    "tg_skinny_gemm": (i32, [C.POINTER(SkinnyDesc), vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

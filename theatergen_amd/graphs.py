@@ -20,8 +20,11 @@ class GraphedCall:
         key = (tuple(x.shape), x.dtype, x.device, self.weights_key())
         hit = self._graphs.get(key)
         if hit is None:
-            static_in = x.detach().clone().contiguous()
-            with torch.no_grad():
+            # Capture OUTSIDE inference mode: the callers (``IPAdapter.get_image_embeds``, reference ip_adapter.py:143) run under ``torch.inference_mode()``, and a
+            # first capture there creates PyTorch's graph-safe RNG state as inference tensors — every later capture outside inference mode (the denoising
+            # engine's) then fails with "Inplace update to inference tensor outside InferenceMode".  Replays are mode-agnostic.
+            with torch.inference_mode(False), torch.no_grad():
+                static_in = x.detach().clone().contiguous()
                 side = torch.cuda.Stream(device=x.device)
                 side.wait_stream(torch.cuda.current_stream(x.device))
                 with torch.cuda.stream(side):

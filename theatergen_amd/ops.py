@@ -296,6 +296,33 @@ def rc_front(x, coef, win, wqkv, rows_per_batch, ln_eps, y=None, qk=None, vt=Non
     return y, qk, vt, int(vt.stride(1))
 
 
+def skinny_gemm(x, wpk, N, *, ln=None, bias=None, act=ACT_NONE, res=None, out=None, segs=None, rows_per_batch=None):
+    """A handful of rows against a fragment-packed weight (``weights_pack.skinny_pack``); see tg_skinny_gemm.  ``ln`` = (u fp32 [N], v fp32 [N], eps): x is the
+    un-normalised stream.  ``segs``: up to three ``(tensor_or_pointer, ld, batch_stride, n_end, transposed)`` output segments (default: one plain [M, N] tensor,
+    returned).  Output pointers in ``segs`` are raw addresses (``tensor.data_ptr() + byte offset``): the caller keeps the tensors alive."""
+    from ._lib import SkinnyDesc
+    _need_cuda(x)
+    M, K = x.shape
+    assert x.stride(1) == 1 and wpk.numel() == N * K, (x.shape, wpk.numel(), N)
+    d = SkinnyDesc()
+    d.dtype, d.x, d.ldx, d.wpk, d.M, d.N, d.K = _dt(x), _ptr(x), int(x.stride(0)), _ptr(wpk), int(M), int(N), int(K)
+    if ln is not None:
+        d.ln, d.ln_u, d.ln_v, d.ln_eps = 1, _ptr(ln[0]), _ptr(ln[1]), float(ln[2])
+    d.bias, d.act = _ptr(bias), int(act)
+    if res is not None:
+        d.res, d.ldres = _ptr(res), int(res.stride(0))
+    if segs is None:
+        if out is None:
+            out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        segs = [(out.data_ptr(), int(out.stride(0)), 0, N, 0)]
+        rows_per_batch = M
+    d.nseg, d.rows_per_batch = len(segs), int(rows_per_batch)
+    for i, (ptr, ld, bs, n_end, tr) in enumerate(segs):
+        d.seg[i].ptr, d.seg[i].ld, d.seg[i].batch_stride, d.seg[i].n_end, d.seg[i].transposed = int(ptr), int(ld), int(bs), int(n_end), int(tr)
+    _lib.check(_lib.lib().tg_skinny_gemm(C.byref(d), _stream()))
+    return out
+
+
 def conv3x3(x, w_packed, batch, in_h, in_w, cin, *, x1=None, c1=0, stride=1, upsample=False, bias=None, pad_mode=0, **kw):
     """3x3 pad-1 convolution as implicit GEMM over token-major x [batch*in_h*in_w, cin] (+ optional concat x1).
     w_packed: [cout, 9*(cin+c1)] tap-major.  ``pad_mode=1``: zero padding on the bottom / right edge only (the VAE

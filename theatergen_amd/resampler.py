@@ -14,7 +14,10 @@ twice: LN(x) and LN(latents) are written into one [b, n1+n2, D] buffer by the La
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
+from .weights_pack import pack_ln_linear, skinny_pack
 
 
 def _round8(n):
@@ -32,6 +35,46 @@ class PerceiverAttention(nn.Module):
         self.to_q = nn.Linear(dim, inner, bias=False)
         self.to_kv = nn.Linear(dim, inner * 2, bias=False)
         self.to_out = nn.Linear(inner, dim, bias=False)
+
+    def packed(self):
+        """kernel-layout weights of the skinny path, rebuilt when the parameters change: to_kv with norm1 folded (image-token rows, tg_gemm), [to_q ; to_kv] with
+        norm2 folded and to_out in tg_skinny_gemm's fragment order"""
+        ps = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight]
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ps)
+        hit = getattr(self, "_pk", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wx, ux, vx = pack_ln_linear(self.to_kv.weight, None, self.norm1.weight, self.norm1.bias)
+                wl, ul, vl = pack_ln_linear(torch.cat([self.to_q.weight, self.to_kv.weight], dim=0), None, self.norm2.weight, self.norm2.bias)
+                hit = (key, dict(kv_x=(wx, ux, vx), qkv_lat=(skinny_pack(wl), ul, vl), out=skinny_pack(self.to_out.weight)))
+            self._pk = hit
+        return hit[1]
+
+    def kv_image(self, xp_pad, b, L, k, vt, ldt):
+        """K rows / V^T columns of the image tokens (norm1 folded into to_kv; independent of the latents: all layers' calls are issued up front).  ``xp_pad`` is
+        [b * L, D] with the latents' slots as padding rows, so the output rows are the attention's K rows one to one; the latents' slots are overwritten by
+        ``run_skinny``."""
+        wx, ux, vx = self.packed()["kv_x"]
+        inner = self.dim_head * self.heads
+        ops.gemm(xp_pad, wx, b * L, 2 * inner, xp_pad.shape[1], rows_per_batch=L, out=k, n_split=inner, out_t=vt, ldt=ldt, ln=(ux, vx, self.norm1.eps))
+
+    def run_skinny(self, lat2d, b, n1, n2, k, vt, ldt):
+        """latents [b * n2, D] -> to_out(attn) + latents; K / V^T hold the image tokens' part already (``kv_image``).  Three launches: [q | k | v] of the latents
+        (norm2 folded, routed into q and behind the image rows / columns of K / V^T: resampler.py:63-68 without the concat), attention, to_out + residual."""
+        pk = self.packed()
+        inner = self.dim_head * self.heads
+        L = n1 + n2
+        es = lat2d.element_size()
+        q = torch.empty((b * n2, inner), dtype=lat2d.dtype, device=lat2d.device)
+        wl, ul, vl = pk["qkv_lat"]
+        ops.skinny_gemm(lat2d, wl, 3 * inner, ln=(ul, vl, self.norm2.eps), rows_per_batch=n2,
+                        segs=[(q.data_ptr(), inner, n2 * inner, inner, 0),
+                              (k.data_ptr() + n1 * inner * es, inner, L * inner, 2 * inner, 0),
+                              (vt.data_ptr() + n1 * es, ldt, inner * ldt, 3 * inner, 1)])
+        o = torch.empty((b * n2, inner), dtype=lat2d.dtype, device=lat2d.device)
+        ops.attention(q, inner, n2 * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, b, self.heads, self.dim_head, n2,
+                      self.scale, o, inner, n2 * inner)
+        return ops.skinny_gemm(o, pk["out"], lat2d.shape[1], res=lat2d)
 
     def run(self, x2d, lat2d, b, n1, n2, residual):
         """x2d [b*n1, D] image features, lat2d [b*n2, D] latents -> to_out(attn) + residual, [b*n2, D]."""
@@ -59,6 +102,25 @@ class PerceiverAttention(nn.Module):
 def FeedForward(dim, mult=4):
     inner = int(dim * mult)
     return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner, bias=False), nn.GELU(), nn.Linear(inner, dim, bias=False))
+
+
+def _ff_packed(ff):
+    ps = [ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight]
+    key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ps)
+    hit = getattr(ff, "_pk", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            w1, u1, v1 = pack_ln_linear(ff[1].weight, None, ff[0].weight, ff[0].bias)
+            hit = (key, (skinny_pack(w1), u1, v1, skinny_pack(ff[3].weight)))
+        ff._pk = hit
+    return hit[1]
+
+
+def _ff_run_skinny(ff, x2d):
+    """LayerNorm folded into the first projection (+ GELU), second projection + residual: two launches (resampler.py:13-20)"""
+    w1, u1, v1, w2 = _ff_packed(ff)
+    h = ops.skinny_gemm(x2d, w1, ff[1].weight.shape[0], ln=(u1, v1, ff[0].eps), act=ops.ACT_GELU)
+    return ops.skinny_gemm(h, w2, x2d.shape[1], res=x2d)
 
 
 def _ff_run(ff, x2d):
@@ -98,6 +160,8 @@ class Resampler(nn.Module):
             x2d = torch.cat([ops.add(x2d[i * n1:(i + 1) * n1], pe) for i in range(b)], dim=0)
         D = self.proj_in.weight.shape[0]
         nq = self.latents.shape[1]
+        if self._skinny_ok(b, n1, D):
+            return self._forward_skinny(x, b, n1, E, D, nq)
         xp = ops.linear(x2d, self.proj_in.weight, self.proj_in.bias)                    # [b*n1, D]
         n2 = nq + self.num_latents_mean_pooled
         lat = torch.empty((b, n2, D), dtype=dt, device=x.device)
@@ -126,6 +190,60 @@ class Resampler(nn.Module):
         return out.reshape(b, n2, -1)
 
     __call__ = forward
+
+    def _skinny_ok(self, b, n1, D):
+        """the IP-Adapter-Plus configurations (no positional embedding, no mean-pooled latents: ip_adapter.py:326-337): latent path on tg_skinny_gemm"""
+        if os.environ.get("TG_RESAMPLER_SKINNY", "1") == "0" or self.pos_emb is not None or self.num_latents_mean_pooled:
+            return False
+        a0, f0 = self.layers[0][0], self.layers[0][1]
+        inner, hidden, odim = a0.dim_head * a0.heads, f0[1].weight.shape[0], self.proj_out.weight.shape[0]
+        return (D % 64 == 0 and (D // 64 in (1, 2, 3, 5, 6, 8, 10, 12, 16, 20) or (D % 128 == 0 and D // 128 in (1, 2, 3, 5, 6, 8, 10, 12, 16, 20))) and inner % 64 == 0 and hidden % 64 == 0 and odim % 32 == 0
+                and self.proj_in.weight.shape[1] % 8 == 0)
+
+    def _forward_skinny(self, x, b, n1, E, D, nq):
+        """Same function as ``forward``'s generic path (tests compare the two), 28 launches instead of 48:
+        * image tokens: proj_in over a [b, n1 + nq, E] buffer whose last nq rows per item are padding, then per layer ONE LayerNorm-folded to_kv GEMM writing K rows /
+          V^T columns in place (independent of the latents: issued up front);
+        * latents (b x nq <= a few times 32 rows): tg_skinny_gemm for every projection — norm2 + [q | k | v] routed behind the image rows, to_out + residual,
+          norm + FeedForward in two launches, proj_out."""
+        dt = self.proj_in.weight.dtype
+        dev = x.device
+        L = n1 + nq
+        x_pad = torch.zeros((b, L, E), dtype=dt, device=dev)       # (allocated per call: a cached buffer would tie later calls to the grad / inference mode of the first)
+        x_pad[:, :n1].copy_(x)
+        xp = ops.linear(x_pad.reshape(b * L, E), self.proj_in.weight, self.proj_in.bias)      # [b * L, D]; the padding rows hold the bias (finite)
+        ldt = _round8(L)
+        kvs = []
+        for attn, _ in self.layers:
+            inner = attn.dim_head * attn.heads
+            kvs.append((torch.empty((b * L, inner), dtype=dt, device=dev), torch.empty((b, inner, ldt), dtype=dt, device=dev)))
+        # the image tokens' K / V^T of layer 0 on this stream, of the later layers on a side stream UNDER the first layer's latent chain (they only need xp)
+        cur = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != dev:
+            side = self._side = torch.cuda.Stream(device=dev)
+        self.layers[0][0].kv_image(xp, b, L, kvs[0][0], kvs[0][1], ldt)
+        if len(self.layers) > 1:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for (attn, _), (k, vt) in zip(list(self.layers)[1:], kvs[1:]):
+                    attn.kv_image(xp, b, L, k, vt, ldt)
+        lat2d = self.latents.to(dt).expand(b, nq, D).reshape(b * nq, D).contiguous()
+        for i, ((attn, ff), (k, vt)) in enumerate(zip(self.layers, kvs)):
+            if i == 1:
+                cur.wait_stream(side)
+            lat2d = attn.run_skinny(lat2d, b, n1, nq, k, vt, ldt)
+            lat2d = _ff_run_skinny(ff, lat2d)
+        pk = getattr(self, "_pk_out", None)
+        w = self.proj_out.weight
+        okey = (w.data_ptr(), w._version, w.dtype, w.device)
+        if pk is None or pk[0] != okey:
+            with torch.no_grad():
+                pk = (okey, skinny_pack(w))
+            self._pk_out = pk
+        out = ops.skinny_gemm(lat2d, pk[1], w.shape[0], bias=self.proj_out.bias)
+        out = ops.layernorm(out, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
+        return out.reshape(b, nq, -1)
 
     def graphed(self, x):
         """The same forward replayed from a hipGraph captured per (input shape, dtype, weights): one graph launch instead of ~40

@@ -103,3 +103,11 @@ def rc_pack_tiles(w: torch.Tensor, v: torch.Tensor = None, u: torch.Tensor = Non
         page[:, 32:64] = tile_order(u)
     out = torch.cat([fb, page.view(torch.uint8)], dim=1).contiguous().reshape(-1)
     return torch.cat([out, torch.zeros(3 * 1024, dtype=torch.uint8, device=w.device)])
+
+
+def skinny_pack(w: torch.Tensor) -> torch.Tensor:
+    """Linear weight [N, K] (N % 32 == 0, K % 16 == 0) -> tg_skinny_gemm's fragment order: block (nt, ks) = 64 lanes x 8 elements, lane (hi, l31), element j =
+    W[32 nt + l31, 16 ks + 8 hi + j] — the A operand of one 32x32x16 MFMA as ONE contiguous KiB, so the weight stream is whole-line loads in K order."""
+    n, k = w.shape
+    assert n % 32 == 0 and k % 16 == 0, (n, k)
+    return w.detach().reshape(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
