@@ -10,6 +10,8 @@ history row itself, so the 50-step loop is 50 graph replays with no host<->devic
 and copies latents to the CPU every step).  Any number of independent character images ride in the batch
 dimension (CFG batch 2*n: all uncond rows first, then all cond rows = ``noise_pred.chunk(2)`` order).
 """
+import os
+
 import torch
 
 from . import ops
@@ -90,6 +92,8 @@ class DenoiseEngine:
         self.graph = None
         self._graph_sig = None
         self.pred_type = 0 if self.scheduler.config.prediction_type == "epsilon" else 1
+        self._tproj_table = None
+        self._tproj_key = None
 
     # ---- conditioning -----------------------------------------------------------------------------------
     def set_conditioning(self, encoder_hidden_states, added_cond_kwargs=None):
@@ -140,6 +144,34 @@ class DenoiseEngine:
             self.graph = None          # frozen_steps is a launch constant
         self.frozen_steps = int(frozen_steps)
 
+    def _ensure_time_proj(self):
+        """The UNet's time path (sinusoidal embedding -> TimestepEmbedding MLP -> SiLU -> all ResBlock ``time_emb_proj`` as one GEMM: models/unet_2d_condition.py:
+        315-328, 829-856, diffusers ResnetBlock2D) depends on the timestep ONLY: one row per step of this engine's schedule is computed once, with the very launches
+        ``unet.time_embed`` issues per step (same shapes: bit-identical rows), and a step gathers its row by the device step counter — 1 launch instead of 5 per step.
+        Rebuilt when the schedule or any of the weights involved change; SDXL's ``text_time`` conditioning enters the embedding, there the per-step path stays."""
+        unet = self.unet
+        if unet.config.addition_embed_type is not None or os.environ.get("TG_TPROJ_TABLE", "1") == "0":
+            if self._tproj_table is not None:
+                self._tproj_table, self._tproj_key, self.graph = None, None, None
+            return
+        te = unet.time_embedding
+        ps = [te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias]
+        for r in unet._resnets:
+            ps += [r.time_emb_proj.weight, r.time_emb_proj.bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (self.t_table.data_ptr(), self.t_table._version, unet.dtype)
+        if key == self._tproj_key:
+            return
+        B = 2 * self.n_img
+        idx = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        rows = []
+        with torch.no_grad(), ops.workspace_slot(self.ws_slot):
+            for s in range(self.steps):
+                idx.fill_(s)
+                rows.append(unet.time_embed(DeviceSchedule(self.t_table, idx), B, None)[1].clone())
+        self._tproj_table = torch.stack(rows).contiguous()                # [steps, B, sum(cout)]
+        self._tproj_key = key
+        self.graph = None                                                  # a captured step holds the old table's address
+
     # ---- one step ---------------------------------------------------------------------------------------
     def _step(self):
         with ops.workspace_slot(self.ws_slot):
@@ -150,9 +182,12 @@ class DenoiseEngine:
         if self.controlnet is not None:
             down, mid = self.controlnet(self.model_in, self.sched, self.cn_enc, self.cn_cond, conditioning_scale=self.cn_scale,
                                         return_dict=False, token_major=True)
+        tp = None
+        if self._tproj_table is not None:
+            tp = torch.index_select(self._tproj_table, 0, self.step_idx)[0]        # this step's row, by the DEVICE step counter (graph-replayable)
         noise_pred = self.unet(self.model_in, self.sched, self.enc, added_cond_kwargs=self.added, return_dict=False,
                                out_dtype=torch.float32, down_block_additional_residuals=down,
-                               mid_block_additional_residual=mid)[0]
+                               mid_block_additional_residual=mid, time_proj=tp)[0]
         ops.step_epilogue(noise_pred, self.latents, self.g, self.coef, self.step_idx, advance=True,
                           prediction_type=self.pred_type, frozen=self.frozen,
                           frozen_mask=self.frozen_mask, frozen_steps=self.frozen_steps, history=self.history,
@@ -185,6 +220,7 @@ class DenoiseEngine:
         self.graph = g
 
     def _ensure_graph(self, latents):
+        self._ensure_time_proj()
         sig = self._signature()
         if self.use_graph and (self.graph is None or sig != self._graph_sig):
             self._reset(latents)

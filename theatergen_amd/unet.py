@@ -577,7 +577,10 @@ class UNet2DConditionModel(nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None, attention_mask=None,
                 cross_attention_kwargs=None, added_cond_kwargs=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, encoder_attention_mask=None, return_dict=True, out_dtype=None):
+                mid_block_additional_residual=None, encoder_attention_mask=None, return_dict=True, out_dtype=None, time_proj=None):
+        """``time_proj`` (optional, [B, sum(cout)] storage dtype): the fused ResBlock time projections of THIS timestep, precomputed by the caller with
+        ``time_embed`` (``DenoiseEngine`` keeps one row per step of its schedule: the embedding depends on the timestep only) — the five launches of
+        ``time_embed`` are skipped."""
         cfg = self.config
         if attention_mask is not None or encoder_attention_mask is not None or class_labels is not None or timestep_cond is not None:
             raise NotImplementedError("attention masks / class labels / timestep_cond are not on the TheaterGen hot path")
@@ -592,7 +595,12 @@ class UNet2DConditionModel(nn.Module):
         ca_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
         track_keys = cross_attention_kwargs is not None
 
-        emb, tproj = self.time_embed(timestep, B, added_cond_kwargs)
+        if time_proj is not None:
+            if tuple(time_proj.shape) != (B, self._tproj_width) or time_proj.dtype != dt or time_proj.stride(1) != 1:
+                raise ValueError(f"time_proj must be a [{B}, {self._tproj_width}] {dt} tensor of time_embed(...)[1]")
+            tproj = time_proj
+        else:
+            _, tproj = self.time_embed(timestep, B, added_cond_kwargs)
 
         w_in = self._p.get("conv_in", [self.conv_in.weight], lambda: pack_conv3x3(self.conv_in.weight.detach()))
         x = _Act(ops.conv_in(sample.contiguous(), w_in, self.conv_in.bias, cfg.block_out_channels[0], dt), B, H, W,
