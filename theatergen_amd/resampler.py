@@ -223,14 +223,18 @@ class Resampler(nn.Module):
         if side is None or side.device != dev:
             side = self._side = torch.cuda.Stream(device=dev)
         self.layers[0][0].kv_image(xp, b, L, kvs[0][0], kvs[0][1], ldt)
-        if len(self.layers) > 1:
+        use_side = len(self.layers) > 1 and os.environ.get("TG_RESAMPLER_SIDE", "1") == "1"
+        if use_side:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for (attn, _), (k, vt) in zip(list(self.layers)[1:], kvs[1:]):
                     attn.kv_image(xp, b, L, k, vt, ldt)
+        else:
+            for (attn, _), (k, vt) in zip(list(self.layers)[1:], kvs[1:]):
+                attn.kv_image(xp, b, L, k, vt, ldt)
         lat2d = self.latents.to(dt).expand(b, nq, D).reshape(b * nq, D).contiguous()
         for i, ((attn, ff), (k, vt)) in enumerate(zip(self.layers, kvs)):
-            if i == 1:
+            if i == 1 and use_side:
                 cur.wait_stream(side)
             lat2d = attn.run_skinny(lat2d, b, n1, nq, k, vt, ldt)
             lat2d = _ff_run_skinny(ff, lat2d)
