@@ -79,6 +79,9 @@ _FUSE_GN = not os.environ.get("TG_NO_GN_FUSE")
 # folding norm3 too costs the FeedForward its 256 x 256 big-tile GEGLU kernel (-0.4 % overall); a separate statistics pass is slower
 # than taking them from the staged tiles (+0.75 % instead of +1.06 %).
 _LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_MODE", "1"))
+# norm3 folded into the GEGLU GEMM for row counts up to this (0 = never): where the plain GEGLU GEMM runs on the 128 x 128 kernel anyway (not the 256 x 256 big tile of
+# the 32 x 32 level) the fold costs no tile choice and removes the layernorm launch
+_LN_FF_MAX_ROWS = int(os.environ.get("TG_LN_FF_MAX_ROWS", "0"))
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
 
@@ -279,7 +282,7 @@ class BasicTransformerBlock(nn.Module):
             fused = self.ff.run_fused(x2d, self.norm3, tail)
             if fused is not None:
                 return (fused, True) if tail is not None else fused
-            if _LN_MODE & 2:
+            if _LN_MODE & 2 or M <= _LN_FF_MAX_ROWS:
                 return self.ff.run(x2d, x2d, ln=folded(self.norm3, x2d))
             h = ops.layernorm(x2d, self.norm3.weight, self.norm3.bias, self.norm3.eps)
             return self.ff.run(h, x2d)
