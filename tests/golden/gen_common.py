@@ -189,3 +189,39 @@ def branch_mask(kind, cross, seed):
     if kind == "bhql":
         return torch.randn(2 * BRANCH_HEADS, BRANCH_N, L, generator=g) * 2
     raise ValueError(kind)
+
+
+# ---- round 5: SD-1.5 FIRST-LEVEL geometry (320 channels = 8 heads x 40, 77 + T tokens) composed the way models/attention.py:186-236 and
+# models/transformer_2d.py:285-327 compose the reference's parts, so that the fixtures route through the row-chain kernels (tg_rc_xattn,
+# tg_rc_linear, tg_rc_ff, tg_rc_front) when the tests lower rowchain.MIN_ROWS / MIN_ROWS_CHAIN
+BLOCK_C, BLOCK_HEADS, BLOCK_CTX, BLOCK_B, BLOCK_H, BLOCK_W = 320, 8, 768, 2, 8, 16        # 128 tokens per item = one 128-row workgroup each
+BLOCK_T = [4, 16]
+
+
+def block_params(T, seed=900):
+    """state dict of a Transformer2DModel(in_channels 320, 1 layer, conv 1x1 projections: SD-1.5) with the reference's parameter names
+    (+ ``attn2.processor.to_{k,v}_ip``), input x [2, 320, 8, 16] and encoder states [2, 77 + T, 768]"""
+    g = torch.Generator().manual_seed(seed + T)
+    C, ctx = BLOCK_C, BLOCK_CTX
+    sd = {"norm.weight": 1 + 0.2 * torch.randn(C, generator=g), "norm.bias": 0.1 * torch.randn(C, generator=g),
+          "proj_in.weight": _u((C, C, 1, 1), C, g), "proj_in.bias": _u((C,), C, g),
+          "proj_out.weight": _u((C, C, 1, 1), C, g), "proj_out.bias": _u((C,), C, g)}
+    b = "transformer_blocks.0."
+    for n in ("norm1", "norm2", "norm3"):
+        sd[b + n + ".weight"] = 1 + 0.2 * torch.randn(C, generator=g)
+        sd[b + n + ".bias"] = 0.1 * torch.randn(C, generator=g)
+    for a, kdim in (("attn1", C), ("attn2", ctx)):
+        sd[b + a + ".to_q.weight"] = _u((C, C), C, g)
+        sd[b + a + ".to_k.weight"] = _u((C, kdim), kdim, g)
+        sd[b + a + ".to_v.weight"] = _u((C, kdim), kdim, g)
+        sd[b + a + ".to_out.0.weight"] = _u((C, C), C, g)
+        sd[b + a + ".to_out.0.bias"] = _u((C,), C, g)
+    sd[b + "attn2.processor.to_k_ip.weight"] = _u((C, ctx), ctx, g)
+    sd[b + "attn2.processor.to_v_ip.weight"] = _u((C, ctx), ctx, g)
+    sd[b + "ff.net.0.proj.weight"] = _u((8 * C, C), C, g)
+    sd[b + "ff.net.0.proj.bias"] = _u((8 * C,), C, g)
+    sd[b + "ff.net.2.weight"] = _u((C, 4 * C), 4 * C, g)
+    sd[b + "ff.net.2.bias"] = _u((C,), 4 * C, g)
+    x = torch.randn(BLOCK_B, C, BLOCK_H, BLOCK_W, generator=g) * 1.2 + 0.3
+    enc = torch.randn(BLOCK_B, 77 + T, ctx, generator=g) * 0.5
+    return sd, x, enc

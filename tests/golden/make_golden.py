@@ -336,11 +336,68 @@ def gen_geometry_latents(ref, out):
     out["lat.compose_checksum"] = np.array([float(comp.double().sum()), float(comp.double().abs().sum())])
 
 
+def gen_block(ref, out):
+    """SD-1.5 first-level geometry composed from the reference's parts.  ``BasicTransformerBlock.forward`` / ``Transformer2DModel.forward``
+    cannot execute as shipped (models/attention_processor.py:161 hands ``object_positions`` to processors that do not take it: TypeError), so
+    the residual structure of models/attention.py:186-236 and models/transformer_2d.py:285-327 is restated HERE, in the generator, around the
+    reference's own ``Attention`` / ``AttnProcessor`` / ``IPAttnProcessor`` (ip_adapter/attention_processor.py) and ``FeedForward``
+    (models/attention.py:243-292) modules and torch's LayerNorm / GroupNorm / Conv2d (what the reference instantiates)."""
+    A, att = ref.attnproc, ref.attention
+    C, H, ctx = gc.BLOCK_C, gc.BLOCK_HEADS, gc.BLOCK_CTX
+    for T in gc.BLOCK_T:
+        sd, x, enc = gc.block_params(T)
+        b = "transformer_blocks.0."
+        sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        def ln(name):
+            m = torch.nn.LayerNorm(C)
+            m.load_state_dict(sub(b + name + "."))
+            return m
+        n1, n2, n3 = ln("norm1"), ln("norm2"), ln("norm3")
+        a1 = A.Attention(query_dim=C, cross_attention_dim=None, heads=H, dim_head=C // H)
+        a1.load_state_dict(sub(b + "attn1."))
+        a2 = A.Attention(query_dim=C, cross_attention_dim=ctx, heads=H, dim_head=C // H)
+        a2.load_state_dict({k: v for k, v in sub(b + "attn2.").items() if not k.startswith("processor.")})
+        ff = att.FeedForward(C, dropout=0.0, activation_fn="geglu")
+        ff.load_state_dict(sub(b + "ff."))
+        gn = torch.nn.GroupNorm(32, C, eps=1e-6)
+        gn.load_state_dict(sub("norm."))
+        pin, pout = torch.nn.Conv2d(C, C, 1), torch.nn.Conv2d(C, C, 1)
+        pin.load_state_dict(sub("proj_in.")); pout.load_state_dict(sub("proj_out."))
+
+        def ipproc(s):
+            p = A.IPAttnProcessor(hidden_size=C, cross_attention_dim=ctx, scale=s, num_tokens=T)
+            p.load_state_dict(sub(b + "attn2.processor."))
+            return p
+
+        with torch.no_grad():
+            B, _, hh, ww = x.shape
+            tok = x.permute(0, 2, 3, 1).reshape(B, hh * ww, C)                    # transformer_2d.py:289 on the raw input: the sub-block fixtures' stream
+            for s in gc.IP_SCALES:
+                # models/attention.py:206-224: norm2 -> attn2 -> + hidden_states
+                out[f"T{T}.xattn.scale{s}"] = (ipproc(s)(a2, n2(tok), encoder_hidden_states=enc) + tok).numpy()
+            # plain AttnProcessor on attn2 (text tokens only: what a UNet without IP-Adapter runs)
+            out[f"T{T}.xattn.plain"] = (A.AttnProcessor()(a2, n2(tok), encoder_hidden_states=enc[:, :77]) + tok).numpy()
+
+            def block(h, s):
+                h = A.AttnProcessor()(a1, n1(h)) + h                              # :186-204
+                h = ipproc(s)(a2, n2(h), encoder_hidden_states=enc) + h           # :206-224
+                return ff(n3(h)) + h                                              # :226-236
+            out[f"T{T}.block.scale0.4"] = block(tok, 0.4).numpy()
+            # transformer_2d.py:285-327 (conv projections: use_linear_projection False, SD-1.5)
+            res = x
+            h = pin(gn(x))
+            h = h.permute(0, 2, 3, 1).reshape(B, hh * ww, C)
+            h = block(h, 0.4)
+            h = h.reshape(B, hh, ww, C).permute(0, 3, 1, 2).contiguous()
+            out[f"T{T}.transformer.scale0.4"] = (pout(h) + res).numpy()
+        print("block T", T, "done")
+
+
 def main():
     ref = load_reference()
     torch.set_num_threads(8)
     jobs = {"attn": gen_attention, "attn_branches": gen_attention_branches, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
-            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half}
+            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half, "block": gen_block}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

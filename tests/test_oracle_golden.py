@@ -244,3 +244,19 @@ def test_clip_text_oracle_pinned_against_transformers():
             ref = torch.from_numpy(g[f"{name}.{key}"])
             assert o[key].shape == ref.shape
             assert float((o[key] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (name, key)
+
+
+@pytest.mark.parametrize("T", gc.BLOCK_T)
+def test_first_level_block_composition(golden_dir, T):
+    """round 5: the oracle's BasicTransformerBlock / Transformer2DModel restatement (oracle/unet.py: rows T1 / T2 of SURVEY §8) against the
+    composition of the reference's own Attention / processors / FeedForward captured by ``make_golden.py::gen_block`` (block.npz)"""
+    gold = _load(golden_dir, "block")
+    sd, x, enc = gc.block_params(T)
+    p = "t"
+    sdp = {p + "." + k: v for k, v in sd.items()}
+    got = ounet.transformer_2d(sdp, p, x, enc, gc.BLOCK_HEADS, 1, False, 32, {}, 0.4, T, "ip")
+    np.testing.assert_allclose(got.numpy(), gold[f"T{T}.transformer.scale0.4"], rtol=2e-5, atol=5e-6)
+    B, C, hh, ww = x.shape
+    tok = x.permute(0, 2, 3, 1).reshape(B, hh * ww, C)
+    got = ounet.basic_transformer_block(sdp, p + ".transformer_blocks.0", tok, enc, gc.BLOCK_HEADS, {}, 0.4, T, "ip")
+    np.testing.assert_allclose(got.numpy(), gold[f"T{T}.block.scale0.4"], rtol=2e-5, atol=5e-6)

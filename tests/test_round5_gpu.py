@@ -1,0 +1,258 @@
+"""GPU: round-5 parity additions (VERDICT r4 "next" item 3).
+
+  * the ROW-CHAIN kernels of round 4 (``tg_rc_xattn``, ``tg_rc_linear``, ``tg_rc_ff``, ``tg_rc_front``) against fixtures captured from the
+    IMPORTED reference (tests/golden/block.npz, ``make_golden.py::gen_block``: SD-1.5 first-level geometry — 320 channels = 8 heads x 40,
+    77 + {4, 16} tokens, IP scales 0 / 0.1 / 0.4 / 1.0 — composed as models/attention.py:186-236 and models/transformer_2d.py:285-327 compose the
+    reference's Attention / IPAttnProcessor / FeedForward).  ``rowchain.MIN_ROWS`` / ``MIN_ROWS_CHAIN`` are lowered so that the 256-row
+    fixtures take the fused launches, and every test ASSERTS that the fused launch ran (a counting wrapper around the op);
+  * one gated-scale loop step of ``custom_pipelines.StableDiffusionXLCustomPipeline`` on the FULL SDXL plan vs the oracle loop;
+  * ``IPAttnProcessor.scale`` assigned while engines replay on their own streams (two engines, one UNet): the device scalar is written on the
+    stream the replay is ordered after.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import gen_common as gc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def op_tol(dtype):
+    return 1.5e-2 if dtype == torch.bfloat16 else 4e-3
+
+
+def close(got, ref, tol, what, l2=None):
+    from tests import parity_metrics as pm
+    got = torch.as_tensor(got).detach().float().cpu()
+    ref = torch.as_tensor(ref).detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: {got.shape} vs {ref.shape}"
+    return pm.check(got, ref, what, tol / 2 if l2 is None else l2, tol)["max_rel"]
+
+
+def _load(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+
+
+def _count(monkeypatch, names):
+    """wrap ``theatergen_amd.ops.<name>`` so that a test can assert which fused launches ran"""
+    from theatergen_amd import ops
+    calls = {n: 0 for n in names}
+    for n in names:
+        orig = getattr(ops, n)
+
+        def wrapper(*a, _o=orig, _n=n, **k):
+            calls[_n] += 1
+            return _o(*a, **k)
+        monkeypatch.setattr(ops, n, wrapper)
+    return calls
+
+
+def _transformer(T, dtype, scale, ip=True):
+    from theatergen_amd.attention_processor import IPAttnProcessor
+    from theatergen_amd.unet import Transformer2DModel
+    sd, x, enc = gc.block_params(T)
+    tf = Transformer2DModel(gc.BLOCK_HEADS, gc.BLOCK_C // gc.BLOCK_HEADS, gc.BLOCK_C, 1, gc.BLOCK_CTX, 32, False)
+    if ip:
+        tf.transformer_blocks[0].attn2.set_processor(IPAttnProcessor(gc.BLOCK_C, gc.BLOCK_CTX, scale=scale, num_tokens=T))
+    else:
+        sd = {k: v for k, v in sd.items() if ".processor." not in k}
+    tf.load_state_dict(sd, strict=True)
+    return tf.to(DEV, dtype), x, enc
+
+
+def _lower_thresholds(monkeypatch):
+    from theatergen_amd import rowchain, unet
+    monkeypatch.setattr(unet, "_FUSE_LN_MIN_ROWS", 128)       # the block's LayerNorm-folded dispatch (unet.py: BasicTransformerBlock.run)
+    monkeypatch.setattr(rowchain, "ENABLED", True)
+    monkeypatch.setattr(rowchain, "MODE", 15)
+    monkeypatch.setattr(rowchain, "MIN_ROWS", 128)
+    monkeypatch.setattr(rowchain, "MIN_ROWS_CHAIN", 128)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", gc.BLOCK_T)
+def test_rc_xattn_vs_reference_golden(dtype, T, monkeypatch):
+    """norm2 + IPAttnProcessor(attn2) + residual of a first-level block THROUGH ``fused_cross_block`` / ``tg_rc_xattn`` vs the imported reference,
+    all four IP scales (the scale is a device scalar: one packed weight set, four launches), and the plain-AttnProcessor (text-only) instance"""
+    from theatergen_amd.attention_processor import AttnProcessor, fused_cross_block
+    gold = _load("block")
+    _lower_thresholds(monkeypatch)
+    calls = _count(monkeypatch, ["rc_xattn", "attention"])
+    tf, x, enc = _transformer(T, dtype, 0.4)
+    blk = tf.transformer_blocks[0]
+    B, C, hh, ww = x.shape
+    tok = x.permute(0, 2, 3, 1).reshape(B * hh * ww, C).contiguous().to(DEV, dtype)
+    encd = enc.to(DEV, dtype)
+    for s in gc.IP_SCALES:
+        blk.attn2.processor.scale = s
+        got = fused_cross_block(blk.attn2, blk.norm2, tok, B, hh * ww, encd, {})
+        assert got is not None, "the fixture must take the fused launch"
+        close(got.reshape(B, hh * ww, C), gold[f"T{T}.xattn.scale{s}"], op_tol(dtype), f"rc_xattn T{T} scale {s} {dtype}")
+    assert calls["rc_xattn"] == len(gc.IP_SCALES) and calls["attention"] == 0
+    blk.attn2.set_processor(AttnProcessor())
+    got = fused_cross_block(blk.attn2, blk.norm2, tok, B, hh * ww, encd[:, :77].contiguous(), {})
+    assert got is not None and calls["rc_xattn"] == len(gc.IP_SCALES) + 1
+    close(got.reshape(B, hh * ww, C), gold[f"T{T}.xattn.plain"], op_tol(dtype), f"rc_xattn T{T} plain {dtype}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", gc.BLOCK_T)
+def test_first_level_block_and_transformer_row_chains_vs_reference_golden(dtype, T, monkeypatch):
+    """the whole BasicTransformerBlock (rc_linear to_out, rc_xattn, rc_ff) and the whole Transformer2DModel (rc_front, ..., rc_ff with proj_out +
+    residual) on the row-chain launches vs the imported reference's composition; then the same fixtures with the row chains OFF (the path the
+    older goldens pin) — both sides of the switch against ONE reference value"""
+    from theatergen_amd import rowchain
+    from theatergen_amd.unet import _Act
+    gold = _load("block")
+    _lower_thresholds(monkeypatch)
+    calls = _count(monkeypatch, ["rc_xattn", "rc_linear", "rc_ff", "rc_front"])
+    tf, x, enc = _transformer(T, dtype, 0.4)
+    blk = tf.transformer_blocks[0]
+    B, C, hh, ww = x.shape
+    n = hh * ww
+    tok = x.permute(0, 2, 3, 1).reshape(B * n, C).contiguous().to(DEV, dtype)
+    encd = enc.to(DEV, dtype)
+    tol = op_tol(dtype)
+    got = blk.run(tok, B, n, encd, {})
+    assert calls["rc_xattn"] == 1 and calls["rc_ff"] == 1 and calls["rc_linear"] == 1 and calls["rc_front"] == 0, calls
+    close(got.reshape(B, n, C), gold[f"T{T}.block.scale0.4"], 1.5 * tol, f"block row-chain T{T} {dtype}")
+    out = tf.run(_Act(tok, B, hh, ww, C), encd, {}).t
+    assert calls["rc_front"] == 1 and calls["rc_ff"] == 2 and calls["rc_xattn"] == 2, calls
+    ref = torch.from_numpy(gold[f"T{T}.transformer.scale0.4"]).permute(0, 2, 3, 1).reshape(B * n, C)
+    close(out, ref, 2 * tol, f"transformer row-chain T{T} {dtype}")
+    monkeypatch.setattr(rowchain, "ENABLED", False)
+    before = dict(calls)
+    got = blk.run(tok, B, n, encd, {})
+    close(got.reshape(B, n, C), gold[f"T{T}.block.scale0.4"], 1.5 * tol, f"block tiled path T{T} {dtype}")
+    out = tf.run(_Act(tok, B, hh, ww, C), encd, {}).t
+    close(out, ref, 2 * tol, f"transformer tiled path T{T} {dtype}")
+    assert calls == before
+
+
+def test_sdxl_custom_pipeline_gated_step_on_the_full_plan_vs_oracle():
+    """ip_adapter/custom_pipelines.py:308-367 on the FULL SDXL-base plan (1024 x 1024 -> 128 x 128 latents, 2.6 B
+    parameters, text_time conditioning, IP-Adapter-Plus = 16 image tokens, fp16): a two-step loop whose first step runs with the IP scale gated
+    to 0 (``control_guidance_start`` = 0.5) and whose second step runs with the conditioning scale — the same captured step graph replayed
+    with the device scalar changed in between — against the oracle loop."""
+    import gc as _gc
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from tests import parity_metrics as pm
+    from tests.test_hotpath_gpu import _build
+    from theatergen_amd import config
+    from theatergen_amd.custom_pipelines import StableDiffusionXLCustomPipeline
+    dtype, T, steps, gs, scale = torch.float16, 16, 2, 5.0, 0.6
+    cfg = config.PLANS["sdxl"]()
+    unet, sd_r = _build(cfg, dtype, T=T, scale=scale)
+    g = torch.Generator().manual_seed(71)
+    ctx = cfg.cross_attention_dim
+    pos, neg = torch.randn(1, 77 + T, ctx, generator=g) * 0.5, torch.randn(1, 77 + T, ctx, generator=g) * 0.5
+    pooled, npooled = torch.randn(1, 1280, generator=g), torch.randn(1, 1280, generator=g)
+    lat = torch.randn(1, 4, 128, 128, generator=g)
+    pipe = StableDiffusionXLCustomPipeline(unet)
+    pipe.set_scale(scale)
+    seen = []
+    out = pipe(prompt_embeds=pos.to(DEV, dtype), negative_prompt_embeds=neg.to(DEV, dtype), pooled_prompt_embeds=pooled.to(DEV, dtype),
+               negative_pooled_prompt_embeds=npooled.to(DEV, dtype), height=1024, width=1024, num_inference_steps=steps, guidance_scale=gs,
+               latents=lat, control_guidance_start=0.5, control_guidance_end=1.0,
+               callback=lambda i, t, x: seen.append((i, t, x.detach().float().cpu().clone()))).images.float().cpu()
+    assert [i for i, _, _ in seen] == [0, 1]
+    del pipe, unet
+    _gc.collect()
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(steps)
+    assert [t for _, t, _ in seen] == osch.timesteps.tolist()
+    enc = torch.cat([neg, pos]).to(dtype).float()
+    added = {"text_embeds": torch.cat([npooled, pooled]).to(dtype).float(), "time_ids": torch.tensor([[1024., 1024., 0., 0., 1024., 1024.]] * 2)}
+    ref = lat.clone()
+    for i, t in enumerate(osch.timesteps.tolist()):
+        s = 0.0 if i / steps < 0.5 else scale
+        npred = ou.unet_forward(cfg, sd_r, torch.cat([ref] * 2).to(dtype).float(), t, enc, ip_scale=s, num_tokens=T, added_cond_kwargs=added)
+        ref = oddim.step_epilogue(osch, npred, t, ref, gs)
+        pm.check(seen[i][2].reshape(ref.shape), ref, f"SDXL full plan, custom-pipeline step {i} (IP scale {s}), fp16", 7.5e-3, 1.5e-2)
+    pm.check(out.reshape(ref.shape), ref, "SDXL full plan, custom-pipeline loop output, fp16", 7.5e-3, 1.5e-2)
+
+
+def test_ip_scale_assignment_is_fenced_against_engine_streams():
+    """``IPAttnProcessor.scale = s`` while two engines replay on THEIR OWN streams.  The device scalar the
+    attention kernels read is filled on the current stream; the fill now waits for the replays already queued on the registered engine streams and
+    the next replays wait for it, so gating the scale between two rounds of ``run_concurrent`` gives the bits of the same gating on a single stream."""
+    from tests.test_hotpath_gpu import _build
+    from theatergen_amd import config
+    from theatergen_amd.attention_processor import IPAttnProcessor
+    from theatergen_amd.pipelines import DenoiseEngine
+    dtype = torch.bfloat16
+    cfg = config.tiny()
+    unet, _ = _build(cfg, dtype)
+    procs = [p for p in unet.attn_processors.values() if isinstance(p, IPAttnProcessor)]
+    assert procs
+    g = torch.Generator().manual_seed(41)
+    steps = 6
+    lats = [torch.randn(2, 4, 16, 16, generator=g) for _ in range(2)]
+    encs = [torch.randn(4, 81, cfg.cross_attention_dim, generator=g) * 0.5 for _ in range(2)]
+    engs = [DenoiseEngine(unet, None, n_img=2, height=128, width=128, num_inference_steps=steps, guidance_scale=7.5, enc_len=81) for _ in range(2)]
+    for e, enc in zip(engs, encs):
+        e.set_conditioning(enc.to(DEV, dtype))
+
+    def gate(i):                                                  # ip_adapter/custom_pipelines.py:328-333 with start 1/3, end 2/3
+        s = 0.0 if (i / steps < 1 / 3 or (i + 1) / steps > 2 / 3) else 0.7
+        for p in procs:
+            p.scale = s
+    seq = [e.run(lat, before_step=gate).clone() for e, lat in zip(engs, lats)]
+    ungated = []
+    for p in procs:
+        p.scale = 0.7
+    ungated = [e.run(lat).clone() for e, lat in zip(engs, lats)]
+    assert not torch.equal(seq[0][-1], ungated[0][-1]), "the gating must change the result for the test to mean anything"
+    for rep in range(3):
+        par = [h.clone() for h in DenoiseEngine.run_concurrent(engs, lats, before_step=gate)]
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(seq[k], par[k]), f"gated concurrent replay differs from the gated single-stream run (engine {k}, repeat {rep})"
+
+
+def test_row_chain_dev_switches_are_rejected_in_release_calls():
+    """the timing switches of the row-chain kernels (skip stores / barriers / MFMAs) ride in descriptor bits; without TG_RC_DEV=1 in the
+    environment a descriptor that carries them is an argument error, not a silently wrong result"""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import rc_pack
+    if os.environ.get("TG_RC_DEV") == "1":
+        pytest.skip("dev switches enabled in this environment")
+    x = torch.randn(256, 320, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(320, 320, device=DEV) / 18).to(torch.bfloat16)
+    wpk = rc_pack(w, None)
+    ops.rc_linear(x, wpk, 320)
+    with pytest.raises(RuntimeError):
+        ops.rc_linear(x, wpk, 320, variant=256)
+
+
+def test_skinny_gemm_large_k_instances_after_the_register_fix():
+    """round 5: the K / 128 in {16, 20} (LayerNorm-folded) and K = 5120 launches of tg_skinny_gemm were the instances that spilled; their chunk
+    structure changed (weight fragments in two pieces, fp32 row conversions not kept alive): parity vs the fp32 reference of the op"""
+    import torch.nn.functional as F
+    from tests import parity_metrics as pm
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear, skinny_pack
+    for dtype, (l2, mx) in ((torch.bfloat16, (3e-3, 1e-2)), (torch.float16, (4e-4, 2.5e-3))):
+        for K, N, ln in ((2048, 256, True), (2560, 128, True), (5120, 1280, False), (2048, 2048, False), (1536, 64, True)):
+            g = torch.Generator().manual_seed(K + N)
+            x = (torch.randn(32, K, generator=g) * 1.3 + 0.2).to(dtype).to(DEV)
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(DEV)
+            b = torch.randn(N, generator=g).to(dtype).to(DEV)
+            if ln:
+                gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype).to(DEV)
+                beta = (0.1 * torch.randn(K, generator=g)).to(dtype).to(DEV)
+                Wp, u, v = pack_ln_linear(W, b, gamma, beta)
+                got = ops.skinny_gemm(x, skinny_pack(Wp), N, ln=(u, v, 1e-5))
+                ref = F.linear(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5), W.float(), b.float())
+            else:
+                got = ops.skinny_gemm(x, skinny_pack(W), N, bias=b)
+                ref = F.linear(x.float(), W.float(), b.float())
+            pm.check(got.float().cpu(), ref.cpu(), f"skinny K{K} N{N} ln={ln} {dtype}", l2 * (1.5 if ln else 1), mx * (1.5 if ln else 1))

@@ -125,6 +125,12 @@ def attention_input_grad(attn, proc, h2d, B, N, enc, dout, extra):
     dt, dev = h2d.dtype, h2d.device
     if dout is None and extra is None:
         return None
+    # the recompute below is the bias-free, un-normalised, un-masked attention of the SD / SDXL UNets; the forward processors also honour q / k / v
+    # biases, attn.group_norm and norm_cross (round 4) — a layer that uses them must not get a silently different gradient
+    if any(getattr(l, "bias", None) is not None for l in (attn.to_q, attn.to_k, attn.to_v)) or getattr(attn, "group_norm", None) is not None \
+            or getattr(attn, "norm_cross", None) or getattr(attn, "spatial_norm", None) is not None:
+        raise NotImplementedError("theatergen_amd.backward: the attention reverse pass covers bias-free projections without group_norm / norm_cross "
+                                  "(every SD-1.5 / SD-2.1 / SDXL UNet attention); this layer has one of them")
     if not hasattr(attn, "_p"):
         from .unet import _Packed
         attn._p = _Packed()
@@ -409,7 +415,7 @@ class GraphedInputGrad:
         self.sample = sample.detach().clone().contiguous()
         self.timestep = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).to(sample.device).clone()
         self.unet = unet
-        self._enc_src = encoder_hidden_states
+        self._enc_src, self._enc_ver = encoder_hidden_states, tensor_version(encoder_hidden_states)
         # a PRIVATE static copy of the conditioning (the caller's tensor may be a temporary): what the captured launches' K / V^T caches belong to
         self.enc = unet.register_conditioning(encoder_hidden_states.detach().to(unet.dtype).clone().contiguous())
         args = (self.sample, self.timestep, self.enc, loss_fn, save_keys)
@@ -433,13 +439,18 @@ class GraphedInputGrad:
         """New embeddings of the captured shape: copied into the graph's static conditioning buffer, K / V^T re-projected IN PLACE (the buffers the
         captured launches read); a no-op for the tensor the graph already holds."""
         src = encoder_hidden_states
-        if src is self.enc or src is self._enc_src:
+        if src is self.enc:
+            return
+        # same tensor OBJECT as last time: skipped only when it was not written since (ADVICE r4: a caller that refills one static buffer with
+        # copy_ for the next character hands over the same object with new contents; an inference-mode tensor has no version: always refreshed)
+        ver = tensor_version(src)
+        if src is self._enc_src and ver is not None and ver == self._enc_ver:
             return
         if tuple(src.shape) != tuple(self.enc.shape):
             raise RuntimeError(f"GraphedInputGrad: conditioning of shape {tuple(src.shape)}, captured with {tuple(self.enc.shape)}")
         self.enc.copy_(src.to(self.enc.dtype))
         self.unet.register_conditioning(self.enc)
-        self._enc_src = src
+        self._enc_src, self._enc_ver = src, ver
 
     def run(self, sample=None, timestep=None):
         """-> (loss, grad): the graph's static output tensors (overwritten by the next ``run``)."""

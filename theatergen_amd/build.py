@@ -65,7 +65,7 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, check_gate=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sources()
@@ -106,21 +106,27 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if todo or not os.path.exists(BUILD_INFO):
         _write_build_info()
-    if todo or not os.path.exists(RESOURCES_JSON):
-        write_resources(check=True, verbose=verbose)           # the register / scratch gate is part of every build
+    # The register / scratch gate: `python -m theatergen_amd.build --resources --check` (what the repository's own build entry, __graft_entry__.build(),
+    # runs: check_gate=True) or TG_BUILD_GATE=1.  A plain build() — another compiler, a read-only or site-packages install — never fails on it and never
+    # has to write under profiles/ (ADVICE r4).
+    if check_gate or os.environ.get("TG_BUILD_GATE") == "1":
+        if todo or not os.path.exists(RESOURCES_JSON):
+            write_resources(check=True, verbose=verbose)
     return LIB
 
 
 # ---- kernel resource report + gate ------------------------------------------------------------------
 # `python -m theatergen_amd.build --resources [--check]` recompiles every source with -Rpass-analysis=kernel-resource-usage
-# (device pass only, no objects kept), writes profiles/r4_kernel_resources.json (VGPR / AGPR / scratch / spills / occupancy per
+# (device pass only, no objects kept), writes profiles/r5_kernel_resources.json (VGPR / AGPR / scratch / spills / occupancy per
 # kernel symbol) and, with --check, fails when a kernel matching HOT_GATES exceeds its allowance.  A hot kernel that gains
 # scratch must be a decision, not an accident (round 3 shipped 6 spills inside the d = 40 attention tile loop).
-RESOURCES_JSON = os.path.join(os.path.dirname(HERE), "profiles", "r4_kernel_resources.json")
+RESOURCES_JSON = os.path.join(os.path.dirname(HERE), "profiles", "r5_kernel_resources.json")
 # (substring of the DEMANGLED name, max scratch bytes / lane, max VGPRs)
 HOT_GATES = [
-    ("attention_kernel<bf16,48,64,true,true,false>", 0, 128),      # SD-1.5 level 0 (d = 40): four waves per SIMD, nothing spilled
-    ("attention_kernel<f16,48,64,true,true,false>", 0, 128),
+    # SD-1.5 level 0 (d = 40): four waves per SIMD, nothing spilled.  Template arguments: <T, DPAD, DV, ONES, FOLD, PIPE, MASK> (round 4 added the last
+    # two; the round-4 strings matched no kernel — ADVICE r4 — and check_resources now fails on a gate that matches nothing)
+    ("attention_kernel<bf16,48,64,true,true,false,false>", 0, 128),
+    ("attention_kernel<f16,48,64,true,true,false,false>", 0, 128),
     ("attention_kernel<", 0, 256),
     ("gemm_glds_kernel<", 0, 256),                                 # the LDS-DMA GEMM family: no scratch anywhere
     ("conv_halo_kernel<", 0, 256),
@@ -132,7 +138,9 @@ HOT_GATES = [
     # row-chain kernels (round 4): straight-line register-array code — any scratch means an array fell out of the registers
     ("rc_xattn_kernel<", 0, 256),
     ("rc_ff_kernel<", 0, 256),
-    ("rc_linear_kernel<bf16,20,8,2,false,0>", 0, 256),             # the instance the UNet launches (plain / + residual)
+    ("rc_front_kernel<", 0, 216),                                  # round 4's first version spilled 108 registers (30 % of its launch)
+    ("rc_linear_kernel<", 0, 256),                                 # every instance (the UNet launches <T,20,8,2,false,0>, plain / + residual)
+    ("skinny_gemm_kernel<", 0, 256),                               # round 5: the CK = 16 / 20 instances spilled 44 .. 164 bytes
 ]
 
 
@@ -206,14 +214,20 @@ def kernel_resources(verbose=True):
 
 
 def check_resources(res):
-    """Every kernel is checked against the FIRST gate whose substring it contains."""
+    """Every kernel is checked against the FIRST gate whose substring it contains; a gate that matches NO kernel is itself a failure (a renamed
+    template or a changed parameter list would otherwise switch its check off silently)."""
     bad = []
+    hits = [0] * len(HOT_GATES)
     for name, r in res.items():
-        for sub, max_scratch, max_vgpr in HOT_GATES:
+        for gi, (sub, max_scratch, max_vgpr) in enumerate(HOT_GATES):
             if sub in name:
+                hits[gi] += 1
                 if r.get("scratch", 0) > max_scratch or r.get("vgprs", 0) > max_vgpr:
                     bad.append(f"{name}: {r.get('vgprs')} VGPRs (<= {max_vgpr}), scratch {r.get('scratch')} B (<= {max_scratch})")
                 break
+    for (sub, _, _), n in zip(HOT_GATES, hits):
+        if n == 0:
+            bad.append(f"gate '{sub}' matches no kernel")
     return bad
 
 
@@ -224,9 +238,12 @@ def write_resources(check=False, verbose=True):
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=HERE).stdout.strip()
     except OSError:
         commit = ""
-    os.makedirs(os.path.dirname(RESOURCES_JSON), exist_ok=True)
-    with open(RESOURCES_JSON, "w") as f:
-        json.dump({"flags": FLAGS, "built_from_commit_or_later": commit, "gates": HOT_GATES, "kernels": dict(sorted(res.items()))}, f, indent=1)
+    try:
+        os.makedirs(os.path.dirname(RESOURCES_JSON), exist_ok=True)
+        with open(RESOURCES_JSON, "w") as f:
+            json.dump({"flags": FLAGS, "built_from_commit_or_later": commit, "gates": HOT_GATES, "kernels": dict(sorted(res.items()))}, f, indent=1)
+    except OSError as e:                                         # read-only tree: the report is optional, the check below is not
+        print(f"[resources] cannot write {RESOURCES_JSON}: {e}", flush=True)
     bad = check_resources(res)
     for b in bad:
         print("[resources] GATE:", b, flush=True)

@@ -1658,12 +1658,20 @@ int dispatch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipS
   }
 }
 
+// The dbg switches of the kernels above (timing experiments: skip stores / barriers / MFMAs — WRONG results by design) ride in descriptor bits the
+// release path never sets; a descriptor that carries them is rejected unless the process opted in with TG_RC_DEV=1 (scripts/dev_rc_*.py) — ADVICE r4
+inline bool rc_dev_enabled() {
+  static const bool on = [] { const char* e = getenv("TG_RC_DEV"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+
 }  // namespace
 
 extern "C" int tg_rc_linear(const tg_rc_linear_desc* d, void* stream) {
   TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_linear: null descriptor");
   TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_linear: dtype %d", d->dtype);
   TG_CHECK(d->K == 320 || d->K == 640, TG_ERR_ARG, "tg_rc_linear: K = %d (320 or 640: the token row lives in registers)", d->K);
+  TG_CHECK(d->variant >= 0 && ((d->variant >> 8) == 0 || rc_dev_enabled()), TG_ERR_ARG, "tg_rc_linear: variant %d carries dev bits (TG_RC_DEV=1 enables them)", d->variant);
   TG_CHECK(d->N > 0 && d->N % 64 == 0, TG_ERR_ARG, "tg_rc_linear: N = %d must be a positive multiple of 64", d->N);
   if (d->K == 640) {
     TG_CHECK(d->N % 128 == 0, TG_ERR_ARG, "tg_rc_linear: K = 640 needs N %% 128 == 0 (the two waves of a pair split the 64-channel chunks), got %d", d->N);
@@ -1688,7 +1696,8 @@ extern "C" int tg_rc_xattn(const tg_rc_xattn_desc* d, void* stream) {
   TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_xattn: null descriptor");
   TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_xattn: dtype %d", d->dtype);
   TG_CHECK(d->h && d->wq && d->kv && d->wo && d->out && d->M > 0, TG_ERR_ARG, "tg_rc_xattn: null operand or M <= 0");
-  TG_CHECK((d->text_len & 255) == 77, TG_ERR_ARG, "tg_rc_xattn: %d text keys (built for CLIP's 77)", d->text_len & 255);
+  TG_CHECK(d->text_len == 77 || (rc_dev_enabled() && d->text_len > 0 && (d->text_len & 255) == 77), TG_ERR_ARG,
+           "tg_rc_xattn: %d text keys (built for CLIP's 77; the high bits are dev switches, TG_RC_DEV=1)", d->text_len);
   TG_CHECK(d->ip_tokens == 0 || d->ip_tokens == 4 || d->ip_tokens == 16, TG_ERR_ARG, "tg_rc_xattn: %d image tokens (0, 4 or 16)", d->ip_tokens);
   TG_CHECK(d->rows_per_batch > 0 && d->rows_per_batch % 128 == 0 && d->M % d->rows_per_batch == 0, TG_ERR_ARG,
            "tg_rc_xattn: rows_per_batch = %d must be a multiple of 128 that divides M (a workgroup's 128 tokens share one key set)", d->rows_per_batch);
@@ -1726,6 +1735,7 @@ extern "C" int tg_rc_ff(const tg_rc_ff_desc* d, void* stream) {
   TG_CHECK(d->inner >= 64 && d->inner % 64 == 0, TG_ERR_ARG, "tg_rc_ff: inner = %d must be a multiple of 64", d->inner);
   TG_CHECK(d->ldh >= 320 && d->ldh % 8 == 0 && d->ldc >= 320 && d->ldc % 8 == 0, TG_ERR_ARG, "tg_rc_ff: row pitches");
   TG_CHECK(!d->wpo || (d->res0 && d->ldres >= 320 && d->ldres % 8 == 0), TG_ERR_ARG, "tg_rc_ff: proj_out needs its residual");
+  TG_CHECK(d->dbg == 0 || rc_dev_enabled(), TG_ERR_ARG, "tg_rc_ff: dbg = %d (dev switches need TG_RC_DEV=1)", d->dbg);
   RcFfParams p;
   p.h = d->h; p.ldh = d->ldh; p.w1 = d->w1; p.w2 = d->w2; p.b2 = d->b2; p.wpo = d->wpo; p.res0 = d->res0; p.ldres = d->ldres;
   p.out = d->out; p.ldc = d->ldc; p.M = d->M; p.n_slices = d->inner / 32; p.ln_eps = d->ln_eps; p.dbg = d->dbg;
@@ -1742,6 +1752,7 @@ extern "C" int tg_rc_front(const tg_rc_front_desc* d, void* stream) {
            "tg_rc_front: rows_per_batch = %d must be a multiple of 128 that divides M", d->rows_per_batch);
   TG_CHECK(d->ldx >= 320 && d->ldx % 8 == 0 && d->ldy >= 320 && d->ldy % 8 == 0 && d->ldqk >= 640 && d->ldqk % 8 == 0 && d->ldt >= d->rows_per_batch,
            TG_ERR_ARG, "tg_rc_front: row pitches");
+  TG_CHECK(d->dbg == 0 || rc_dev_enabled(), TG_ERR_ARG, "tg_rc_front: dbg = %d (dev switches need TG_RC_DEV=1)", d->dbg);
   RcFrontParams p;
   p.x = d->x; p.ldx = d->ldx; p.coef = d->coef; p.win = d->win; p.wqkv = d->wqkv; p.y = d->y; p.ldy = d->ldy; p.qk = d->qk; p.ldqk = d->ldqk;
   p.vt = d->vt; p.ldt = d->ldt; p.M = d->M; p.rows_per_batch = d->rows_per_batch; p.ln_eps = d->ln_eps; p.dbg = d->dbg;

@@ -68,12 +68,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(SkinnyParams p) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // AH: the weight fragments of a chunk are fetched in AH pieces of AC k-steps (round 5): with CK = 16 / 20 the 2 CK fragment registers + their
+  // 64-bit addresses did not fit the 256 registers of an 8-wave workgroup (44 .. 164 bytes of scratch); the rows (b) stay whole for the LayerNorm fold
+  constexpr int AH = CK > 12 ? 2 : 1, AC = CK / AH;
   for (int c = 0; c < ksw; c += CK) {
-    V8 a[CK], b[CK];
-#pragma unroll
-    for (int s = 0; s < CK; ++s) a[s] = sk_gld<V8>(wp + (long)(c + s) * 512);
+    V8 b[CK];
 #pragma unroll
     for (int s = 0; s < CK; ++s) b[s] = sk_gld<V8>(xr + (c + s) * 16);
+    V8 a[AC];
+#pragma unroll
+    for (int s = 0; s < AC; ++s) a[s] = sk_gld<V8>(wp + (long)(c + s) * 512);
     if (p.ln) {
       // (single chunk: ksw == CK, checked by the host) row statistics from the registers, two-pass like tg_layernorm
       float sum = 0.f;
@@ -89,6 +93,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(SkinnyParams p) {
       for (int w = 0; w < NW; ++w) tot += red[0][w][l31];
       const float mean = tot / (float)p.K;
       float c2 = 0.f;
+      // opaque to the optimiser: without it hipcc keeps the fp32 conversions of the first pass (8 CK registers) alive for the second one
+#pragma unroll
+      for (int s = 0; s < CK; ++s) asm volatile("" : "+v"(b[s]));
 #pragma unroll
       for (int s = 0; s < CK; ++s)
 #pragma unroll
@@ -106,7 +113,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(SkinnyParams p) {
       }
     }
 #pragma unroll
-    for (int s = 0; s < CK; ++s) acc = mfma32(a[s], b[s], acc);
+    for (int h = 0; h < AH; ++h) {
+#pragma unroll
+      for (int s = 0; s < AC; ++s) acc = mfma32(a[s], b[h * AC + s], acc);
+      if (h + 1 < AH) {
+#pragma unroll
+        for (int s = 0; s < AC; ++s) a[s] = sk_gld<V8>(wp + (long)(c + (h + 1) * AC + s) * 512);
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) accs[wave][r][lane] = acc[r];
@@ -147,8 +161,9 @@ int launch_skinny_nw(const SkinnyParams& p, hipStream_t st) {
   const int ksw = p.K / (16 * NW);
   dim3 grid((unsigned)(p.N / 32), (unsigned)((p.M + 31) / 32));
 #define TG_SK(CKV) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, CKV>), grid, dim3(NW * 64), 0, st, p)
-  if (ksw % 20 == 0) TG_SK(20);
-  else if (ksw % 16 == 0) TG_SK(16);
+  // chunks above 12 k-steps only where the LayerNorm fold needs the whole row slice in registers (their weight fragments come in two pieces)
+  if (p.ln && ksw % 20 == 0) TG_SK(20);
+  else if (p.ln && ksw % 16 == 0) TG_SK(16);
   else if (ksw % 12 == 0) TG_SK(12);
   else if (ksw % 10 == 0) TG_SK(10);
   else if (ksw % 8 == 0) TG_SK(8);

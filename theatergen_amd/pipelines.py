@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import ops
+from .attention_processor import register_replay_stream, tensor_version
 from .scheduler import DDIMScheduler
 from .unet import DeviceSchedule
 
@@ -158,7 +159,7 @@ class DenoiseEngine:
         ps = [te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias]
         for r in unet._resnets:
             ps += [r.time_emb_proj.weight, r.time_emb_proj.bias]
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (self.t_table.data_ptr(), self.t_table._version, unet.dtype)
+        key = tuple((p.data_ptr(), tensor_version(p)) for p in ps) + (self.t_table.data_ptr(), tensor_version(self.t_table), unet.dtype)
         if key == self._tproj_key:
             return
         B = 2 * self.n_img
@@ -228,13 +229,14 @@ class DenoiseEngine:
             self._graph_sig = sig
 
     @staticmethod
-    def run_concurrent(engines, latents_list):
+    def run_concurrent(engines, latents_list, before_step=None):
         """Independent denoising chains (e.g. the two halves of a story's character batch) replayed CONCURRENTLY, one HIP
         stream per engine: the second chain's kernels fill the partially filled grid rounds, small-grid layers and
         launch gaps of the first (+4 % images/s for 2 x 4 images vs 1 x 8 on MI355X).  Engines may share one UNet; each
         has its own conditioning buffers, K / V^T caches, kernel scratch slot and captured graph.  Returns the histories.
-        The IP scale is ONE device scalar per processor (= per UNet): set it before this call (the engine streams wait for the current
-        stream once, here); per-step ``set_scale`` gating needs ``run(before_step=...)``."""
+        The IP scale is ONE device scalar per processor (= per UNet).  ``before_step(i)`` (optional) runs on the host before round i of replays is
+        queued — the per-step ``set_scale`` gating of ``ip_adapter/custom_pipelines.py:328-333``: the assignment fences its 4-byte fill against the
+        engine streams (``attention_processor.fenced_fill``), so round i - 1 still reads the old value and round i the new one."""
         dev = engines[0].dev
         with torch.no_grad():
             for e, lat in zip(engines, latents_list):
@@ -247,7 +249,9 @@ class DenoiseEngine:
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     e._reset(lat)
-            for _ in range(engines[0].steps):
+            for i in range(engines[0].steps):
+                if before_step is not None:
+                    before_step(i)
                 for e, st in zip(engines, streams):
                     with torch.cuda.stream(st):
                         e.graph.replay()
@@ -257,7 +261,8 @@ class DenoiseEngine:
 
     def _stream(self):
         if getattr(self, "_own_stream", None) is None:
-            self._own_stream = torch.cuda.Stream(device=self.dev)
+            # registered: host-side writes of device scalars the captured step reads (IPAttnProcessor.scale) fence against it
+            self._own_stream = register_replay_stream(torch.cuda.Stream(device=self.dev))
         return self._own_stream
 
     def run(self, latents, before_step=None):

@@ -17,6 +17,7 @@ import torch.nn as nn
 import os
 
 from . import ops
+from .attention_processor import tensor_version
 from .weights_pack import pack_ln_linear, skinny_pack
 
 
@@ -40,7 +41,7 @@ class PerceiverAttention(nn.Module):
         """kernel-layout weights of the skinny path, rebuilt when the parameters change: to_kv with norm1 folded (image-token rows, tg_gemm), [to_q ; to_kv] with
         norm2 folded and to_out in tg_skinny_gemm's fragment order"""
         ps = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight]
-        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ps)
+        key = tuple((t.data_ptr(), tensor_version(t), t.dtype, t.device) for t in ps)
         hit = getattr(self, "_pk", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -106,7 +107,7 @@ def FeedForward(dim, mult=4):
 
 def _ff_packed(ff):
     ps = [ff[0].weight, ff[0].bias, ff[1].weight, ff[3].weight]
-    key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ps)
+    key = tuple((t.data_ptr(), tensor_version(t), t.dtype, t.device) for t in ps)
     hit = getattr(ff, "_pk", None)
     if hit is None or hit[0] != key:
         with torch.no_grad():
@@ -240,7 +241,7 @@ class Resampler(nn.Module):
             lat2d = _ff_run_skinny(ff, lat2d)
         pk = getattr(self, "_pk_out", None)
         w = self.proj_out.weight
-        okey = (w.data_ptr(), w._version, w.dtype, w.device)
+        okey = (w.data_ptr(), tensor_version(w), w.dtype, w.device)
         if pk is None or pk[0] != okey:
             with torch.no_grad():
                 pk = (okey, skinny_pack(w))
@@ -255,7 +256,7 @@ class Resampler(nn.Module):
         if getattr(self, "_graphed", None) is None:
             from .graphs import GraphedCall
             w = self.proj_in.weight
-            self._graphed = GraphedCall(self.forward, lambda: (w.data_ptr(), w._version, self.latents.data_ptr(), self.latents._version))
+            self._graphed = GraphedCall(self.forward, lambda: (w.data_ptr(), tensor_version(w), self.latents.data_ptr(), tensor_version(self.latents)))
         return self._graphed(x)
 
 
