@@ -156,7 +156,25 @@ def roofline_leg(unet, engine):
             k["launches"] += 1
             k["ms"] += r["ms"]
             k["flops"] += r["flops"]
-    name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    # Which template the headline `frac` describes is NOT decided by this run's timings (two templates within 1 % of each other made the
+    # round-4 line flip between 0.21 and 0.38): it is the dominant template of the COMMITTED graph-replay trace of this
+    # command (profiles/*_dominant_template.json, written by scripts/step_breakdown.py from a rocprofv3 kernel trace); its live numbers come
+    # from this run's HIP events, and the runner-up's frac rides beside it when the trace has them within 5 %.
+    live_name = max(fam.items(), key=lambda kv: kv[1]["ms"])[0]
+    name, dom_src, runner = live_name, "this run's HIP events (no committed trace names a template this run launches)", None
+    pdir0 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for fn in sorted((f for f in os.listdir(pdir0) if f.endswith("_dominant_template.json")), reverse=True):
+        try:
+            with open(os.path.join(pdir0, fn)) as f:
+                dj = json.load(f)
+            if dj["template"] in fam:
+                name, dom_src = dj["template"], f"profiles/{fn} <- {dj.get('source', 'rocprofv3 kernel trace')}"
+                if dj.get("runner_up") in fam and dj.get("within_5pct"):
+                    runner = dj["runner_up"]
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    top = fam[name]
     members = {k: v for k, v in by.items() if _family(k) == name}
     tot_ms = sum(v["ms"] for v in by.values())
     tot_fl = sum(v["flops"] for v in by.values())
@@ -201,20 +219,89 @@ def roofline_leg(unet, engine):
     families = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                     "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src, "traffic_collected_on_build": traffic_build,
-            "library_build": lib,
-            "traffic_build_matches_library": (bool(traffic_build) and bool(lib) and traffic_build.get("sources_sha256") == lib.get("sources_sha256")) if traffic else None,
-            "algorithmic_bytes_per_launch_avg": round(alg), "hbm": hbm,
-            "kernel": name + "<*> (all instantiations: " + ", ".join(sorted(members)) + ")", "dominant_by": "kernel template, summed over instantiations",
-            "launches_per_cfg_call": top["launches"], "cfg_batch_of_measured_call": 2 * engine.n_img,
-            "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
+    # SHORT SCALARS FIRST (the driver's record keeps scalars and cuts strings / nested tables: VERDICT r4 weak 15b); tables and prose last
+    out = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+           "traffic": round(traffic) if traffic else None, "kernel": name + "<*>",
+           "runner_up_kernel": (runner + "<*>") if runner else None,
+           "runner_up_frac": families[runner]["frac"] if runner else None,
+           "live_dominant_kernel": live_name + "<*>",
+           "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2), "launches_per_cfg_call": top["launches"],
+           "algorithmic_bytes_per_launch_avg": round(alg), "traffic_over_algorithmic": hbm["traffic_over_algorithmic"],
+           "hbm_frac_algorithmic": hbm["algorithmic_frac"], "hbm_frac_measured": hbm["measured_frac"],
+           "all_kernels_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "all_kernels_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+           "library_sha256": lib.get("sources_sha256"), "library_commit": lib.get("commit"),
+           "traffic_build_matches_library": (bool(traffic_build) and bool(lib) and traffic_build.get("sources_sha256") == lib.get("sources_sha256")) if traffic else None}
+    for k, v in list(families.items())[:6]:                # per-template fractions as flat scalars: frac.gemm_glds_kernel, frac.conv_slab_kernel, ...
+        out["frac." + k] = v["frac"]
+    out.update({
+            "dominant_template_source": dom_src,
+            "traffic_source": traffic_src, "traffic_collected_on_build": traffic_build,
+            "library_build": lib, "hbm": hbm,
+            "kernel_instantiations": sorted(members), "dominant_by": "kernel template, summed over instantiations",
+            "cfg_batch_of_measured_call": 2 * engine.n_img,
             "flop_per_launch_avg": top["flops"] / top["launches"],
             "by_template": families,
             "all_timed_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "ms_per_cfg_call": round(tot_ms, 3),
                                   "flop_per_cfg_call": tot_fl, "launches": len(recs), "includes": "GEMM / conv / attention / row-chain launches"},
             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                          for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
+                          for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}})
+    out["executed_flop_per_step_call"] = tot_fl              # what ONE captured step really runs (the hoisted projections are not in it)
+    return out
+
+
+class ClockPowerSampler:
+    """rocm-smi --showclocks --showpower sampled from a side thread while the timed region runs (the pool spreads 12 % for one
+    build; the granted shader clock and the package power say which kind of box a line came from).  Host-side only: nothing is launched on the GPU."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        smi = "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(smi):
+            return
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run([smi, "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10)
+                d = json.loads(r.stdout)
+                c = d.get(f"card{torch.cuda.current_device()}", d.get("card0", {}))
+                sclk = pwr = None
+                for k, v in c.items():
+                    if "sclk" in k.lower():
+                        m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+                        if m:
+                            sclk = int(m.group(1))
+                    if "Graphics Package Power" in k:
+                        try:
+                            pwr = float(v)
+                        except ValueError:
+                            pass
+                if sclk is not None:
+                    self.samples.append((sclk, pwr))
+            except (OSError, ValueError, subprocess.SubprocessError):
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(timeout=15)
+
+    def summary(self):
+        import statistics
+        load = [s for s in self.samples if s[1] is None or s[1] > 600.0] or self.samples
+        if not load:
+            return {"sclk_mhz_median": None, "power_w_median": None, "clock_power_samples": 0}
+        pw = [p for _, p in load if p is not None]
+        med = statistics.median([c for c, _ in load])
+        return {"sclk_mhz_median": med, "power_w_median": statistics.median(pw) if pw else None, "clock_power_samples": len(load),
+                "mfma_peak_at_granted_clock_tflops": round(MFMA_PEAK_TFLOPS * med / 2400.0, 1)}
 
 
 def cpu_config1_loop(cfg, sd32, steps):
@@ -290,8 +377,19 @@ def dry_launch(args, D, rank, world):
     worst = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
     got = D.gather_latents(torch.full((2, 3), float(rank)))
     ok = worst == float(n) and got.shape[0] == 2 * n and [float(v) for v in got[::2, 0]] == [float(r) for r in range(n)]
+    # the strong partition's round trip through the REAL group: rank r owns items r, r + n, ... of a 2 n-item story; all_gather + unshard
+    # must give the items back in item order (theatergen_amd.distributed.run_story_strong)
+    items = list(range(2 * n))
+    mine = torch.tensor(D.shard(items, rank, n), dtype=torch.float32).reshape(-1, 1)
+    back = D.unshard(D.gather_latents(mine), n) if n > 1 else mine
+    unshard_ok = [int(v) for v in back[:, 0]] == items
+    ok = ok and unshard_ok
     if rank == 0:
-        print(json.dumps({"dry": True, "n_gpus": n, "collectives_ok": bool(ok)}), flush=True)
+        rec = {"dry": True, "n_gpus": n, "collectives_ok": bool(ok)}
+        if n > 2:
+            rec.update({"unshard_of_shard_is_identity": bool(unshard_ok), "host_threads": torch.get_num_threads(),
+                        "cpus_of_rank0": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None})
+        print(json.dumps(rec), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if not ok:
@@ -595,6 +693,7 @@ def main():
     rank, world, local = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    D.pin_host_threads(local, world)                      # N launch threads on one node: one CPU slice each (no-op at N = 1)
     if args.dry_launch:
         return dry_launch(args, D, rank, world)
     if local >= torch.cuda.device_count():
@@ -705,14 +804,19 @@ def main():
 
     for s in range(args.warmup):
         run_story(prepared[s])
+    sampler = ClockPowerSampler() if rank == 0 else None
     D.barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps_total):
         gathered = run_story(prepared[s])
     D.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     elapsed = D.max_over_ranks(elapsed, device)
     assert torch.isfinite(gathered).all()
 
@@ -743,9 +847,17 @@ def main():
         result["unit"] = "images/s"
         result["config"]["workload"] += "; STAGE 2: SD-1.5 ControlNet (361 M params, control image 512x512, scale 1.0) runs every step before the UNet"
         result.pop("whole_job_tflops"); result.pop("whole_job_mfma_frac")
+    if sampler is not None:
+        result.update(sampler.summary())
     if rank == 0 and world == 1 and not args.stage2 and not args.with_vae:
         if not args.no_roofline:
             result["roofline"] = roofline_leg(unet, engine)
+            if ns == 1 and cb == 8:
+                # whole_job_tflops prices every image at the algorithmic 1.607 TFLOP per CFG call; the captured step does not re-run the
+                # conditioning K / V projections or the timestep path (hoisted, bit-identical): what it EXECUTES is stated beside it
+                ex = result["roofline"]["executed_flop_per_step_call"] * args.ddim_steps * args.steps
+                result["whole_job_tflops_executed"] = round(ex / elapsed / 1e12, 2)
+                result["whole_job_mfma_frac_executed"] = round(ex / elapsed / 1e12 / MFMA_PEAK_TFLOPS, 4)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(cfg, sd, dtype, args.cpu_calls, args.ddim_steps, args.cpu_loop_steps)
     if rank == 0 and world == 1 and not args.stage2 and not args.with_vae and not args.no_other_configs:

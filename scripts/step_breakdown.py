@@ -83,6 +83,20 @@ def main():
         v[1] += e - s
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:46s} {c:4d} {t / 1e3:9.1f} us {100 * t / busy:5.1f}%")
+    # dominant kernel TEMPLATE of the replayed step (all instantiations summed): what bench.py's `roofline.kernel` names (TG_DOMINANT_JSON = output path)
+    tpl = {}
+    for s, e, n in ks:
+        v = tpl.setdefault(short(n), [0, 0])
+        v[0] += 1
+        v[1] += e - s
+    order = sorted(tpl.items(), key=lambda kv: -kv[1][1])
+    if os.environ.get("TG_DOMINANT_JSON") and len(order) >= 2:
+        (t1, (c1, u1)), (t2, (c2, u2)) = order[0], order[1]
+        with open(os.environ["TG_DOMINANT_JSON"], "w") as f:
+            json.dump({"template": t1, "launches": c1, "us_per_step": round(u1 / 1e3, 1), "runner_up": t2, "runner_up_launches": c2,
+                       "runner_up_us_per_step": round(u2 / 1e3, 1), "within_5pct": bool(u2 >= 0.95 * u1), "step_kernels": len(ks),
+                       "step_kernel_time_us": round(busy / 1e3, 1),
+                       "source": "median graph-replayed step of a rocprofv3 --kernel-trace of `python bench.py` (scripts/step_breakdown.py)"}, f, indent=1)
     if recs is None:
         return
     shaped = [(s, e, n) for s, e, n in ks if short(n) in SHAPED]

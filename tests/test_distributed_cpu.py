@@ -3,6 +3,8 @@ all_gather of final latents, max-over-ranks timing) — the same code bench.py r
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.multiprocessing as mp
 
@@ -75,6 +77,37 @@ def test_bench_self_launches_its_ranks_world2():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_dry_launch_world_4_and_8_through_the_real_launcher(world):
+    """`python bench.py --gpus 8 --dry-launch` brings up 8 gloo ranks through the launcher the driver's SCALE run uses
+    (self-launch under torch.distributed.run on 127.0.0.1), every rank pins its host threads to its own CPU slice, the timed region's
+    collectives work and `unshard(all_gather(shard(items)))` is the identity at that world size."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["dry"] and rec["n_gpus"] == world and rec["collectives_ok"] and rec["unshard_of_shard_is_identity"], rec
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if rec["cpus_of_rank0"] is not None and ncpu >= world:
+        assert rec["cpus_of_rank0"] == ncpu // world, rec            # rank 0 kept 1 / world of the CPUs the launcher could use
+
+
+def test_unshard_inverts_shard_for_every_world_size():
+    from theatergen_amd import distributed as D
+    for world in (1, 2, 4, 8):
+        items = list(range(8))
+        gathered = torch.tensor([it for r in range(world) for it in D.shard(items, r, world)], dtype=torch.float32).reshape(-1, 1)
+        assert [int(v) for v in D.unshard(gathered, world)[:, 0]] == items
 
 
 def _strong_inputs_and_denoise(shared, img_tok, cidx, ctx):

@@ -39,6 +39,26 @@ def init(backend=None, device=None):
     return rank, world, local
 
 
+def pin_host_threads(local, world):
+    """One process per GPU on ONE node: N Python launch threads (+ torch's intra-op pools, used by the CPU-side latent recipe) must not fight over
+    the same cores.  Rank ``local`` of ``world`` takes a contiguous slice of the CPUs this process may run on (``sched_setaffinity``) and sizes
+    torch's pool to it.  Returns (first cpu, count).  A single-rank run keeps the whole machine."""
+    if world <= 1:
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    per = max(1, len(cpus) // world)
+    mine = cpus[(local % world) * per:(local % world) * per + per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(max(1, min(len(mine), 8)))
+    return mine[0], len(mine)
+
+
 def is_dist(force=False):
     """True when collectives have to run: a process group of more than one rank — or, with ``force``, any initialised group
     (the world-size-1 RCCL test exercises the real library calls on one GPU)."""
