@@ -256,3 +256,31 @@ def test_skinny_gemm_large_k_instances_after_the_register_fix():
                 got = ops.skinny_gemm(x, skinny_pack(W), N, bias=b)
                 ref = F.linear(x.float(), W.float(), b.float())
             pm.check(got.float().cpu(), ref.cpu(), f"skinny K{K} N{N} ln={ln} {dtype}", l2 * (1.5 if ln else 1), mx * (1.5 if ln else 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(16384, 640, 640), (4096, 1280, 1280), (9000, 1000, 192), (300, 640, 64), (4096, 1280, 5120), (66000, 320, 320)])
+def test_gemm_128x160_tiles(dtype, shape):
+    """round 5: gemm_glds_kernel on 128 x 160 tiles (force_tile 21 / 22 / 23 = BK 64 x 3 stages / BK 32 x 4 stages / BK 64 x 2 stages; tg_gemm_t160.hip) —
+    ragged M and N, K of one tile up to 80 tiles, bias + per-batch vector + residual through the chunked LDS epilogue; the K order per output is the
+    128 x 128 kernel's, so the results must be BIT-identical to it; and the planner's own choice (force_tile 0) for the shapes it was built for."""
+    import math
+    from tests.test_kernels_gpu import check, rnd
+    from theatergen_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    rows = 100 if M % 100 == 0 else M
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias, res, bvec = rnd((N,), dtype, g), rnd((M, N), dtype, g), rnd((M // rows, N), dtype, g)
+    ad, wd, bd, rd, vd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), bvec.to(DEV)
+    ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
+    base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
+    for tile in (21, 22, 23, 0):
+        if tile == 22 and K % 32:
+            continue
+        out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
+        check(out, ref, dtype, f"128x160 tile {tile} {shape}")
+        assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
+    if (M, N) in ((16384, 640), (4096, 1280)):
+        pl = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, plan_only=True)
+        assert (pl[0], pl[1]) == (128, 160), pl

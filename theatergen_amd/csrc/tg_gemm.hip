@@ -23,8 +23,14 @@
 namespace {
 
 struct TileCfg { int bm, bn, bk; };
-const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}, {128, 128, 32}};
-constexpr int kNumTiles = 7;  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
+const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}, {128, 128, 32},
+                          {128, 160, 64}, {128, 160, 32}, {128, 160, 64}};
+constexpr int kNumTiles = 10;
+// ids 7 / 8 / 9 (round 5, force_tile 21 / 22 / 23): 128 x 160 tiles, four waves of 32 tokens x 160 channels (1 x 5 MFMA tiles, fragments per k-step).
+// TILE COUNT, not tile shape, is what they are for: the UNet's mid-level projections are M x N = 16384 x 640 and 4096 x 1280 — 640 / 320 tiles of
+// 128 x 128 on 512 (768) co-resident slots = one round at 62 .. 83 % with the busiest CUs holding three tiles, but 512 / 256 tiles of 128 x 160:
+// exactly two / one per CU.  7: BK = 64, three stages (108 KB, one workgroup per CU, two K-tiles in flight); 8: BK = 32, four stages (72 KB, two per CU,
+// three K-tiles in flight); 9: BK = 64, two stages (72 KB, two per CU).  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
 // workgroups per CU instead of two; forced / dev switch: see make_plan)
 // id 5 = 256x256, 8 waves of 128x64, fragments read per k-step (230 VGPRs): +11..22 % over 128x128 on large plain GEMMs
 // (8192x4096x4096 929 vs 839 TF, 16384x5120x2560 1001 vs 818) but no gain at the SD-1.5 UNet's K = 320..1280 with the GEGLU
@@ -93,6 +99,13 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
+// dev A/B knob TG_T160: 0 = never, 1 (default) = 128 x 160 tiles where they fill whole rounds (two-per-CU problems on the BK = 32 / four-stage
+// variant), 2 = the same with the BK = 64 / two-stage variant for the two-per-CU problems
+inline int t160_mode() {
+  const char* e = getenv("TG_T160");
+  return e ? (int)strtol(e, nullptr, 0) : 1;
+}
+
 inline long t3_max_tiles() {
   const char* e = getenv("TG_T3_MAX");
   return e ? strtol(e, nullptr, 0) : 256;
@@ -134,7 +147,17 @@ Plan make_plan(const tg_gemm_desc* d) {
         if (fit && fit[0] == '1' && t == 0 && d->mode == 0 && !d->geglu && K % 32 == 0 && t128 > 512 && t128 <= 768) t = 6;
       }
     }
-    if (d->force_tile > 0) t = d->force_tile - 1;
+    // round 5: tile-count-aware 128 x 160 tiles (see kTiles) — where they fill whole rounds and the 128 x 128 tiling does not
+    if ((t == 0 || t == 6) && d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE && d->n_split <= 0 && N % 160 == 0 && M % 128 == 0 && K % 64 == 0 && t160_mode() != 0) {
+      const long t128 = ((M + 127) / 128) * ((N + 127) / 128), s128 = (t == 6) ? 768 : 512;
+      const long t160 = (M / 128) * (N / 160);
+      const double eff128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
+      const long s160 = t160 <= 256 ? 256 : 512;
+      const double eff160 = (double)t160 / (double)(((t160 + s160 - 1) / s160) * s160);
+      if (t160 >= 192 && eff160 >= eff128 + 0.1) t = t160 <= 256 ? 7 : (t160_mode() == 2 ? 9 : 8);
+    }
+    if (d->force_tile >= 21 && d->force_tile <= 23) t = d->force_tile - 14;
+    else if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
   const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
@@ -153,7 +176,7 @@ Plan make_plan(const tg_gemm_desc* d) {
   // longest-K 8x8 projections; every other layer measured faster unsplit (partials cost more than the idle CUs).
   long S = 512;
   if (!halo && (t == 1 || t == 6)) S = 768;
-  if (!halo && (t == 4 || t == 5)) S = 256;
+  if (!halo && (t == 4 || t == 5 || t == 7)) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
   if (d->force_split_k > 0) {
@@ -218,6 +241,8 @@ int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, v
 int tg_gemm_lc_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 // LayerNorm-fused projections (tg_gemm_ln.hip): 128 x 128 tiles, no K split
 int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, int grid, void* stream);
+// 128 x 160 tiles (tg_gemm_t160.hip): variant 0 = BK 64 x 3 stages, 1 = BK 32 x 4 stages, 2 = BK 64 x 2 stages
+int tg_gemm_t160_launch(const tg_gemm_desc* d, const void* params, int variant, int grid, void* stream);
 // LDS-halo conv (tg_conv_halo.hip): grid = full tiles + tail tiles * K splits
 int tg_conv_halo_launch(const tg_gemm_desc* d, const void* params, int grid, void* stream);
 namespace {
@@ -458,6 +483,12 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
     case 4: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
     case 6: return launch_cfg2<T, 128, 128, 2, 2, 3, 32>(d, p, pl, st);   // three 16 KB K stages: 3 blocks / CU
+    case 7: case 8: case 9: {                                             // 128 x 160 tiles (tg_gemm_t160.hip): 7 = 1 block / CU, 8 / 9 = 2 blocks / CU
+      TG_CHECK(d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE, TG_ERR_ARG, "tg_gemm: the 128 x 160 tiles take plain GEMMs with a linear epilogue");
+      const int rc = tg_gemm_t160_launch(d, &p, pl.tile - 7, pl.full + pl.tail * pl.s, st);
+      if (rc != TG_OK) return rc;
+      return launch_reduce<T>(p, pl, st);
+    }
     default: return launch_cfg2<T, 256, 256, 2, 4, 2>(d, p, pl, st);   // 8 waves of 128x64, 128 KB, 1 block / CU
   }
 }
@@ -473,7 +504,7 @@ int validate(const tg_gemm_desc* d) {
   if (d->geglu) {
     TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
              TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
-    const int ft = d->force_tile & 15;
+    const int ft = d->force_tile;
     TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6 || ft == 10, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
     TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
   }

@@ -59,7 +59,8 @@ void gemm_glds_kernel(GemmParams p) {
   constexpr int XJ = BM / (RPI * NW);   // DMA instructions per wave per K-tile for the activation tile
   constexpr int WJ = BN / (RPI * NW);
   static_assert(BKT == 64 || BKT == 32, "BK");
-  static_assert((size_t)NW * 32 * (TN * 32 + 4) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "epilogue scratch must fit the operand stages");
+  constexpr int SCW = TN <= 2 ? TN : 2;       // widest column chunk that goes through the epilogue's LDS bounce in one piece (epilogue_tile_lds)
+  static_assert((size_t)NW * 32 * (SCW * 32 + 4) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "epilogue scratch must fit the operand stages");
   typedef typename Vec<T>::v8 V8;
   static_assert(NW % 2 == 0 && XJ >= 1 && WJ >= 1, "tile / wave layout");
 
@@ -317,8 +318,8 @@ void gemm_glds_kernel(GemmParams p) {
     // row statistics -> (a, b) = (rstd, -rstd * mean) and this tile's u[n] into LDS behind the epilogue scratch (the operand stages
     // are dead); then, still in accumulator layout (lane & 31 = row: a, b are per-lane scalars; a register quad = 4 consecutive
     // columns: one broadcast ds_read_b128 of u), acc <- a * acc + b * u = rstd * (acc - mean * u), in place
-    static_assert((size_t)(NW * 32 * (TN * 32 + 4) + 2 * BM + BN) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "LN: row statistics must fit the operand stages");
-    float* lnrow = reinterpret_cast<float*>(smem) + NW * 32 * (TN * 32 + 4);
+    static_assert((size_t)(NW * 32 * (SCW * 32 + 4) + 2 * BM + BN) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "LN: row statistics must fit the operand stages");
+    float* lnrow = reinterpret_cast<float*>(smem) + NW * 32 * (SCW * 32 + 4);
     float* lnu = lnrow + 2 * BM;
     if constexpr (LN == 1) {
       const float s_all = ln_s + __shfl_xor(ln_s, 1, 64), q_all = ln_q + __shfl_xor(ln_q, 1, 64);
@@ -379,10 +380,10 @@ void gemm_glds_kernel(GemmParams p) {
       }
     }
     epilogue_tile_lds<T, TM, TN, EPI, true>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                            reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
+                                            reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
   } else {
     epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                     reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
+                                     reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
   }
 }
 
