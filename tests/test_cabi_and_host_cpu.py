@@ -382,7 +382,10 @@ def test_gemm_planner_kernel_choice(monkeypatch):
     assert plan(gemm(16384, 640, 2560))[3] == 0                              # loader / compute GEMM: not selected by default
     # round 5: tile-count-aware 128 x 160 tiles where they fill whole rounds (512 / 256 tiles) and 128 x 128 does not (640 / 320)
     assert plan(gemm(16384, 640, 2560))[:2] == (128, 160) and plan(gemm(16384, 640, 640))[:2] == (128, 160) and plan(gemm(4096, 1280, 1280))[:2] == (128, 160)
-    assert plan(gemm(4096, 10240, 1280))[:2] == (128, 128) and plan(gemm(65536, 320, 1280))[:2] == (128, 128) and plan(gemm(1024, 1280, 1280))[:2] == (64, 64)
+    assert plan(gemm(4096, 10240, 1280))[:2] == (128, 128) and plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(1024, 1280, 1280))[:2] == (64, 64)
+    assert plan(gemm(65536, 320, 1280))[:2] == (128, 160)                     # N = 320 = 2.5 tiles of 128: a sixth of the MFMA work would be padding
+    monkeypatch.setenv("TG_T160", "3")
+    assert plan(gemm(65536, 320, 1280))[:2] == (128, 128) and plan(gemm(16384, 640, 640))[:2] == (128, 160)
     monkeypatch.setenv("TG_T160", "0")
     assert plan(gemm(16384, 640, 2560))[:2] == (128, 128)
     monkeypatch.delenv("TG_T160")

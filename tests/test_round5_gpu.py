@@ -261,7 +261,7 @@ def test_skinny_gemm_large_k_instances_after_the_register_fix():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(16384, 640, 640), (4096, 1280, 1280), (9000, 1000, 192), (300, 640, 64), (4096, 1280, 5120), (66000, 320, 320)])
 def test_gemm_128x160_tiles(dtype, shape):
-    """round 5: gemm_glds_kernel on 128 x 160 tiles (force_tile 21 / 22 / 23 = BK 64 x 3 stages / BK 32 x 4 stages / BK 64 x 2 stages; tg_gemm_t160.hip) —
+    """round 5: gemm_glds_kernel on 128 x 160 tiles (force_tile 21 / 23 = BK 64 x 3 stages / BK 64 x 2 stages; tg_gemm_t160.hip) —
     ragged M and N, K of one tile up to 80 tiles, bias + per-batch vector + residual through the chunked LDS epilogue; the K order per output is the
     128 x 128 kernel's, so the results must be BIT-identical to it; and the planner's own choice (force_tile 0) for the shapes it was built for."""
     import math
@@ -275,12 +275,63 @@ def test_gemm_128x160_tiles(dtype, shape):
     ad, wd, bd, rd, vd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), bvec.to(DEV)
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
     base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
-    for tile in (21, 22, 23, 0):
-        if tile == 22 and K % 32:
-            continue
+    for tile in (21, 23, 0):
         out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         check(out, ref, dtype, f"128x160 tile {tile} {shape}")
         assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
     if (M, N) in ((16384, 640), (4096, 1280)):
         pl = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, plan_only=True)
         assert (pl[0], pl[1]) == (128, 160), pl
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(16384, 640), (4096, 1280), (65536, 320)])
+def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
+    """round 5: the LayerNorm-folded projections (attn2.to_q, attn1 q | k | v^T) on the tile-count-aware 128 x 160 tiles vs
+    ``F.linear(F.layer_norm(x), W)`` in fp32, in-kernel and precomputed row statistics, and BIT-identical to the 128 x 128 instance (TG_T160=0):
+    the fold runs in accumulator layout with the same operands in the same order."""
+    import math
+    import torch.nn.functional as F
+    from tests.test_kernels_gpu import check, rnd
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear
+    g = torch.Generator().manual_seed(M + C)
+    x = ((torch.randn(M, C, generator=g) + 0.7 * torch.randn(M, 1, generator=g)) * 1.3).to(dtype)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.3 * torch.randn(C, generator=g)).to(dtype)
+    eps = 1e-5
+    xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps)
+    xd = x.to(DEV)
+    w = rnd((C, C), dtype, g, 1 / math.sqrt(C))
+    wl, u, v = pack_ln_linear(w.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+    on160 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)[:2] == (128, 160)
+    assert on160 or C == 320                                 # (65536 x 320 fills whole rounds with 128 x 128 already: planner keeps it)
+    got = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
+    check(got, xn @ w.float().t(), dtype, f"ln-folded to_q 128x160 {(M, C)}", scale=1.5)
+    rows_st = ops.layernorm_stats(xd, eps)
+    got2 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps, rows_st))
+    check(got2, xn @ w.float().t(), dtype, f"ln-folded (precomputed statistics) to_q 128x160 {(M, C)}", scale=1.5)
+    B = 2
+    rows = M // B
+    w3 = rnd((3 * C, C), dtype, g, 1 / math.sqrt(C))
+    wl3, u3, v3 = pack_ln_linear(w3.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+
+    def qkv():
+        qk = torch.zeros((M, 2 * C), dtype=dtype, device=DEV)
+        vt = torch.zeros((B, C, rows), dtype=dtype, device=DEV)
+        ops.gemm(xd, wl3, M, 3 * C, C, rows_per_batch=rows, out=qk, n_split=2 * C, out_t=vt, ldt=rows, ln=(u3, v3, eps))
+        return qk, vt
+    qk, vt = qkv()
+    ref3 = xn @ w3.float().t()
+    check(qk, ref3[:, :2 * C], dtype, f"ln-folded q|k 128x160 {(M, C)}", scale=1.5)
+    check(vt, ref3[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, f"ln-folded v^T 128x160 {(M, C)}", scale=1.5)
+    monkeypatch.setenv("TG_T160", "0")
+    assert ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)[:2] == (128, 128)
+    # with PRECOMPUTED statistics both instances fold the same fp32 (rstd, -rstd mean) into the same MFMA sums: bit-identical.  The in-kernel statistics are
+    # fp32 sums over the K-tiles a workgroup stages (64-wide here, 32-wide in the K <= 640 instance of the 128 x 128 kernel): same value to fp32 rounding
+    old2 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps, rows_st))
+    assert torch.equal(old2, got2), "128 x 160 and 128 x 128 LayerNorm-folded instances differ with identical row statistics"
+    old = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
+    qk0, vt0 = qkv()
+    check(old, got.float(), dtype, f"ln-folded 128x160 vs 128x128 {(M, C)}", scale=0.5)
+    check(qk0, qk.float(), dtype, f"ln-folded q|k 128x160 vs 128x128 {(M, C)}", scale=0.5)
+    check(vt0, vt.float(), dtype, f"ln-folded v^T 128x160 vs 128x128 {(M, C)}", scale=0.5)

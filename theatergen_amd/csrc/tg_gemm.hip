@@ -24,13 +24,15 @@ namespace {
 
 struct TileCfg { int bm, bn, bk; };
 const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}, {128, 128, 32},
-                          {128, 160, 64}, {128, 160, 32}, {128, 160, 64}};
+                          {128, 160, 64}, {128, 160, 64}, {128, 160, 64}};
 constexpr int kNumTiles = 10;
 // ids 7 / 8 / 9 (round 5, force_tile 21 / 22 / 23): 128 x 160 tiles, four waves of 32 tokens x 160 channels (1 x 5 MFMA tiles, fragments per k-step).
 // TILE COUNT, not tile shape, is what they are for: the UNet's mid-level projections are M x N = 16384 x 640 and 4096 x 1280 — 640 / 320 tiles of
 // 128 x 128 on 512 (768) co-resident slots = one round at 62 .. 83 % with the busiest CUs holding three tiles, but 512 / 256 tiles of 128 x 160:
-// exactly two / one per CU.  7: BK = 64, three stages (108 KB, one workgroup per CU, two K-tiles in flight); 8: BK = 32, four stages (72 KB, two per CU,
-// three K-tiles in flight); 9: BK = 64, two stages (72 KB, two per CU).  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
+// exactly two / one per CU.  7: BK = 64, three stages (108 KB, one workgroup per CU, two K-tiles in flight); 9 (= 8): BK = 64, two stages (72 KB, two per
+// CU).  (A BK = 32 / four-stage variant does not exist: 160 weight rows are not a whole number of 16-row DMA instructions per wave.)  Isolated, rotating
+// operands, us (profiles/r5_t160_sweep.txt; 128 x 128 -> 128 x 160): 16384 x 640 x 640 + res 30.6 -> 27.5, x 2560 86.4 -> 70.2, x 1280 44.0 -> 35.2;
+// 4096 x 1280 x 1280 + res 27.3 -> 24.9, x 5120 87.5 -> 79.2; 65536 x 320 x 1280 97.0 -> 84.0 (N = 320 is 2.5 tiles of 128: a sixth of those MFMAs is padding).  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
 // workgroups per CU instead of two; forced / dev switch: see make_plan)
 // id 5 = 256x256, 8 waves of 128x64, fragments read per k-step (230 VGPRs): +11..22 % over 128x128 on large plain GEMMs
 // (8192x4096x4096 929 vs 839 TF, 16384x5120x2560 1001 vs 818) but no gain at the SD-1.5 UNet's K = 320..1280 with the GEGLU
@@ -99,11 +101,11 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
-// dev A/B knob TG_T160: 0 = never, 1 (default) = 128 x 160 tiles where they fill whole rounds (two-per-CU problems on the BK = 32 / four-stage
-// variant), 2 = the same with the BK = 64 / two-stage variant for the two-per-CU problems
+// dev A/B knob TG_T160 (bit mask, default 7): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
+// projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960)
 inline int t160_mode() {
   const char* e = getenv("TG_T160");
-  return e ? (int)strtol(e, nullptr, 0) : 1;
+  return e ? (int)strtol(e, nullptr, 0) : 7;
 }
 
 inline long t3_max_tiles() {
@@ -148,13 +150,14 @@ Plan make_plan(const tg_gemm_desc* d) {
       }
     }
     // round 5: tile-count-aware 128 x 160 tiles (see kTiles) — where they fill whole rounds and the 128 x 128 tiling does not
-    if ((t == 0 || t == 6) && d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE && d->n_split <= 0 && N % 160 == 0 && M % 128 == 0 && K % 64 == 0 && t160_mode() != 0) {
+    if ((t == 0 || t == 6) && d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE && d->n_split <= 0 && N % 160 == 0 && M % 128 == 0 && K % 64 == 0 && (t160_mode() & 5)) {
       const long t128 = ((M + 127) / 128) * ((N + 127) / 128), s128 = (t == 6) ? 768 : 512;
       const long t160 = (M / 128) * (N / 160);
       const double eff128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
       const long s160 = t160 <= 256 ? 256 : 512;
       const double eff160 = (double)t160 / (double)(((t160 + s160 - 1) / s160) * s160);
-      if (t160 >= 192 && eff160 >= eff128 + 0.1) t = t160 <= 256 ? 7 : (t160_mode() == 2 ? 9 : 8);
+      const bool ragged128 = N % 128 != 0 && K >= 640 && (t160_mode() & 4);          // N = 320 / 960: the last 128-column tile is half padding
+      if (d->force_split_k <= 1 && t160 >= 192 && (((t160_mode() & 1) && eff160 >= eff128 + 0.1) || (ragged128 && eff160 >= eff128 - 0.01))) t = t160 <= 256 ? 7 : 9;
     }
     if (d->force_tile >= 21 && d->force_tile <= 23) t = d->force_tile - 14;
     else if (d->force_tile > 0) t = d->force_tile - 1;
@@ -389,6 +392,18 @@ inline int bt_tile_of(const tg_gemm_desc* d) {
   return -1;
 }
 
+// LayerNorm-folded projections on 128 x 160 tiles: 0 = no, 160 = three stages / one workgroup per CU, 161 = two stages / two per CU (tg_gemm_ln.hip)
+inline int ln_t160_of(const tg_gemm_desc* d) {
+  if (!(t160_mode() & 2) || d->geglu || d->N % 160 != 0 || d->M % 128 != 0 || d->K % 64 != 0 || (d->n_split > 0 && d->n_split % 160 != 0)) return 0;
+  const long t128 = (d->M / 128) * ((d->N + 127) / 128), s128 = d->K <= 640 ? 768 : 512;
+  const long t160 = (d->M / 128) * (d->N / 160);
+  const long s160 = t160 <= 256 ? 256 : 512;
+  const double eff128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
+  const double eff160 = (double)t160 / (double)(((t160 + s160 - 1) / s160) * s160);
+  if (t160 < 192 || eff160 < eff128 + 0.1) return 0;
+  return t160 <= 256 ? 160 : 161;
+}
+
 template <typename T>
 int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   Plan pl = make_plan(d);
@@ -419,11 +434,13 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
   if (d->ln_u != nullptr) {
-    // LayerNorm-fused projection: whole rows per workgroup (no K split), 128 x 128 tiles in XCD-chunked order
-    const long tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128);
-    p.full_tiles = (int)tiles; p.tail_s = 1; p.tiles_n = (int)((d->N + 127) / 128); p.tile_bm = 128; p.tile_bn = 128;
+    // LayerNorm-fused projection: whole rows per workgroup (no K split), 128 x 128 tiles — or 128 x 160 where those fill whole rounds — in XCD-chunked order
+    const int t160 = ln_t160_of(d);
+    const int bn = t160 ? 160 : 128;
+    const long tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
+    p.full_tiles = (int)tiles; p.tail_s = 1; p.tiles_n = (int)((d->N + bn - 1) / bn); p.tile_bm = 128; p.tile_bn = bn;
     p.kt_per_split = 0;
-    return tg_gemm_ln_launch(d, &p, d->K <= 640 ? 1 : 0, (int)tiles, st);
+    return tg_gemm_ln_launch(d, &p, t160 ? t160 : (d->K <= 640 ? 1 : 0), (int)tiles, st);
   }
   if (const int sp = slab_splits_of(d); sp > 0) {
     const long tiles = (d->M / 128) * (d->N / 320);
@@ -552,7 +569,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
   if (rc != TG_OK) return rc;
   if (d->ln_u != nullptr) {
     if (tile_m) *tile_m = 128;
-    if (tile_n) *tile_n = 128;
+    if (tile_n) *tile_n = ln_t160_of(d) ? 160 : 128;
     if (splits) *splits = 1;
     if (kernel_kind) *kernel_kind = 6;
     return TG_OK;

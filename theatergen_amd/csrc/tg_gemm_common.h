@@ -681,11 +681,11 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
   if constexpr (TN <= 2) {
     epilogue_chunk_lds<T, TM, TN, EPI, 0, TN, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
   } else {
-    static_assert(!LN, "the LayerNorm fold is instantiated for the 64-column wave tiles only");
-    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
-    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
-    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
-    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1, false, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    // (LN: the 160-column wave tiles of the LayerNorm-folded projections, round 5; the fold's fp32 vector v rides where the bias does, per chunk)
+    epilogue_chunk_lds<T, TM, TN, EPI, 0, 2, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN >= 4) epilogue_chunk_lds<T, TM, TN, EPI, 2, 2, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
+    if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
     static_assert(TN <= 5, "wave tiles wider than 160 columns are not instantiated");
   }
 }

@@ -59,6 +59,7 @@ void gemm_glds_kernel(GemmParams p) {
   constexpr int XJ = BM / (RPI * NW);   // DMA instructions per wave per K-tile for the activation tile
   constexpr int WJ = BN / (RPI * NW);
   static_assert(BKT == 64 || BKT == 32, "BK");
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "every wave issues a whole number of DMA instructions per operand tile");
   constexpr int SCW = TN <= 2 ? TN : 2;       // widest column chunk that goes through the epilogue's LDS bounce in one piece (epilogue_tile_lds)
   static_assert((size_t)NW * 32 * (SCW * 32 + 4) * 4 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T), "epilogue scratch must fit the operand stages");
   typedef typename Vec<T>::v8 V8;
@@ -200,13 +201,16 @@ void gemm_glds_kernel(GemmParams p) {
 
   // LN: thread -> (tile row tid / 2, half tid & 1 of the row's K-tile); SCH 16-byte slots per thread and K-tile.  The slot order is
   // rotated by the row so that the 16 lanes of one ds_read_b128 phase hit 16 different 4-bank groups.
-  static_assert(LN == 0 || (BM * 2 == NW * 64 && !CONV && TN <= 2), "LN: two threads per tile row, plain GEMM, 64-column wave tiles");
+  static_assert(LN == 0 || (BM * 2 == NW * 64 && !CONV && TN <= 5), "LN: two threads per tile row, plain GEMM");
   constexpr int SCH = CH / 2;
   const int srow = tid >> 1, shalf = tid & 1;
   const int srot = CH == 8 ? (srow >> 1) : (srow >> 2);
   float ln_s = 0.f, ln_q = 0.f;
 
-  constexpr bool BIGW = TM * TN > 4;            // big wave tiles: fragments are read per k-step (register budget)
+  // big wave tiles: fragments are read per k-step (register budget).  The 1 x 5 wave tile of the plain 128 x 160 kernel (round 5) still reads a whole K-tile's
+  // 24 fragments up front (96 VGPRs + 80 accumulators): per k-step hipcc emits read-2 / lgkmcnt(0) / mfma groups on ONE recycled register quad — ten exposed LDS
+  // latencies per K-tile with two waves per SIMD; its LayerNorm-folded instance (209 VGPRs) keeps the per-k-step form
+  constexpr bool BIGW = TM * TN > 4 && !(TM * TN == 5 && LN == 0);
   // EARLY REFILL (2 stages, all fragments of a K-tile read into registers up front): a stage is dead as soon as every wave
   // has its 16 fragments, i.e. half a K-tile before the next one starts — it is refilled right then with the tile AFTER
   // next.  Two K-tiles are in flight with two 32 KB stages; the K-tile period was one DMA round trip (~1800 cycles against

@@ -22,7 +22,6 @@ template <typename T>
 int dispatch_t160(const GemmParams& p, int variant, int grid, hipStream_t st) {
   switch (variant) {
     case 0: return launch_t160<T, 3, 64>(p, grid, st);       // 108 KB: one workgroup per CU, two K-tiles in flight
-    case 1: return launch_t160<T, 4, 32>(p, grid, st);       // 72 KB: two per CU, three 32-wide K-tiles in flight each
     default: return launch_t160<T, 2, 64>(p, grid, st);      // 72 KB: two per CU, one K-tile in flight each
   }
 }
