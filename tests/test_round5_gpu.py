@@ -320,6 +320,8 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
         vt = torch.zeros((B, C, rows), dtype=dtype, device=DEV)
         ops.gemm(xd, wl3, M, 3 * C, C, rows_per_batch=rows, out=qk, n_split=2 * C, out_t=vt, ldt=rows, ln=(u3, v3, eps))
         return qk, vt
+    assert ops.gemm(xd, wl3, M, 3 * C, C, rows_per_batch=rows, out=torch.empty((M, 2 * C), dtype=dtype, device=DEV), n_split=2 * C,
+                    out_t=torch.empty((B, C, rows), dtype=dtype, device=DEV), ldt=rows, ln=(u3, v3, eps), plan_only=True)[:2] == (128, 128)   # planner keeps q | k | v^T on 128 x 128
     qk, vt = qkv()
     ref3 = xn @ w3.float().t()
     check(qk, ref3[:, :2 * C], dtype, f"ln-folded q|k 128x160 {(M, C)}", scale=1.5)
@@ -335,3 +337,40 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     check(old, got.float(), dtype, f"ln-folded 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(qk0, qk.float(), dtype, f"ln-folded q|k 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(vt0, vt.float(), dtype, f"ln-folded v^T 128x160 vs 128x128 {(M, C)}", scale=0.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,cin,c1,cout", [(16, 1280, 0, 1280), (16, 1280, 1280, 1280), (16, 640, 640, 1280), (4, 1280, 0, 320), (18, 1280, 0, 1280)])
+def test_conv_halo_8x8_on_128x160_tiles(dtype, B, cin, c1, cout, monkeypatch):
+    """round 5: the 8 x 8 level's conv3x3 (ResnetBlock2D convs of the mid / last down / first up blocks: 1024 pixels at CFG batch 16) on the LDS-halo
+    kernel's 128 x 160 instance — one workgroup per CU, double-buffered window, five-stage weight ring, K split over the channel chunks — vs the fp32
+    reference of the op (bias + time-embedding vector + residual in the reduce epilogue), vs the 128 x 128 instance (TG_T160 without bit 3), run to run."""
+    import torch.nn.functional as F
+    from tests.test_kernels_gpu import check, rnd
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    h = w = 8
+    ctot = cin + c1
+    g = torch.Generator().manual_seed(B + cin + c1 + cout)
+    x = rnd((B, ctot, h, w), dtype, g).to(DEV)
+    wt = rnd((cout, ctot, 3, 3), dtype, g, 1 / (9 * ctot) ** 0.5).to(DEV)
+    bias, bvec = rnd((cout,), dtype, g).to(DEV), rnd((B, cout), dtype, g).to(DEV)
+    res = rnd((B * h * w, cout), dtype, g).to(DEV)
+    ref = F.conv2d(x.float(), wt.float(), bias.float(), padding=1) + bvec.float()[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * h * w, cout) + res.float()
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, ctot)
+    x0 = tok[:, :cin].contiguous()
+    x1 = tok[:, cin:].contiguous() if c1 else None
+    wp = pack_conv3x3(wt)
+    kw = dict(x1=x1, c1=c1, bias=bias, bvec=bvec, rows_per_batch=h * w, res=res)
+    pl = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
+    got = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
+    check(got, ref.cpu(), dtype, f"conv 8x8 {(B, cin, c1, cout)} plan {pl}")
+    assert torch.equal(got, ops.conv3x3(x0, wp, B, h, w, cin, **kw))
+    if cout % 160 == 0 and (B * h * w) % 128 == 0 and B * h * w >= 1024:
+        assert pl[:2] == (128, 160) and pl[3] == 2, pl
+    monkeypatch.setenv("TG_T160", "7")
+    pl0 = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
+    assert pl0[:2] != (128, 160)
+    old = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
+    check(old, got.float(), dtype, f"conv 8x8 128x160 vs 128x128 {(B, cin, c1, cout)}", scale=0.5)

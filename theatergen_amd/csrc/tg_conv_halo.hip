@@ -15,9 +15,18 @@ namespace {
 // (full-width rows make the block's pixels contiguous in the token-major tensor).
 // UPS = true: the same for Upsample2D (nearest x2 then conv3x3): WI is the OUTPUT width, the slab holds the
 // (TH/2 + 2) x (WI/2 + 2) INPUT pixels the block's upsampled window maps to (input pixel = upsampled coordinate >> 1).
-template <typename T, int WI, bool UPS>
+// BNT = 160 (round 5; the 8 x 8 level only): 128 pixels x 160 channels per workgroup, four waves of 32 pixels x 160 channels.  At CFG batch 16 the level
+// is M = 1024 pixels: 8 x 8 = 64 tiles x 4 K splits = 256 work items = exactly ONE per CU (128 x 128: 80 tiles x 5 splits = 400 items on 512 slots, 144 CUs
+// with two, 112 with one).  One workgroup per CU owns the whole LDS: the slab is DOUBLE-buffered (the next chunk's window is requested five K-steps before it
+// is needed, no barrier / drain at the chunk boundary) and the weight ring is five 20 KB stages deep (four tiles in flight: a K-step's period was one DMA
+// round trip).  Same K order per output as the 128 x 128 instance: bit-identical partial sums when the splits agree.
+template <int N> __device__ __forceinline__ void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int WI, bool UPS, int BNT = 128>
 __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
-  constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, WAVES_N = 2;
+  constexpr int BM = 128, BN = BNT, NW = 4, WAVES_N = BN == 128 ? 2 : 1, WAVES_M = NW / WAVES_N, TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr bool DEEP = BN != 128;
+  static_assert(!DEEP || (WI == 8 && !UPS && BN == 160), "the deep-ring instance is the 8 x 8 level's");
   // WI = 8 (the 8x8 level): a block's 128 pixels are TWO whole 8x8 images; their two 10x10 padded windows are stacked
   // in the slab (20 slab rows of width 10), everything else is unchanged
   constexpr bool MULTI = WI == 8;
@@ -32,9 +41,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   stagger_first_round(p.flags, smem);
   // weight-tile ring: 3 stages (2 tiles in flight) wherever slab + 3 x 16 KB still lets two blocks share a CU (every
   // variant but the 64-wide one): a K-step's period was one DMA round trip of the next W tile, not its 16 MFMAs
-  constexpr int WST = ((size_t)NI * 8 * BK + 3 * BN * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
+  constexpr int WST = DEEP ? 5 : (((size_t)NI * 8 * BK + 3 * BN * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2);
   constexpr int WD = WST - 1;                          // W tiles issued ahead of the one being multiplied
-  T* sW = sS + NI * 8 * BK;                           // [WST][BN][64]  weight tiles
+  constexpr int NSLAB = DEEP ? 2 : 1;
+  T* sW = sS + NSLAB * NI * 8 * BK;                   // [WST][BN][64]  weight tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
   };
-  auto issue_slab = [&](int cc) {
+  auto issue_slab = [&](int cc, int sb = 0) {
     int c = cc * BK;
     const T* base = A0;
     int pitch = p.c0;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     for (int j = 0; j < SJ; ++j) {
       if (j * NW + wave < NI) {
         const T* src = spix[j] >= 0 ? base + (long)spix[j] * pitch + c : zero;
-        dma(src, sS + (j * NW + wave) * 8 * BK);
+        dma(src, sS + sb * NI * 8 * BK + (j * NW + wave) * 8 * BK);
       }
     }
   };
@@ -152,22 +162,28 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
       if (++itap == 9) { itap = 0; ++icc; }
     }
   }
-  if (WD == 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (DEEP) {
+    // slab + W(0) landed = at most the (min(WD, nkt) - 1) younger W tiles still in flight (LDS-DMA completes in issue order); nkt >= 9
+    halo_wait_vm<(WD - 1) * WJ>();
+  } else {
+    if (WD == 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
 
   int cc = c_begin, tap = 0;
-  int buf = 0;
+  int buf = 0, cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
+    const T* sSc = sS + cur * NI * 8 * BK;
     V8 xf[BK / 16][TM], wf[BK / 16][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int sr = UPS ? (((ppy[i] + ky - 1) >> 1) + 1) * SW + ((ppx[i] + kx - 1) >> 1) + 1
                          : (ppy[i] + ky) * SW + ppx[i] + kx;
       const int key = (sr >> 1) & 7;
-      const T* bx = sS + sr * BK;
+      const T* bx = sSc + sr * BK;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) xf[ks][i] = *reinterpret_cast<const V8*>(bx + ((2 * ks + hi) ^ key) * 8);
     }
@@ -180,13 +196,19 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     int ncc = cc, ntap = tap + 1;
     if (ntap == 9) { ntap = 0; ncc = cc + 1; }
-    if (kt + 1 < nkt) {
-      if (ntap == 0) {
-        // the next K-step starts a new channel chunk: every wave must have its tap-8 fragments in registers before
-        // the slab is overwritten; the slab DMA then overlaps this step's 16 MFMAs
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_slab(ncc);
+    if constexpr (DEEP) {
+      // next chunk's window into the OTHER slab buffer, five K-steps ahead of its first use (last read a whole chunk ago: no barrier needed);
+      // issued BEFORE this step's W tile, so it is older than the W tile whose landing the chunk's first step waits for
+      if (tap == 3 && cc + 1 < c_end) issue_slab(cc + 1, cur ^ 1);
+    } else {
+      if (kt + 1 < nkt) {
+        if (ntap == 0) {
+          // the next K-step starts a new channel chunk: every wave must have its tap-8 fragments in registers before
+          // the slab is overwritten; the slab DMA then overlaps this step's 16 MFMAs
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          issue_slab(ncc);
+        }
       }
     }
     if (kt + WD < nkt) {
@@ -205,24 +227,36 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // the W tile of step kt+1 (and a slab requested in this step, which is older than this step's W request) must have
     // landed; the W tile requested in this step may stay in flight
-    if (WD == 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DEEP) {
+      // W tiles younger than W(kt + 1) that may stay in flight: W(kt + 2) .. W(min(kt + WD, nkt - 1)).  (While a slab request is younger than
+      // W(kt + 1) — three steps per chunk — the count under-states what is in flight and the wait retires a little more than it has to.)
+      const int younger = nkt - 2 - kt;
+      if (younger >= WD - 1) halo_wait_vm<(WD - 1) * WJ>();
+      else if (younger == 2) halo_wait_vm<2 * WJ>();
+      else if (younger == 1) halo_wait_vm<WJ>();
+      else halo_wait_vm<0>();
+    } else {
+      if (WD == 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     cc = ncc;
     tap = ntap;
+    if (DEEP && ntap == 0) cur ^= 1;
     buf = buf + 1 == WST ? 0 : buf + 1;
   }
 
+  constexpr int SCW = TN <= 2 ? TN : 2;
   epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                 reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
+                                 reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
 }
 
-template <typename T, int WI, bool UPS>
+template <typename T, int WI, bool UPS, int BNT = 128>
 int launch_halo(const GemmParams& p, int grid, hipStream_t st) {
   constexpr int TH = 128 / WI, SLAB = WI == 8 ? 200 : (UPS ? (TH / 2 + 2) * (WI / 2 + 2) : (TH + 2) * (WI + 2)), NI = (SLAB + 7) / 8;
-  const int wst = ((size_t)NI * 8 * BK + 3 * 128 * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2;
-  const size_t lds = ((size_t)NI * 8 * BK + wst * 128 * BK) * sizeof(T);
-  auto k = conv_halo_kernel<T, WI, UPS>;
+  const int wst = BNT != 128 ? 5 : (((size_t)NI * 8 * BK + 3 * 128 * BK) * sizeof(T) <= 80 * 1024 ? 3 : 2);
+  const size_t lds = ((size_t)(BNT != 128 ? 2 : 1) * NI * 8 * BK + wst * BNT * BK) * sizeof(T);
+  auto k = conv_halo_kernel<T, WI, UPS, BNT>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
@@ -239,7 +273,7 @@ int dispatch_halo(const tg_gemm_desc* d, const GemmParams& p, int grid, hipStrea
   }
   if (d->out_w == 64) return launch_halo<T, 64, false>(p, grid, st);
   if (d->out_w == 32) return launch_halo<T, 32, false>(p, grid, st);
-  if (d->out_w == 8) return launch_halo<T, 8, false>(p, grid, st);
+  if (d->out_w == 8) return p.tile_bn == 160 ? launch_halo<T, 8, false, 160>(p, grid, st) : launch_halo<T, 8, false>(p, grid, st);
   return launch_halo<T, 16, false>(p, grid, st);
 }
 

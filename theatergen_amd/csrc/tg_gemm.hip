@@ -101,11 +101,11 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
-// dev A/B knob TG_T160 (bit mask, default 7): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
-// projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960)
+// dev A/B knob TG_T160 (bit mask, default 15): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
+// projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960), 8 = the 8 x 8 level's LDS-halo convs on 128 x 160 tiles
 inline int t160_mode() {
   const char* e = getenv("TG_T160");
-  return e ? (int)strtol(e, nullptr, 0) : 7;
+  return e ? (int)strtol(e, nullptr, 0) : 15;
 }
 
 inline long t3_max_tiles() {
@@ -154,15 +154,18 @@ Plan make_plan(const tg_gemm_desc* d) {
       const long t128 = ((M + 127) / 128) * ((N + 127) / 128), s128 = (t == 6) ? 768 : 512;
       const long t160 = (M / 128) * (N / 160);
       const double eff128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
-      const long s160 = t160 <= 256 ? 256 : 512;
-      const double eff160 = (double)t160 / (double)(((t160 + s160 - 1) / s160) * s160);
+      const double e256 = (double)t160 / (double)(((t160 + 255) / 256) * 256), e512 = (double)t160 / (double)(((t160 + 511) / 512) * 512);
+      const bool one_per_cu = e256 > e512 + 1e-9;              // whole rounds only at one workgroup per CU (three K stages): 256 / 768 / 1280 tiles
+      const double eff160 = one_per_cu ? e256 : e512;
       const bool ragged128 = N % 128 != 0 && K >= 640 && (t160_mode() & 4);          // N = 320 / 960: the last 128-column tile is half padding
-      if (d->force_split_k <= 1 && t160 >= 192 && (((t160_mode() & 1) && eff160 >= eff128 + 0.1) || (ragged128 && eff160 >= eff128 - 0.01))) t = t160 <= 256 ? 7 : 9;
+      if (d->force_split_k <= 1 && t160 >= 192 && (((t160_mode() & 1) && eff160 >= eff128 + 0.1) || (ragged128 && eff160 >= eff128 - 0.01))) t = one_per_cu ? 7 : 9;
     }
     if (d->force_tile >= 21 && d->force_tile <= 23) t = d->force_tile - 14;
     else if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
+  // round 5: the 8 x 8 level's LDS-halo convs on 128 x 160 tiles, one workgroup per CU (tg_conv_halo.hip: BNT = 160): M = 1024 -> 64 tiles x 4 splits = 256
+  if (halo && d->out_w == 8 && N % 160 == 0 && (t160_mode() & 8)) t = 7;
   const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
   const long T = tm * tn;
   // K units that a split may cut at, and the fewest a work item should keep
@@ -180,6 +183,7 @@ Plan make_plan(const tg_gemm_desc* d) {
   long S = 512;
   if (!halo && (t == 1 || t == 6)) S = 768;
   if (!halo && (t == 4 || t == 5 || t == 7)) S = 256;
+  if (halo && t == 7) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
   if (d->force_split_k > 0) {
@@ -394,14 +398,17 @@ inline int bt_tile_of(const tg_gemm_desc* d) {
 
 // LayerNorm-folded projections on 128 x 160 tiles: 0 = no, 160 = three stages / one workgroup per CU, 161 = two stages / two per CU (tg_gemm_ln.hip)
 inline int ln_t160_of(const tg_gemm_desc* d) {
-  if (!(t160_mode() & 2) || d->geglu || d->N % 160 != 0 || d->M % 128 != 0 || d->K % 64 != 0 || (d->n_split > 0 && d->n_split % 160 != 0)) return 0;
+  // (attn2.to_q only: measured in situ, same box — profiles/r5_t160_findings.md — the q | k | v^T projections, whose V^T third leaves through the
+  // transposed direct epilogue, are no faster on these tiles: 16384 x 1920 x 640 76.4 -> 80.9 us, 4096 x 3840 x 1280 74.5 -> 90.3 us; to_q 33.0 -> 29.4, 29.3 -> 27.1)
+  if (!(t160_mode() & 2) || d->geglu || d->N % 160 != 0 || d->M % 128 != 0 || d->K % 64 != 0 || d->n_split > 0) return 0;
   const long t128 = (d->M / 128) * ((d->N + 127) / 128), s128 = d->K <= 640 ? 768 : 512;
   const long t160 = (d->M / 128) * (d->N / 160);
-  const long s160 = t160 <= 256 ? 256 : 512;
   const double eff128 = (double)t128 / (double)(((t128 + s128 - 1) / s128) * s128);
-  const double eff160 = (double)t160 / (double)(((t160 + s160 - 1) / s160) * s160);
-  if (t160 < 192 || eff160 < eff128 + 0.1) return 0;
-  return t160 <= 256 ? 160 : 161;
+  const double e256 = (double)t160 / (double)(((t160 + 255) / 256) * 256), e512 = (double)t160 / (double)(((t160 + 511) / 512) * 512);
+  const bool one_per_cu = e256 > e512 + 1e-9;
+  const double eff160 = one_per_cu ? e256 : e512;
+  if (t160 < 192 || eff160 < eff128 + 0.05) return 0;
+  return one_per_cu ? 160 : 161;
 }
 
 template <typename T>

@@ -207,10 +207,10 @@ void gemm_glds_kernel(GemmParams p) {
   const int srot = CH == 8 ? (srow >> 1) : (srow >> 2);
   float ln_s = 0.f, ln_q = 0.f;
 
-  // big wave tiles: fragments are read per k-step (register budget).  The 1 x 5 wave tile of the plain 128 x 160 kernel (round 5) still reads a whole K-tile's
-  // 24 fragments up front (96 VGPRs + 80 accumulators): per k-step hipcc emits read-2 / lgkmcnt(0) / mfma groups on ONE recycled register quad — ten exposed LDS
-  // latencies per K-tile with two waves per SIMD; its LayerNorm-folded instance (209 VGPRs) keeps the per-k-step form
-  constexpr bool BIGW = TM * TN > 4 && !(TM * TN == 5 && LN == 0);
+  // big wave tiles: fragments are read per k-step (register budget).  The 1 x 5 wave tile of the 128 x 160 kernels (round 5) still reads a whole K-tile's
+  // 24 fragments up front (96 VGPRs + 80 accumulators = 212 .. 239 VGPRs incl. the LayerNorm fold, no scratch): per k-step hipcc emits read-2 / lgkmcnt(0) /
+  // mfma groups on ONE recycled register quad — ten exposed LDS latencies per K-tile with two waves per SIMD (4096 x 1280 x 5120: 79 -> 72 us)
+  constexpr bool BIGW = TM * TN > 5;
   // EARLY REFILL (2 stages, all fragments of a K-tile read into registers up front): a stage is dead as soon as every wave
   // has its 16 fragments, i.e. half a K-tile before the next one starts — it is refilled right then with the tile AFTER
   // next.  Two K-tiles are in flight with two 32 KB stages; the K-tile period was one DMA round trip (~1800 cycles against
