@@ -6,7 +6,7 @@ import torch
 from theatergen_amd import ops
 from theatergen_amd.weights_pack import pack_conv3x3
 dev, dt = "cuda:0", torch.bfloat16
-NC = 4
+NC = int(os.environ.get('NC', '4'))
 def timeit(fns, iters=24):
     for f in fns: f()
     torch.cuda.synchronize()

@@ -19,11 +19,14 @@ namespace {
 // is M = 1024 pixels: 8 x 8 = 64 tiles x 4 K splits = 256 work items = exactly ONE per CU (128 x 128: 80 tiles x 5 splits = 400 items on 512 slots, 144 CUs
 // with two, 112 with one).  One workgroup per CU owns the whole LDS: the slab is DOUBLE-buffered (the next chunk's window is requested five K-steps before it
 // is needed, no barrier / drain at the chunk boundary) and the weight ring is five 20 KB stages deep (four tiles in flight: a K-step's period was one DMA
-// round trip).  Same K order per output as the 128 x 128 instance: bit-identical partial sums when the splits agree.
+// round trip).  EIGHT waves: two groups of four share every K-step — group g multiplies k-steps 2g, 2g + 1 of the 64-wide K-tile on the same 32 x 160 wave
+// tiles (12 fragment reads + 10 MFMAs per wave and step instead of 24 + 20, W requests alternate between the groups): a lone wave per SIMD pays its LDS
+// reads, its DMA issue and its MFMAs as a SUM (first version, four waves: 57.8 us = the 128 x 128 instance's 57.3), two waves per SIMD overlap them.  The
+// groups' partial accumulators meet in LDS after the loop (fixed order: group 0 + group 1), group 0 runs the epilogue.
 template <int N> __device__ __forceinline__ void halo_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int WI, bool UPS, int BNT = 128>
-__global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
+__global__ __launch_bounds__(BNT == 128 ? 256 : 512) void conv_halo_kernel(GemmParams p) {
   constexpr int BM = 128, BN = BNT, NW = 4, WAVES_N = BN == 128 ? 2 : 1, WAVES_M = NW / WAVES_N, TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr bool DEEP = BN != 128;
   static_assert(!DEEP || (WI == 8 && !UPS && BN == 160), "the deep-ring instance is the 8 x 8 level's");
@@ -32,7 +35,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   constexpr bool MULTI = WI == 8;
   static_assert(!(MULTI && UPS), "no upsample variant at width 8");
   constexpr int TH = BM / WI, WIN = UPS ? WI / 2 : WI, SW = WIN + 2, SROWS = MULTI ? 20 : (UPS ? TH / 2 + 2 : TH + 2);
-  constexpr int SLAB = SROWS * SW, NI = (SLAB + 7) / 8, SJ = (NI + NW - 1) / NW;
+  constexpr int NWD = DEEP ? 2 * NW : NW;           // waves that issue the slab's DMA (all of them)
+  constexpr int NG = DEEP ? 2 : 1, KSG = (BK / 16) / NG;     // wave groups, k-steps of a K-tile per group
+  constexpr int SLAB = SROWS * SW, NI = (SLAB + 7) / 8, SJ = (NI + NWD - 1) / NWD;
   constexpr int WJ = BN / (8 * NW);
   typedef typename Vec<T>::v8 V8;
 
@@ -48,7 +53,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = DEEP ? wave_all >> 2 : 0;           // DEEP: which half of every K-tile's k-steps this wave multiplies
+  const int wave = wave_all & 3;
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
   int lbid, split = 0, part = -1;     // same work-item scheme as gemm_glds_kernel; the K split runs over channel chunks
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   int spix[SJ];                                       // input pixel feeding this lane's slab row (-1: zero padding)
 #pragma unroll
   for (int j = 0; j < SJ; ++j) {
-    const int sr = (j * NW + wave) * 8 + lrow;
+    const int sr = (j * NWD + wave_all) * 8 + lrow;
     const int sy = sr / SW, sx = sr - sy * SW;
     int iy = iy0 + sy, im = img;
     if (MULTI) { im = img + sy / 10; iy = sy % 10 - 1; }       // slab rows [10 i, 10 i + 10) = padded window of image img + i
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     c += chunk * 8;
 #pragma unroll
     for (int j = 0; j < SJ; ++j) {
-      if (j * NW + wave < NI) {
+      if (j * NWD + wave_all < NI) {
         const T* src = spix[j] >= 0 ? base + (long)spix[j] * pitch + c : zero;
-        dma(src, sS + sb * NI * 8 * BK + (j * NW + wave) * 8 * BK);
+        dma(src, sS + sb * NI * 8 * BK + (j * NWD + wave_all) * 8 * BK);
       }
     }
   };
@@ -158,13 +165,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 #pragma unroll
   for (int s_ = 0; s_ < WD; ++s_) {
     if (s_ < nkt) {
-      issue_w(icc, itap, s_);
+      if (!DEEP || (s_ & 1) == grp) issue_w(icc, itap, s_);      // DEEP: W tile t is requested (and later awaited) by group t & 1
       if (++itap == 9) { itap = 0; ++icc; }
     }
   }
   if constexpr (DEEP) {
-    // slab + W(0) landed = at most the (min(WD, nkt) - 1) younger W tiles still in flight (LDS-DMA completes in issue order); nkt >= 9
-    halo_wait_vm<(WD - 1) * WJ>();
+    // own requests so far: slab, W(grp), W(grp + 2).  Slab + W(0) landed: group 0 lets its younger W(2) fly, group 1 (W(1), W(3) both younger than the slab)
+    // lets both fly; nkt >= 9
+    if (grp == 0) halo_wait_vm<WJ>(); else halo_wait_vm<2 * WJ>();
   } else {
     if (WD == 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const T* bw = sW + buf * BN * BK + (wave_n * TN * 32 + l31) * BK;
     const T* sSc = sS + cur * NI * 8 * BK;
-    V8 xf[BK / 16][TM], wf[BK / 16][TN];
+    V8 xf[KSG][TM], wf[KSG][TN];
+    const int ks0 = KSG * grp;                          // first k-step of this wave's group
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int sr = UPS ? (((ppy[i] + ky - 1) >> 1) + 1) * SW + ((ppx[i] + kx - 1) >> 1) + 1
@@ -185,11 +194,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
       const int key = (sr >> 1) & 7;
       const T* bx = sSc + sr * BK;
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) xf[ks][i] = *reinterpret_cast<const V8*>(bx + ((2 * ks + hi) ^ key) * 8);
+      for (int ks = 0; ks < KSG; ++ks) xf[ks][i] = *reinterpret_cast<const V8*>(bx + ((2 * (ks0 + ks) + hi) ^ key) * 8);
     }
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int so = ((2 * ks + hi) ^ rkey) * 8;
+    for (int ks = 0; ks < KSG; ++ks) {
+      const int so = ((2 * (ks0 + ks) + hi) ^ rkey) * 8;
 #pragma unroll
       for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BK + so);
     }
@@ -214,12 +223,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     if (kt + WD < nkt) {
       int nb = buf + WD;
       if (nb >= WST) nb -= WST;
-      issue_w(icc, itap, nb);
+      if (!DEEP || ((kt + WD) & 1) == grp) issue_w(icc, itap, nb);
       if (++itap == 9) { itap = 0; ++icc; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks)
+    for (int ks = 0; ks < KSG; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -230,11 +239,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
     if constexpr (DEEP) {
       // W tiles younger than W(kt + 1) that may stay in flight: W(kt + 2) .. W(min(kt + WD, nkt - 1)).  (While a slab request is younger than
       // W(kt + 1) — three steps per chunk — the count under-states what is in flight and the wait retires a little more than it has to.)
-      const int younger = nkt - 2 - kt;
-      if (younger >= WD - 1) halo_wait_vm<(WD - 1) * WJ>();
-      else if (younger == 2) halo_wait_vm<2 * WJ>();
-      else if (younger == 1) halo_wait_vm<WJ>();
-      else halo_wait_vm<0>();
+      // DEEP: W(kt + 1) was requested by group (kt + 1) & 1 — its waves wait for it, letting their one younger request W(kt + 3) fly; the other
+      // group's next tile W(kt + 2) is awaited a step later.  (A slab request younger than the awaited tile makes the wait retire a little more.)
+      if (((kt + 1) & 1) == grp) {
+        if (kt + 3 < nkt) halo_wait_vm<WJ>(); else halo_wait_vm<0>();
+      }
     } else {
       if (WD == 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -247,8 +256,37 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
   }
 
   constexpr int SCW = TN <= 2 ? TN : 2;
-  epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                 reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
+  float* scr = reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4));
+  if constexpr (DEEP) {
+    // the two groups' partial sums of the same wave tile meet in LDS (operand stages are dead: every request was awaited above): group 1 parks its 80
+    // accumulator registers per lane, group 0 adds them (fp32, fixed order) and runs the epilogue with its scratch BEHIND the parked data
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4* park = reinterpret_cast<f32x4*>(smem) + (wave * TM * TN * 4) * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            park[((i * TN + j) * 4 + g) * 64] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = park[((i * TN + j) * 4 + g) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += o[e];
+        }
+    scr = reinterpret_cast<float*>(smem) + NW * TM * TN * 4 * 64 * 4 + wave * (32 * (SCW * 32 + 4));
+  }
+  epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane, scr, part, m0, n0);
 }
 
 template <typename T, int WI, bool UPS, int BNT = 128>
@@ -259,7 +297,7 @@ int launch_halo(const GemmParams& p, int grid, hipStream_t st) {
   auto k = conv_halo_kernel<T, WI, UPS, BNT>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(BNT == 128 ? 256 : 512), lds, st, p);
   TG_LAUNCH_CHECK();
   return TG_OK;
 }

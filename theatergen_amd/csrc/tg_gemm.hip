@@ -101,11 +101,11 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
-// dev A/B knob TG_T160 (bit mask, default 15): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
+// dev A/B knob TG_T160 (bit mask, default 7): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
 // projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960), 8 = the 8 x 8 level's LDS-halo convs on 128 x 160 tiles
 inline int t160_mode() {
   const char* e = getenv("TG_T160");
-  return e ? (int)strtol(e, nullptr, 0) : 15;
+  return e ? (int)strtol(e, nullptr, 0) : 7;
 }
 
 inline long t3_max_tiles() {
