@@ -50,28 +50,27 @@ def tensor_version(t):
 # ordered against kernels already queued on those streams (VERDICT r4 weak item 5 / ADVICE r3): ``IPAttnProcessor.scale = s`` therefore fences the
 # fill against every registered replay stream — the current stream first waits for what they have queued (no write under a running reader), they
 # then wait for the fill (every later replay reads the new value).  No registered stream (the default single-stream engine): no cost.
-_REPLAY_STREAMS = []          # weak references to torch.cuda.Stream objects
+_REPLAY_STREAMS = []          # (torch.device, torch.cuda.Stream): STRONG references — the owner unregisters (``unregister_replay_stream``, a
+                              # ``weakref.finalize`` of the engine); a weakly referenced Stream object crashed in ``.device`` on the GPU box
 
 
-def register_replay_stream(stream):
-    for r in _REPLAY_STREAMS:
-        if r() is stream:
+def register_replay_stream(stream, device=None):
+    dev = torch.device(device) if device is not None else stream.device
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    for d, st in _REPLAY_STREAMS:
+        if st is stream:
             return stream
-    _REPLAY_STREAMS.append(weakref.ref(stream))
+    _REPLAY_STREAMS.append((dev, stream))
     return stream
 
 
+def unregister_replay_stream(stream):
+    _REPLAY_STREAMS[:] = [(d, st) for d, st in _REPLAY_STREAMS if st is not stream]
+
+
 def _live_replay_streams(device):
-    out, dead = [], False
-    for r in _REPLAY_STREAMS:
-        st = r()
-        if st is None:
-            dead = True
-        elif st.device == device:
-            out.append(st)
-    if dead:
-        _REPLAY_STREAMS[:] = [r for r in _REPLAY_STREAMS if r() is not None]
-    return out
+    return [st for d, st in _REPLAY_STREAMS if d == device]
 
 
 def fenced_fill(t, value):

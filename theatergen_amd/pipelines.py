@@ -11,11 +11,12 @@ and copies latents to the CPU every step).  Any number of independent character 
 dimension (CFG batch 2*n: all uncond rows first, then all cond rows = ``noise_pred.chunk(2)`` order).
 """
 import os
+import weakref
 
 import torch
 
 from . import ops
-from .attention_processor import register_replay_stream, tensor_version
+from .attention_processor import register_replay_stream, tensor_version, unregister_replay_stream
 from .scheduler import DDIMScheduler
 from .unet import DeviceSchedule
 
@@ -262,7 +263,8 @@ class DenoiseEngine:
     def _stream(self):
         if getattr(self, "_own_stream", None) is None:
             # registered: host-side writes of device scalars the captured step reads (IPAttnProcessor.scale) fence against it
-            self._own_stream = register_replay_stream(torch.cuda.Stream(device=self.dev))
+            self._own_stream = register_replay_stream(torch.cuda.Stream(device=self.dev), self.dev)
+            weakref.finalize(self, unregister_replay_stream, self._own_stream)
         return self._own_stream
 
     def run(self, latents, before_step=None):
