@@ -260,7 +260,7 @@ def test_skinny_gemm_large_k_instances_after_the_register_fix():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(16384, 640, 640), (4096, 1280, 1280), (9000, 1000, 192), (300, 640, 64), (4096, 1280, 5120), (66000, 320, 320)])
-def test_gemm_128x160_tiles(dtype, shape):
+def test_gemm_128x160_tiles(dtype, shape, monkeypatch):
     """round 5: gemm_glds_kernel on 128 x 160 tiles (force_tile 21 / 23 = BK 64 x 3 stages / BK 64 x 2 stages; tg_gemm_t160.hip) —
     ragged M and N, K of one tile up to 80 tiles, bias + per-batch vector + residual through the chunked LDS epilogue; the K order per output is the
     128 x 128 kernel's, so the results must be BIT-identical to it; and the planner's own choice (force_tile 0) for the shapes it was built for."""
@@ -276,9 +276,15 @@ def test_gemm_128x160_tiles(dtype, shape):
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
     base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
     for tile in (21, 23, 0):
+        # K rotation (dev bit 16: every work item starts its K walk at another tile — another fp32 summation order, deterministic; measured slower, off)
+        monkeypatch.setenv("TG_T160", "23")
         out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         check(out, ref, dtype, f"128x160 tile {tile} {shape}")
+        assert torch.equal(out, ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)), "not run-to-run identical"
+        monkeypatch.setenv("TG_T160", "7")                  # rotation off: the 128 x 128 kernel's K order per output -> the same bits
+        out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
+        monkeypatch.delenv("TG_T160")
     if (M, N) in ((16384, 640), (4096, 1280)):
         pl = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, plan_only=True)
         assert (pl[0], pl[1]) == (128, 160), pl
@@ -303,6 +309,7 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     xd = x.to(DEV)
     w = rnd((C, C), dtype, g, 1 / math.sqrt(C))
     wl, u, v = pack_ln_linear(w.to(DEV), None, gamma.to(DEV), beta.to(DEV))
+    monkeypatch.setenv("TG_T160", "7")                       # K rotation off for the bit-identity part; the rotated default is checked at the end
     on160 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)[:2] == (128, 160)
     assert on160 or C == 320                                 # (65536 x 320 fills whole rounds with 128 x 128 already: planner keeps it)
     got = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
@@ -337,6 +344,10 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     check(old, got.float(), dtype, f"ln-folded 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(qk0, qk.float(), dtype, f"ln-folded q|k 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(vt0, vt.float(), dtype, f"ln-folded v^T 128x160 vs 128x128 {(M, C)}", scale=0.5)
+    monkeypatch.setenv("TG_T160", "23")
+    rot = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
+    check(rot, xn @ w.float().t(), dtype, f"ln-folded to_q 128x160, rotated K walk {(M, C)}", scale=1.5)
+    assert torch.equal(rot, ops.gemm(xd, wl, M, C, C, ln=(u, v, eps)))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -111,7 +111,17 @@ __global__ __launch_bounds__(BNT == 128 ? 256 : 512) void conv_halo_kernel(GemmP
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
   };
-  auto issue_slab = [&](int cc, int sb = 0) {
+  // channel chunks of this work item (kt_per_split counts chunks here)
+  const int c_begin = part >= 0 ? split * p.kt_per_split : 0;
+  int c_end = part >= 0 ? c_begin + p.kt_per_split : nchunks;
+  if (c_end > nchunks) c_end = nchunks;
+  // CHUNK ROTATION (round 5, p.k_rot): work item lbid walks its chunks starting at chunk lbid % (number of chunks) and wraps — the workgroups of a launch run in
+  // lockstep and would otherwise all ask the L2 for the same K offset (same few channels) at the same time; see tg_gemm_glds.h.  cc below = LOGICAL chunk.
+  const int ncl = c_end - c_begin;
+  const int crot = (p.k_rot != 0 && ncl > 1) ? lbid % ncl : 0;
+  auto pchunk = [&](int cc) { int t = cc - c_begin + crot; if (t >= ncl) t -= ncl; return c_begin + t; };
+  auto issue_slab = [&](int ccl, int sb = 0) {
+    const int cc = pchunk(ccl);
     int c = cc * BK;
     const T* base = A0;
     int pitch = p.c0;
@@ -125,7 +135,8 @@ __global__ __launch_bounds__(BNT == 128 ? 256 : 512) void conv_halo_kernel(GemmP
       }
     }
   };
-  auto issue_w = [&](int cc, int tap, int buf) {
+  auto issue_w = [&](int ccl, int tap, int buf) {
+    const int cc = pchunk(ccl);
     const long kc = (long)tap * ctot + cc * BK + chunk * 8;
     T* dw = sW + buf * BN * BK;
 #pragma unroll
@@ -153,11 +164,6 @@ __global__ __launch_bounds__(BNT == 128 ? 256 : 512) void conv_halo_kernel(GemmP
     ppy[i] = MULTI ? (pm >> 6) * 10 + ((pm & 63) >> 3) : pm / WI;
     ppx[i] = pm % WI;
   }
-
-  // channel chunks of this work item (kt_per_split counts chunks here)
-  const int c_begin = part >= 0 ? split * p.kt_per_split : 0;
-  int c_end = part >= 0 ? c_begin + p.kt_per_split : nchunks;
-  if (c_end > nchunks) c_end = nchunks;
 
   const int nkt = (c_end - c_begin) * 9;
   int icc = c_begin, itap = 0;                         // (chunk, tap) of the next W tile to request

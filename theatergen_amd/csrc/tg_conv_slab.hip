@@ -108,7 +108,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                    : "memory");
     };
     const T* wlane = nullptr;                      // this lane's 16 bytes of (row wave * 8 + lane / 8, tap 0, chunk 0) of the tile's rows
-    auto issue_w = [&](int cc, int tap, int stage) {
+    int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
+    int crot = 0;                                       // CHUNK ROTATION (round 5, p.k_rot): the work item walks its chunks starting at chunk (item % nchunks) and
+    // wraps — lockstep workgroups otherwise ask the L2 for the same K offset (the same few channels) at the same time; see tg_gemm_glds.h
+    auto pchunk = [&](int cc) { int t = cc - cfirst + crot; if (t >= nchunks) t -= nchunks; return cfirst + t; };
+    auto issue_w = [&](int ccl, int tap, int stage) {
+      const int cc = pchunk(ccl);
       const T* src = wlane + ((long)tap * ctot + cc * BK);
       const unsigned dst = lds0 + W_BASE + (unsigned)stage * WST_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 ca0, ca1, cd0, cd1;                       // its GroupNorm coefficients a[8], d[8] (of the image of patch 0)
     f32x4 cb0, cb1, ce0, ce1;                       // NP = 2: the same for the image of patch 1 (slab rows >= WIN)
     int img = 0, img1 = 0;
-    auto load_slab = [&](int cc) {                  // request chunk cc of the window (asm: the compiler's waitcnt pass must not see these)
+    auto load_slab = [&](int ccl) {                 // request chunk cc of the window (asm: the compiler's waitcnt pass must not see these)
+      const int cc = pchunk(ccl);
       int c = cc * BK;
       const T* base = A0;
       int pitch = p.c0;
@@ -188,7 +194,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < SJ; ++j) *reinterpret_cast<u32x4*>(smem + sdst + (unsigned)j * 4096u) = sreg[j];
     };
-    int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
     auto setup_tile = [&](int v) {
       int t, sp;
       work_item(v, t, sp);
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       cfirst = sp * cps;
       nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
       nkt = nchunks * 9;
+      crot = (p.k_rot != 0 && nchunks > 1) ? v % nchunks : 0;
       // PATCH TILES (round 3): a tile is TH rows x WI columns of an image that may be WIDER than WI (p.in_w = 128 with WI = 64: SDXL's
       // 128 x 128 level; p.in_w = 96 with WI = 32: SD-2.1's 96 x 96 level): tile_m -> (image, patch row ty, patch column tx); the
       // window's halo columns then hold real neighbour pixels instead of padding.  p.in_w == WI is the whole-rows case of round 2.

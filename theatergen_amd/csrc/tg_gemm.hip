@@ -101,7 +101,7 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
-// dev A/B knob TG_T160 (bit mask, default 7): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
+// dev A/B knob TG_T160 (bit mask, default 7; dev bits: 16 = K rotation of the 128 x 160 launches (tg_gemm_glds.h), 32 / 64 = chunk rotation of the halo / slab convs): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
 // projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960), 8 = the 8 x 8 level's LDS-halo convs on 128 x 160 tiles
 inline int t160_mode() {
   const char* e = getenv("TG_T160");
@@ -447,6 +447,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     const long tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
     p.full_tiles = (int)tiles; p.tail_s = 1; p.tiles_n = (int)((d->N + bn - 1) / bn); p.tile_bm = 128; p.tile_bn = bn;
     p.kt_per_split = 0;
+    p.k_rot = (t160 && (t160_mode() & 16)) ? 1 : 0;
     return tg_gemm_ln_launch(d, &p, t160 ? t160 : (d->K <= 640 ? 1 : 0), (int)tiles, st);
   }
   if (const int sp = slab_splits_of(d); sp > 0) {
@@ -463,6 +464,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
       p.patch_np = np;
       if (patch) { int l = 0; while ((1 << l) < pw) ++l; p.patch_pwl = l; }
     }
+    p.k_rot = (t160_mode() & 64) ? 1 : 0;                 // dev A/B: chunk rotation of the slab conv's K walk
     int rc = tg_conv_slab_launch(d, &p, sp, st);
     if (rc != TG_OK || sp == 1) return rc;
     p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
@@ -496,6 +498,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     return tg_gemm_bt_launch(d, &p, bt, st);
   }
   if (pl.halo) {
+    p.k_rot = (t160_mode() & 32) ? 1 : 0;                 // dev A/B: chunk rotation of the LDS-halo conv's K walk
     const int rc = tg_conv_halo_launch(d, &p, pl.full + pl.tail * pl.s, st);
     if (rc != TG_OK) return rc;
     return launch_reduce<T>(p, pl, st);
@@ -509,6 +512,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 6: return launch_cfg2<T, 128, 128, 2, 2, 3, 32>(d, p, pl, st);   // three 16 KB K stages: 3 blocks / CU
     case 7: case 8: case 9: {                                             // 128 x 160 tiles (tg_gemm_t160.hip): 7 = 1 block / CU, 8 / 9 = 2 blocks / CU
       TG_CHECK(d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE, TG_ERR_ARG, "tg_gemm: the 128 x 160 tiles take plain GEMMs with a linear epilogue");
+      p.k_rot = (t160_mode() & 16) ? 1 : 0;
       const int rc = tg_gemm_t160_launch(d, &p, pl.tile - 7, pl.full + pl.tail * pl.s, st);
       if (rc != TG_OK) return rc;
       return launch_reduce<T>(p, pl, st);

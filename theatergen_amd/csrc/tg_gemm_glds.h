@@ -95,6 +95,13 @@ void gemm_glds_kernel(GemmParams p) {
   int kt_end = part >= 0 ? kt_begin + p.kt_per_split : nkt_total;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
+  // K ROTATION (round 5, p.k_rot; the 128 x 160 launches): work item `lbid` walks its K-tiles starting at tile lbid % nkt and wraps.  The single-round
+  // launches run in lockstep: with an operand row pitch that is a large power-of-two multiple (K = 5120: 10 KiB, K = 2560: 5 KiB) every workgroup of an XCD
+  // asks the SAME few L2 channels for the same K offset at the same time (profiles/r5_operand_pitch.txt: 4096 x 1280 x 5120 594 TF, 718-751 TF with the pitch
+  // padded by 64 / 192 elements).  Consecutive lbid share an XCD (xcd_chunked_block_id), so its 32 CUs spread over 32 consecutive 128-byte K offsets.
+  // fp32 accumulation order per output now depends on the tile: deterministic, not bit-identical to the unrotated kernels.
+  const int rot = (p.k_rot != 0 && nkt > 1) ? lbid % nkt : 0;
+  auto ktile = [&](int i) { int t = i + rot; if (t >= nkt) t -= nkt; return kt_begin + t; };
 
   // DMA lane geometry: instruction q covers tile rows [RPI*q, RPI*q + RPI); lane -> (row RPI*q + lane/CH, slot lane%CH)
   const int lrow = lane / CH;
@@ -220,14 +227,14 @@ void gemm_glds_kernel(GemmParams p) {
     // counted waits: a wave only waits until the NEXT tile's DMA has landed (vmcnt(NDMA) = one younger tile may stay in
     // flight; LDS-DMA completes in issue order); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
     if constexpr (ER) {
-      issue_tile(kt_begin, 0);
-      if (nkt > 1) issue_tile(kt_begin + 1, 1);
+      issue_tile(ktile(0), 0);
+      if (nkt > 1) issue_tile(ktile(1), 1);
       if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
 #pragma unroll
       for (int s = 0; s < PF; ++s)
-        if (s < nkt) issue_tile(kt_begin + s, s);
+        if (s < nkt) issue_tile(ktile(s), s);
       if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -268,7 +275,7 @@ void gemm_glds_kernel(GemmParams p) {
         if (it + PF < nkt) {
           int nb = buf + PF;
           if (nb >= STAGES) nb -= STAGES;
-          issue_tile(kt_begin + it + PF, nb);
+          issue_tile(ktile(it + PF), nb);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -288,7 +295,7 @@ void gemm_glds_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (it + 2 < nkt) issue_tile(kt_begin + it + 2, buf);
+            if (it + 2 < nkt) issue_tile(ktile(it + 2), buf);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
