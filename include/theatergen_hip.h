@@ -390,8 +390,7 @@ typedef struct {
   int32_t ln;
   float ln_eps;
   int32_t variant;
-  /* K = 640 (the 32 x 32 level): `wpk` = rc_pack_tiles(w, page = False) (N / 32 tiles of 40 KiB, no vector pages), the vectors as fp32 [N] arrays
-   * in natural channel order: v640 = bias (or W beta + bias under the fold; may be NULL), u640 = row sums of the rounded W gamma (fold only) */
+  /* reserved (round 4's K = 640 variant, removed in round 5: K must be 320); kept so that the struct layout / ABI version do not move */
   const float* v640;
   const float* u640;
 } tg_rc_linear_desc;

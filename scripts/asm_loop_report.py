@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from theatergen_amd import build as tg_build  # noqa: E402
 
-HOT = ["tg_conv_slab.hip", "tg_conv_halo.hip", "tg_gemm.hip", "tg_gemm_ln.hip", "tg_gemm_bt.hip", "tg_gemm_lc.hip", "tg_attention.hip", "tg_rowchain.hip"]
+HOT = ["tg_conv_slab.hip", "tg_conv_halo.hip", "tg_gemm.hip", "tg_gemm_ln.hip", "tg_gemm_bt.hip", "tg_attention.hip", "tg_rowchain.hip"]
 
 
 def demangle(names):

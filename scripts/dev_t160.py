@@ -23,8 +23,7 @@ def case(M, N, K, res=True):
     outs = [torch.empty(M, N, device=dev, dtype=dt) for _ in range(NCOPY)]
     ref = ops.gemm(As[0], ws[0], M, N, K, bias=b, res=rs[0], force_tile=1).clone()
     row = []
-    for ft, rotenv in ((0, "0"), (1, "0"), (21, "0"), (23, "0"), (21, "16"), (23, "16")):
-        os.environ["TG_T160"] = rotenv                       # "16" = rules off, K rotation of the forced 128 x 160 launch on
+    for ft in (0, 1, 7, 21, 23):
         try:
             pl = ops.gemm(As[0], ws[0], M, N, K, bias=b, res=rs[0], force_tile=ft, plan_only=True)
             got = ops.gemm(As[0], ws[0], M, N, K, bias=b, res=rs[0], force_tile=ft)
@@ -32,7 +31,7 @@ def case(M, N, K, res=True):
             fns = [(lambda i=i: ops.gemm(As[i], ws[i], M, N, K, bias=b, res=rs[i], out=outs[i], force_tile=ft)) for i in range(NCOPY)]
             timeit(fns)
             t = timeit(fns)
-            row.append(f"ft{ft}{'r' if rotenv == '16' else ''}[{pl[0]}x{pl[1]}s{pl[2]}]{'' if same else '!DIFF'}:{t:6.1f}")
+            row.append(f"ft{ft}[{pl[0]}x{pl[1]}s{pl[2]}]{'' if same else '!DIFF'}:{t:6.1f}")
         except RuntimeError as e:
             row.append(f"ft{ft}:ERR {str(e)[:40]}")
     print(f"M={M:6d} N={N:5d} K={K:5d} res={int(res)} {2.0 * M * N * K / 1e9:6.1f} GF  " + " ".join(row), flush=True)

@@ -379,7 +379,6 @@ def test_gemm_planner_kernel_choice(monkeypatch):
         return d
     assert plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(65536, 320, 320))[3] == 0
     assert plan(gemm(65536, 2560, 320, geglu=1)) == (256, 256, 1, 3)          # fused GEGLU FF1 on the big tile
-    assert plan(gemm(16384, 640, 2560))[3] == 0                              # loader / compute GEMM: not selected by default
     # round 5: tile-count-aware 128 x 160 tiles where they fill whole rounds (512 / 256 tiles) and 128 x 128 does not (640 / 320)
     assert plan(gemm(16384, 640, 2560))[:2] == (128, 160) and plan(gemm(16384, 640, 640))[:2] == (128, 160) and plan(gemm(4096, 1280, 1280))[:2] == (128, 160)
     assert plan(gemm(4096, 10240, 1280))[:2] == (128, 128) and plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(1024, 1280, 1280))[:2] == (64, 64)
@@ -389,10 +388,6 @@ def test_gemm_planner_kernel_choice(monkeypatch):
     monkeypatch.setenv("TG_T160", "0")
     assert plan(gemm(16384, 640, 2560))[:2] == (128, 128)
     monkeypatch.delenv("TG_T160")
-    assert plan(gemm(16384, 640, 2560, force_tile=13)) == (128, 320, 1, 5)
-    assert plan(gemm(4096, 1280, 5120, force_tile=14)) == (128, 320, 2, 5)
-    monkeypatch.setenv("TG_GEMM_FLAGS", "256")
-    assert plan(gemm(16384, 640, 2560)) == (128, 320, 1, 5) and plan(gemm(4096, 1280, 5120)) == (128, 320, 2, 5)
 
 
 def test_shift_tensor_ignore_last_dim_matches_reference_formula():

@@ -614,7 +614,7 @@ def test_latent_shift_and_compose_at_96x96():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(66000, 320, 320), (9000, 1000, 192), (4096, 1280, 1280), (300, 640, 64), (16384, 640, 2560)])
 def test_gemm_big_tiles(dtype, shape):
-    """The big-tile kernels (tg_gemm_bt.hip: force_tile 9 = 128 x 320, 10 = 256 x 256; 8 waves, persistent, one barrier per
+    """The big-tile kernel (tg_gemm_bt.hip: force_tile 10 = 256 x 256 — its 128 x 320 sibling was removed in round 5; 8 waves, persistent, one barrier per
     K-tile, asm LDS-DMA / fragment reads with counted waits): ragged M and N, K of one tile up to 40 tiles, several output
     tiles per workgroup (the cross-tile prefetch), bias + per-batch vector + residual in the chunked LDS epilogue.  They
     accumulate in the same order as the 128 x 128 kernel, so the results must also be BIT-identical to it."""
@@ -628,7 +628,7 @@ def test_gemm_big_tiles(dtype, shape):
     ad, wd, bd, rd, vd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev), bvec.to(dev)
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
     base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
-    for tile in (9, 10):
+    for tile in (10,):
         out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         check(out, ref, dtype, f"big tile {tile} {shape}")
         same = torch.equal(out, base)
@@ -637,7 +637,7 @@ def test_gemm_big_tiles(dtype, shape):
         same = torch.equal(out, again)
         assert same
     # activation epilogue + scale
-    out = ops.linear(ad, wd, bd, act=ops.ACT_SILU, out_scale=0.5, force_tile=9)
+    out = ops.linear(ad, wd, bd, act=ops.ACT_SILU, out_scale=0.5, force_tile=10)
     check(out, F.silu(ad.float() @ wd.float().t() + bd.float()).cpu() * 0.5, dtype, f"big tile silu {shape}")
 
 
@@ -653,7 +653,7 @@ def test_gemm_big_tiles_qkv_split_and_geglu(dtype):
     M, N, K = B * rows, 3 * C, C
     a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
     ref = a.float() @ w.float().t()
-    for tile in (1, 9):
+    for tile in (1, 10):
         out = torch.zeros((M, 2 * C), dtype=dtype, device=dev)
         out_t = torch.zeros((B, C, rows), dtype=dtype, device=dev)
         ops.gemm(a.to(dev), w.to(dev), M, N, K, rows_per_batch=rows, out=out, n_split=2 * C, out_t=out_t, ldt=rows, force_tile=tile)
@@ -808,39 +808,6 @@ def test_conv_gn_prologue_rejected_outside_the_slab_kernel():
     coef = torch.zeros(2, 2, 128, device=dev)
     with pytest.raises(RuntimeError, match="slab conv kernel"):
         ops.conv3x3(x, wp, 2, 8, 8, 128, a_coef=coef, a_silu=True)
-
-
-# ---- loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles, long K, optional K split ----
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [
-    # M, N, K, force_tile (13 = 1 split, 14 = 2 splits, 0 = heuristic), expected splits
-    (256, 320, 1280, 13, 1),           # two tiles, 20 K-steps
-    (1024, 640, 64, 13, 1),            # ONE K-step (no refill, no second stage)
-    (384, 960, 192, 14, 2),            # 3 K-steps split 2 + 1
-    (4096, 1280, 5120, 0, 2),          # SD-1.5 16x16 level FeedForward net.2: 128 tiles -> the heuristic splits K in 2
-    (16384, 640, 2560, 0, 1),          # FeedForward net.2 at 32x32: 256 tiles
-    (34816, 320, 1024, 13, 1),         # 272 tiles on 256 persistent workgroups
-])
-def test_gemm_loader_compute_kernel(dtype, case, monkeypatch):
-    """vs fp32 matmul with bias + per-batch vector + residual + scale; deterministic; kernel_kind 5 (the heuristic takes it
-    only with the dev switch TG_GEMM_FLAGS bit 8: measured no end-to-end gain, see tg_gemm.hip)"""
-    from theatergen_amd import ops
-    dev = _dev()
-    M, N, K, ft, want_s = case
-    monkeypatch.setenv("TG_GEMM_FLAGS", "256")
-    g = torch.Generator().manual_seed(M + N + K)
-    a = rnd((M, K), dtype, g).to(dev)
-    w = rnd((N, K), dtype, g, 1 / math.sqrt(K)).to(dev)
-    bias, res = rnd((N,), dtype, g).to(dev), rnd((M, N), dtype, g).to(dev)
-    nb = 4
-    bvec = rnd((nb, N), dtype, g).to(dev)
-    ref = (a.float() @ w.float().t() + bias.float() + bvec.float().repeat_interleave(M // nb, dim=0) + res.float()) * 0.5
-    kw = dict(bias=bias, res=res, bvec=bvec, rows_per_batch=M // nb, out_scale=0.5, force_tile=ft)
-    tm, tn, sp, kk = ops.gemm(a, w, M, N, K, plan_only=True, **kw)
-    assert (tm, tn, sp, kk) == (128, 320, want_s, 5)
-    out = ops.gemm(a, w, M, N, K, **kw)
-    check(out, ref.cpu(), dtype, f"loader/compute gemm {case}")
-    assert torch.equal(out, ops.gemm(a, w, M, N, K, **kw))
 
 
 LN_CASES = [  # (rows, C, row mean offset, row scale): the offset / scale stress the mean * u cancellation and E[x^2] - mean^2

@@ -260,7 +260,7 @@ def test_skinny_gemm_large_k_instances_after_the_register_fix():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(16384, 640, 640), (4096, 1280, 1280), (9000, 1000, 192), (300, 640, 64), (4096, 1280, 5120), (66000, 320, 320)])
-def test_gemm_128x160_tiles(dtype, shape, monkeypatch):
+def test_gemm_128x160_tiles(dtype, shape):
     """round 5: gemm_glds_kernel on 128 x 160 tiles (force_tile 21 / 23 = BK 64 x 3 stages / BK 64 x 2 stages; tg_gemm_t160.hip) —
     ragged M and N, K of one tile up to 80 tiles, bias + per-batch vector + residual through the chunked LDS epilogue; the K order per output is the
     128 x 128 kernel's, so the results must be BIT-identical to it; and the planner's own choice (force_tile 0) for the shapes it was built for."""
@@ -276,15 +276,9 @@ def test_gemm_128x160_tiles(dtype, shape, monkeypatch):
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
     base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
     for tile in (21, 23, 0):
-        # K rotation (dev bit 16: every work item starts its K walk at another tile — another fp32 summation order, deterministic; measured slower, off)
-        monkeypatch.setenv("TG_T160", "23")
         out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         check(out, ref, dtype, f"128x160 tile {tile} {shape}")
-        assert torch.equal(out, ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)), "not run-to-run identical"
-        monkeypatch.setenv("TG_T160", "7")                  # rotation off: the 128 x 128 kernel's K order per output -> the same bits
-        out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
-        monkeypatch.delenv("TG_T160")
     if (M, N) in ((16384, 640), (4096, 1280)):
         pl = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, plan_only=True)
         assert (pl[0], pl[1]) == (128, 160), pl
@@ -309,7 +303,6 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     xd = x.to(DEV)
     w = rnd((C, C), dtype, g, 1 / math.sqrt(C))
     wl, u, v = pack_ln_linear(w.to(DEV), None, gamma.to(DEV), beta.to(DEV))
-    monkeypatch.setenv("TG_T160", "7")                       # K rotation off for the bit-identity part; the rotated default is checked at the end
     on160 = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps), plan_only=True)[:2] == (128, 160)
     assert on160 or C == 320                                 # (65536 x 320 fills whole rounds with 128 x 128 already: planner keeps it)
     got = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
@@ -344,45 +337,3 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     check(old, got.float(), dtype, f"ln-folded 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(qk0, qk.float(), dtype, f"ln-folded q|k 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(vt0, vt.float(), dtype, f"ln-folded v^T 128x160 vs 128x128 {(M, C)}", scale=0.5)
-    monkeypatch.setenv("TG_T160", "23")
-    rot = ops.gemm(xd, wl, M, C, C, ln=(u, v, eps))
-    check(rot, xn @ w.float().t(), dtype, f"ln-folded to_q 128x160, rotated K walk {(M, C)}", scale=1.5)
-    assert torch.equal(rot, ops.gemm(xd, wl, M, C, C, ln=(u, v, eps)))
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,cin,c1,cout", [(16, 1280, 0, 1280), (16, 1280, 1280, 1280), (16, 640, 640, 1280), (4, 1280, 0, 320), (18, 1280, 0, 1280)])
-def test_conv_halo_8x8_on_128x160_tiles(dtype, B, cin, c1, cout, monkeypatch):
-    """round 5: the 8 x 8 level's conv3x3 (ResnetBlock2D convs of the mid / last down / first up blocks: 1024 pixels at CFG batch 16) on the LDS-halo
-    kernel's 128 x 160 instance — one workgroup per CU, double-buffered window, five-stage weight ring, K split over the channel chunks — vs the fp32
-    reference of the op (bias + time-embedding vector + residual in the reduce epilogue), vs the 128 x 128 instance (TG_T160 without bit 3), run to run."""
-    import torch.nn.functional as F
-    from tests.test_kernels_gpu import check, rnd
-    from theatergen_amd import ops
-    from theatergen_amd.weights_pack import pack_conv3x3
-    h = w = 8
-    ctot = cin + c1
-    g = torch.Generator().manual_seed(B + cin + c1 + cout)
-    x = rnd((B, ctot, h, w), dtype, g).to(DEV)
-    wt = rnd((cout, ctot, 3, 3), dtype, g, 1 / (9 * ctot) ** 0.5).to(DEV)
-    bias, bvec = rnd((cout,), dtype, g).to(DEV), rnd((B, cout), dtype, g).to(DEV)
-    res = rnd((B * h * w, cout), dtype, g).to(DEV)
-    ref = F.conv2d(x.float(), wt.float(), bias.float(), padding=1) + bvec.float()[:, :, None, None]
-    ref = ref.permute(0, 2, 3, 1).reshape(B * h * w, cout) + res.float()
-    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, ctot)
-    x0 = tok[:, :cin].contiguous()
-    x1 = tok[:, cin:].contiguous() if c1 else None
-    wp = pack_conv3x3(wt)
-    kw = dict(x1=x1, c1=c1, bias=bias, bvec=bvec, rows_per_batch=h * w, res=res)
-    monkeypatch.setenv("TG_T160", "15")                      # bit 3: the 128 x 160 instance (measured no faster in situ: off by default)
-    pl = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
-    got = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
-    check(got, ref.cpu(), dtype, f"conv 8x8 {(B, cin, c1, cout)} plan {pl}")
-    assert torch.equal(got, ops.conv3x3(x0, wp, B, h, w, cin, **kw))
-    if cout % 160 == 0 and (B * h * w) % 128 == 0 and B * h * w >= 1024:
-        assert pl[:2] == (128, 160) and pl[3] == 2, pl
-    monkeypatch.setenv("TG_T160", "7")
-    pl0 = ops.conv3x3(x0, wp, B, h, w, cin, plan_only=True, **kw)
-    assert pl0[:2] != (128, 160)
-    old = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
-    check(old, got.float(), dtype, f"conv 8x8 128x160 vs 128x128 {(B, cin, c1, cout)}", scale=0.5)

@@ -67,7 +67,7 @@ def test_rc_linear_rejects_other_shapes():
         ops.rc_linear(x, torch.zeros((64 // 32) * 64 * 1280, dtype=torch.uint8, device=DEV), 64)        # K = 1280: a row does not fit the registers
     x6 = torch.zeros(64, 640, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError):
-        ops.rc_linear(x6, torch.zeros((64 // 32) * 64 * 640, dtype=torch.uint8, device=DEV), 64)        # K = 640 needs N % 128 == 0
+        ops.rc_linear(x6, torch.zeros((128 // 32) * 64 * 640, dtype=torch.uint8, device=DEV), 128)      # K = 640: round 4's variant was removed
 
 
 def _xattn_case(B, N, T, dtype, seed, ip_w=0.4):
@@ -257,31 +257,3 @@ def test_rc_front_vs_fp32_reference(dtype, B, N):
     check(gy, y, f"rc_front y B{B} N{N} {dtype}", 1.5 * l2, 1.5 * mx)
     check(gqk, qkv[:, :640], f"rc_front qk B{B} N{N} {dtype}", 2 * l2, 2 * mx)
     check(gvt[:, :, :N].permute(0, 2, 1).reshape(M, C), qkv[:, 640:], f"rc_front v^T B{B} N{N} {dtype}", 2 * l2, 2 * mx)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,res,ln", [(16384, 640, True, False), (1000, 128, True, True), (4096, 1280, False, True), (130, 640, False, False)])
-def test_rc_linear_k640_vs_fp32(dtype, M, N, res, ln):
-    """The K = 640 variant of tg_rc_linear (one wave per SIMD, the two waves of a token pair split the output chunks; built and parity-tested,
-    not selected by the UNet: it measured slower than tg_gemm) vs the fp32 reference of the op"""
-    from theatergen_amd import ops
-    from theatergen_amd.weights_pack import pack_ln_linear, rc_pack_tiles
-    g = torch.Generator().manual_seed(M + N + 1)
-    K = 640
-    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(dtype).to(DEV)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).to(DEV)
-    bias = torch.randn(N, generator=g).to(dtype).to(DEV)
-    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(dtype).to(DEV)
-    beta = (0.1 * torch.randn(K, generator=g)).to(dtype).to(DEV)
-    r = torch.randn(M, N, generator=g).to(dtype).to(DEV) if res else None
-    if ln:
-        Wp, u, v = pack_ln_linear(W, bias, gamma, beta)
-        ref = F.linear(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5), W.float(), bias.float())
-        got = ops.rc_linear(x, rc_pack_tiles(Wp, page=False), N, res=r, ln_eps=1e-5, v=v, u=u)
-    else:
-        ref = F.linear(x.float(), W.float(), bias.float())
-        got = ops.rc_linear(x, rc_pack_tiles(W, page=False), N, res=r, v=bias.float().contiguous())
-    if res:
-        ref = ref + r.float()
-    l2, mx = tols(dtype)
-    check(got, ref, f"rc_linear K640 {M}x{N} res={res} ln={ln} {dtype}", l2 * (1.5 if ln else 1), mx * (1.5 if ln else 1))

@@ -473,9 +473,7 @@ class AttnProcessor(nn.Module):
             enc, L, enc_bs = _enc_rows(encoder_hidden_states)
             mask = _prepare_mask(attention_mask, L, B, heads, N) if attention_mask is not None else None
             ctx = enc.shape[2]
-            q = rowchain.ln_linear640(x, wl, ul, vl, norm.eps, attn, "q", _cached) if lnq and rows is None else None
-            if q is None:
-                q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight, attn.to_q.bias)
+            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight, attn.to_q.bias)
             ldt = _round8(L)
             k = torch.empty((B * L, inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
@@ -644,9 +642,7 @@ class IPAttnProcessor(nn.Module):
         if _fused_ln is not None:
             norm, rows = _fused_ln
             wl, ul, vl = ln_weight(attn, "q", norm)
-            q = rowchain.ln_linear640(x, wl, ul, vl, norm.eps, attn, "q", _cached) if rows is None else None
-            if q is None:
-                q = ops.linear(x, wl, ln=(ul, vl, norm.eps, rows))
+            q = ops.linear(x, wl, ln=(ul, vl, norm.eps, rows))
         else:
             q = ops.linear(x, attn.to_q.weight, attn.to_q.bias)
         o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)

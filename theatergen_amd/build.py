@@ -134,7 +134,6 @@ HOT_GATES = [
     # change can only lower them (VERDICT r3 item 4 asks for 0 inside the K loops)
     ("conv_slab_kernel<", 320, 256),
     ("bt_gemm_kernel<", 132, 256),
-    ("lc_gemm_kernel<", 100, 256),
     # row-chain kernels (round 4): straight-line register-array code — any scratch means an array fell out of the registers
     ("rc_xattn_kernel<", 0, 256),
     ("rc_ff_kernel<", 0, 256),

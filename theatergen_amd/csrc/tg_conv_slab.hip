@@ -109,9 +109,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     const T* wlane = nullptr;                      // this lane's 16 bytes of (row wave * 8 + lane / 8, tap 0, chunk 0) of the tile's rows
     int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
-    int crot = 0;                                       // CHUNK ROTATION (round 5, p.k_rot): the work item walks its chunks starting at chunk (item % nchunks) and
-    // wraps — lockstep workgroups otherwise ask the L2 for the same K offset (the same few channels) at the same time; see tg_gemm_glds.h
-    auto pchunk = [&](int cc) { int t = cc - cfirst + crot; if (t >= nchunks) t -= nchunks; return cfirst + t; };
+    // (a per-work-item rotation of the chunk walk — L2 channel spread of lockstep workgroups — was measured in round 5: 1.5 % SLOWER end to end)
+    auto pchunk = [&](int cc) { return cc; };
     auto issue_w = [&](int ccl, int tap, int stage) {
       const int cc = pchunk(ccl);
       const T* src = wlane + ((long)tap * ctot + cc * BK);
@@ -202,7 +201,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       cfirst = sp * cps;
       nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
       nkt = nchunks * 9;
-      crot = (p.k_rot != 0 && nchunks > 1) ? v % nchunks : 0;
       // PATCH TILES (round 3): a tile is TH rows x WI columns of an image that may be WIDER than WI (p.in_w = 128 with WI = 64: SDXL's
       // 128 x 128 level; p.in_w = 96 with WI = 32: SD-2.1's 96 x 96 level): tile_m -> (image, patch row ty, patch column tx); the
       // window's halo columns then hold real neighbour pixels instead of padding.  p.in_w == WI is the whole-rows case of round 2.

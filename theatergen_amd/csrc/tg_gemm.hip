@@ -101,8 +101,8 @@ inline long t64_max_tiles() {
   return e ? strtol(e, nullptr, 0) : 128;
 }
 
-// dev A/B knob TG_T160 (bit mask, default 7; dev bits: 16 = K rotation of the 128 x 160 launches (tg_gemm_glds.h), 32 / 64 = chunk rotation of the halo / slab convs): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
-// projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960), 8 = the 8 x 8 level's LDS-halo convs on 128 x 160 tiles
+// dev A/B knob TG_T160 (bit mask, default 7): 1 = 128 x 160 tiles for plain GEMMs where they fill whole rounds, 2 = the same for the LayerNorm-folded
+// projections, 4 = plain GEMMs whose N is 2.5 / 7.5 tiles of 128 (N = 320, 960)
 inline int t160_mode() {
   const char* e = getenv("TG_T160");
   return e ? (int)strtol(e, nullptr, 0) : 7;
@@ -164,8 +164,6 @@ Plan make_plan(const tg_gemm_desc* d) {
     else if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
-  // round 5: the 8 x 8 level's LDS-halo convs on 128 x 160 tiles, one workgroup per CU (tg_conv_halo.hip: BNT = 160): M = 1024 -> 64 tiles x 4 splits = 256
-  if (halo && d->out_w == 8 && N % 160 == 0 && (t160_mode() & 8)) t = 7;
   const long tm = (M + kTiles[t].bm - 1) / kTiles[t].bm, tn = (N + kTiles[t].bn - 1) / kTiles[t].bn;
   const long T = tm * tn;
   // K units that a split may cut at, and the fewest a work item should keep
@@ -183,7 +181,6 @@ Plan make_plan(const tg_gemm_desc* d) {
   long S = 512;
   if (!halo && (t == 1 || t == 6)) S = 768;
   if (!halo && (t == 4 || t == 5 || t == 7)) S = 256;
-  if (halo && t == 7) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
   if (d->force_split_k > 0) {
@@ -240,12 +237,10 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
 }
 
 }  // namespace
-// big-tile kernels (tg_gemm_bt.hip): bt_tile 0 = 256 x 320, 1 = 128 x 320, 2 = 256 x 256
+// big-tile kernel (tg_gemm_bt.hip): bt_tile 2 = 256 x 256 (the 128 x 320 instance, bt_tile 1, was removed in round 5)
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
 // slab conv kernel (tg_conv_slab.hip): BM x 320 output tiles, GroupNorm(+SiLU) prologue on the staged window
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
-// loader / compute GEMM (tg_gemm_lc.hip): 128 x 320 tiles for long-K plain GEMMs
-int tg_gemm_lc_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
 // LayerNorm-fused projections (tg_gemm_ln.hip): 128 x 128 tiles, no K split
 int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, int grid, void* stream);
 // 128 x 160 tiles (tg_gemm_t160.hip): variant 0 = BK 64 x 3 stages, 1 = BK 32 x 4 stages, 2 = BK 64 x 2 stages
@@ -336,36 +331,10 @@ inline int slab_splits_of(const tg_gemm_desc* d) {
   return best_s;
 }
 
-// Loader / compute GEMM (tg_gemm_lc.hip): plain GEMM, one A source, N a multiple of 320, K a multiple of 64 and >= 1024, linear
-// epilogue.  -> K splits per tile (1 | 2), 0 = not taken.  force_tile 13 / 14 = 1 / 2 splits regardless of the tile count (tests);
-// the heuristic wants the persistent grid (256 workgroups) at least 3/4 full in every round, with the K split if that is what it
-// takes and every split keeps >= 32 K-steps.  NOT selected by default: in isolation (scripts/dev_lc_bench.py, rotating operands) it
-// beats the 128x128 kernel on the FeedForward output projections (65536x320x1280 98 vs 110 us, 16384x640x2560 81 vs 102,
-// 4096x1280x5120 split in two 86 vs 97, 8192x3840x4096 846 vs 746 TF), in the hipGraph-replayed bench the same launches change
-// nothing (7.910 vs 7.924 images/s, three interleaved rounds): at K = 1280..5120 a 128 x 320 tile is 20..80 K-steps, and its
-// epilogue (the compute waves alone, twelve dependent residual-load -> bounce -> store chains) is as long as a 20-step K loop.
-// TG_GEMM_FLAGS bit 8 (dev) turns the heuristic on.
-inline int lc_splits_of(const tg_gemm_desc* d) {
-  if (d->mode != 0 || d->geglu || d->act != TG_ACT_NONE || d->a1 != nullptr || d->a_rows_per_batch > 0 || d->n_split > 0) return 0;
-  if (d->N % 320 != 0 || d->K % BK != 0 || d->M % 128 != 0 || d->force_split_k > 1) return 0;
-  if (d->force_tile == 13) return 1;
-  if (d->force_tile == 14) return d->K / BK >= 2 ? 2 : 0;
-  if (d->force_tile != 0) return 0;
-  {
-    const char* e = getenv("TG_GEMM_FLAGS");
-    const long f = e ? strtol(e, nullptr, 0) : 0;
-    if (!(f & 256)) return 0;
-    if (d->K < ((f & 512) ? 256 : 1024)) return 0;        // dev bit 9: short-K GEMMs too (A/B experiment)
-  }
-  const long t = (d->M / 128) * (d->N / 320);
-  auto full = [](long n) { return 4 * n >= 3 * ((n + 255) / 256) * 256; };
-  if (full(t)) return 1;
-  // (split in 2 only where each half keeps >= 32 K-steps: 4096 x 1280 x 1280 measured 39 us split against 30 on the 128x128 kernel)
-  if (d->K / BK >= 64 && full(2 * t)) return 2;
-  return 0;
-}
-
-// Big tiles (tg_gemm_bt.hip): force_tile 9 = 128 x 320, 10 = 256 x 256; plain GEMM with one A source, K a multiple of 64,
+// (Round 2's loader / compute GEMM on 128 x 320 tiles, tg_gemm_lc.hip / force_tile 13, 14 — faster than the 128 x 128 kernel in isolation on the long-K
+// FeedForward projections (16384 x 640 x 2560: 81 vs 102 us), never selected: no gain under graph replay — was REMOVED in round 5: the tile-count-aware
+// 128 x 160 tiles run the same shape in 69 us and ARE selected.)
+// Big tile (tg_gemm_bt.hip): force_tile 10 = 256 x 256 (round 2 also had force_tile 9 = 128 x 320; the notes below are its measurements); plain GEMM with one A source, K a multiple of 64,
 // no K split.  What the heuristic (force_tile 0) takes, and why so little (profiles/r2_gemm_findings.md, all on MI355X):
 //   * isolated launches (scripts/dev_bt_bench.py, rotating operands; us, 128x128 -> big tile): fused GEGLU 65536x2560x320
 //     230 -> 188, 16384x5120x640 193 -> 156; projections 16384x640x640 29.1 -> 25.6, 16384x640x2560 92 -> 80, 65536x320x320
@@ -376,11 +345,12 @@ inline int lc_splits_of(const tg_gemm_desc* d) {
 //     faster (7.698).  rocprofv3 + rocm-smi of the two runs: the projection launches take the same time as before (32.4 us
 //     average against 128x128's mix), but the shader clock settles at ~2150 MHz instead of ~2225 MHz (at LOWER package power,
 //     1170 vs 1240 W) and every other kernel of the step slows down with it (attention 288 -> 303 us, halo convs +2..4 %).
-//   So only the GEGLU tile is selected; 128 x 320 stays available as force_tile 9 (parity-tested, bit-identical results).
+//   So only the GEGLU tile is selected; 128 x 320 was removed in round 5 (the 128 x 160 tiles took its place AND pay under graph replay).
 inline int bt_tile_of(const tg_gemm_desc* d) {
   const int ft = d->force_tile;
   const bool can = d->mode == 0 && d->force_split_k <= 1 && d->a1 == nullptr && d->K % BK == 0;
-  if (ft >= 9 && ft <= 10) return can ? ft - 8 : -1;
+  if (ft == 10) return can ? 2 : -1;
+  if (ft == 9) return -1;                     // (the 128 x 320 big tile of round 2 was removed in round 5: never selected)
   if (ft != 0 || !can) return -1;
   int devf = 0;
   { const char* e = getenv("TG_GEMM_FLAGS"); devf = e ? (int)strtol(e, nullptr, 0) : 0; }   // dev A/B switches
@@ -388,10 +358,6 @@ inline int bt_tile_of(const tg_gemm_desc* d) {
   if (d->geglu) {
     const long tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     return (d->M >= 16384 && tiles >= 1024) ? 2 : -1;
-  }
-  if ((devf & 64) && d->N % 320 == 0 && d->N <= 640 && (d->n_split <= 0 || d->n_split % 160 == 0)) {   // off by default (see above)
-    const long tiles = ((d->M + 127) / 128) * (d->N / 320);
-    if (tiles >= 256 && !(d->N == 320 && d->K >= 1280)) return 1;
   }
   return -1;
 }
@@ -447,7 +413,6 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     const long tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
     p.full_tiles = (int)tiles; p.tail_s = 1; p.tiles_n = (int)((d->N + bn - 1) / bn); p.tile_bm = 128; p.tile_bn = bn;
     p.kt_per_split = 0;
-    p.k_rot = (t160 && (t160_mode() & 16)) ? 1 : 0;
     return tg_gemm_ln_launch(d, &p, t160 ? t160 : (d->K <= 640 ? 1 : 0), (int)tiles, st);
   }
   if (const int sp = slab_splits_of(d); sp > 0) {
@@ -464,22 +429,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
       p.patch_np = np;
       if (patch) { int l = 0; while ((1 << l) < pw) ++l; p.patch_pwl = l; }
     }
-    p.k_rot = (t160_mode() & 64) ? 1 : 0;                 // dev A/B: chunk rotation of the slab conv's K walk
     int rc = tg_conv_slab_launch(d, &p, sp, st);
-    if (rc != TG_OK || sp == 1) return rc;
-    p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
-    Plan rp = pl;
-    rp.tail = (int)tiles; rp.s = sp;
-    return launch_reduce<T>(p, rp, st);
-  }
-  if (const int sp = lc_splits_of(d); sp > 0) {
-    const long tiles = (d->M / 128) * (d->N / 320);
-    if (sp > 1) {
-      const int64_t need = tiles * sp * 128 * 320 * 4;
-      TG_CHECK(d->workspace != nullptr && d->workspace_bytes >= need, TG_ERR_ARG, "tg_gemm: the K split needs %lld workspace bytes, got %lld",
-               (long long)need, (long long)d->workspace_bytes);
-    }
-    int rc = tg_gemm_lc_launch(d, &p, sp, st);
     if (rc != TG_OK || sp == 1) return rc;
     p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
     Plan rp = pl;
@@ -494,11 +444,10 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   }
   if (const int bt = bt_tile_of(d); bt >= 0) {
     TG_CHECK(!d->geglu || bt == 2, TG_ERR_ARG, "tg_gemm: the GEGLU epilogue needs the 256 x 256 big tile (force_tile 10)");
-    TG_CHECK(d->n_split <= 0 || d->n_split % (bt == 2 ? 128 : 160) == 0, TG_ERR_ARG, "tg_gemm: big tiles need n_split on a wave-tile boundary");
+    TG_CHECK(d->n_split <= 0 || d->n_split % 128 == 0, TG_ERR_ARG, "tg_gemm: the big tile needs n_split on a wave-tile boundary");
     return tg_gemm_bt_launch(d, &p, bt, st);
   }
   if (pl.halo) {
-    p.k_rot = (t160_mode() & 32) ? 1 : 0;                 // dev A/B: chunk rotation of the LDS-halo conv's K walk
     const int rc = tg_conv_halo_launch(d, &p, pl.full + pl.tail * pl.s, st);
     if (rc != TG_OK) return rc;
     return launch_reduce<T>(p, pl, st);
@@ -512,7 +461,6 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 6: return launch_cfg2<T, 128, 128, 2, 2, 3, 32>(d, p, pl, st);   // three 16 KB K stages: 3 blocks / CU
     case 7: case 8: case 9: {                                             // 128 x 160 tiles (tg_gemm_t160.hip): 7 = 1 block / CU, 8 / 9 = 2 blocks / CU
       TG_CHECK(d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE, TG_ERR_ARG, "tg_gemm: the 128 x 160 tiles take plain GEMMs with a linear epilogue");
-      p.k_rot = (t160_mode() & 16) ? 1 : 0;
       const int rc = tg_gemm_t160_launch(d, &p, pl.tile - 7, pl.full + pl.tail * pl.s, st);
       if (rc != TG_OK) return rc;
       return launch_reduce<T>(p, pl, st);
@@ -592,16 +540,9 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
     if (kernel_kind) *kernel_kind = 4;
     return TG_OK;
   }
-  if (const int sp = lc_splits_of(d); sp > 0) {
-    if (tile_m) *tile_m = 128;
-    if (tile_n) *tile_n = 320;
-    if (splits) *splits = sp;
-    if (kernel_kind) *kernel_kind = 5;
-    return TG_OK;
-  }
   if (const int bt = bt_tile_of(d); bt >= 0) {
-    if (tile_m) *tile_m = bt == 1 ? 128 : 256;
-    if (tile_n) *tile_n = bt == 1 ? 320 : 256;
+    if (tile_m) *tile_m = 256;
+    if (tile_n) *tile_n = 256;
     if (splits) *splits = 1;
     if (kernel_kind) *kernel_kind = 3;
     return TG_OK;
@@ -618,7 +559,6 @@ extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
   if (d->ln_u != nullptr) return 0;
   if (const int sp = slab_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
-  if (const int sp = lc_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
 }

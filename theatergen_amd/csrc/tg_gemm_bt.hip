@@ -283,11 +283,9 @@ int launch_bt(const tg_gemm_desc* d, GemmParams p, hipStream_t st) {
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (bt_tile != 1 && bt_tile != 2) { tg_set_error("tg_gemm: unknown big tile %d", bt_tile); return TG_ERR_ARG; }
+  if (bt_tile != 2) { tg_set_error("tg_gemm: unknown big tile %d (the 128 x 320 instance was removed in round 5: never selected)", bt_tile); return TG_ERR_ARG; }
   if (d->dtype == TG_BF16) {
-    if (bt_tile == 1) return launch_bt<bf16_t, 128, 320, 4, 2>(d, p, st);
     return launch_bt<bf16_t, 256, 256, 4, 2>(d, p, st);
   }
-  if (bt_tile == 1) return launch_bt<f16_t, 128, 320, 4, 2>(d, p, st);
   return launch_bt<f16_t, 256, 256, 4, 2>(d, p, st);
 }

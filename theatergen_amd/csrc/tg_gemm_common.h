@@ -49,7 +49,6 @@ struct GemmParams {
   // slab conv PATCH tiles (tg_conv_slab.hip): a 128-pixel tile = patch_np patches of (128 / patch_np >> patch_pwl) rows x (1 << patch_pwl)
   // columns of an in_h x in_w image, patches numbered image-major / patch-row / patch-column.  patch_pwl = 0: tile rows are contiguous tokens.
   int patch_pwl, patch_np;
-  int k_rot;        // gemm_glds_kernel: rotate the K-tile walk by the work item's index (L2 channel spread of lockstep single-round launches)
   int slab_order;   // slab conv work order: 0 tile-major, 1 (column tile, split)-major / row-tile-minor (weight-heavy layers)
 };
 

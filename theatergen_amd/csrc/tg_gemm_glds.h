@@ -95,13 +95,10 @@ void gemm_glds_kernel(GemmParams p) {
   int kt_end = part >= 0 ? kt_begin + p.kt_per_split : nkt_total;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
-  // K ROTATION (round 5, p.k_rot; the 128 x 160 launches): work item `lbid` walks its K-tiles starting at tile lbid % nkt and wraps.  The single-round
-  // launches run in lockstep: with an operand row pitch that is a large power-of-two multiple (K = 5120: 10 KiB, K = 2560: 5 KiB) every workgroup of an XCD
-  // asks the SAME few L2 channels for the same K offset at the same time (profiles/r5_operand_pitch.txt: 4096 x 1280 x 5120 594 TF, 718-751 TF with the pitch
-  // padded by 64 / 192 elements).  Consecutive lbid share an XCD (xcd_chunked_block_id), so its 32 CUs spread over 32 consecutive 128-byte K offsets.
-  // fp32 accumulation order per output now depends on the tile: deterministic, not bit-identical to the unrotated kernels.
-  const int rot = (p.k_rot != 0 && nkt > 1) ? lbid % nkt : 0;
-  auto ktile = [&](int i) { int t = i + rot; if (t >= nkt) t -= nkt; return kt_begin + t; };
+  // (K ROTATION — every work item starting its K walk at another tile so that the lockstep workgroups of a single-round launch do not ask the same few L2
+  // channels for the same K offset — was built and measured in round 5: the operand-pitch effect is real (profiles/r5_operand_pitch.txt: 4096 x 1280 x 5120
+  // 594 TF, 718-751 TF with the row pitch padded by 64 / 192 elements) but the rotation loses more L2 locality than it wins: 16384 x 640 x 2560 70.2 -> 80.1 us.)
+  auto ktile = [&](int i) { return kt_begin + i; };
 
   // DMA lane geometry: instruction q covers tile rows [RPI*q, RPI*q + RPI); lane -> (row RPI*q + lane/CH, slot lane%CH)
   const int lrow = lane / CH;

@@ -1043,201 +1043,8 @@ int launch_rc_front(const tg_rc_front_desc* d, const RcFrontParams& p, hipStream
   return TG_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// rc_linear_wide_kernel: the K = 640 projections of the 32 x 32 level (16384 tokens at CFG batch 16: to_out + residual, proj_in, proj_out, the
-// LayerNorm-folded to_q) in row-chain form.  Only 512 wave-tasks of 32 tokens exist for 1024 SIMDs, and a token row is 160 VGPRs, so:
-// a workgroup = 64 tokens x 4 waves, ONE wave per SIMD; waves (0, 1) share tokens 0-31, waves (2, 3) tokens 32-63, and the two waves of a pair
-// split the OUTPUT chunks by parity (wave parity p computes chunks p, p + 2, ...): every SIMD of all 256 CUs runs 400 MFMAs.  LDS holds four
-// 40-KiB weight tiles (the current tile of each parity + the next: 160 KiB exactly), so the streams carry no vector page: bias / LayerNorm
-// vectors come from fp32 arrays in natural channel order (accumulator register rho of lane half hi = channel 64 c + 32 hi + 16 u + rho).
-struct RcWideParams {
-  const void* x;
-  long ldx;
-  const void* wpk;        // rc_pack_tiles(w, page=False): N / 32 tiles of K / 16 KiB
-  const float* v;         // fp32 [N]: bias, or W beta + bias under the fold; may be NULL
-  const float* u;         // fp32 [N]: fold only
-  const void* res;
-  long ldres;
-  void* out;
-  long ldc;
-  long M;
-  int N;
-  float ln_eps;
-};
-
-template <typename T, bool LN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rc_linear_wide_kernel(RcWideParams p) {
-  typedef typename Vec<T>::v8 V8;
-  constexpr int KS = 40, NW = 4;
-  constexpr int TB = KS * 1024;                // bytes of a weight tile (no vector page)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int par = wave & 1;                    // which output chunks this wave computes
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int lbid = rc_block_id((int)blockIdx.x, (int)gridDim.x);
-  const long tok0 = ((long)lbid * 2 + (wave >> 1)) * 32;
-  const int qb = lane & 3;
-  long mrow[4];
-  bool mok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long r = tok0 + (l31 & ~3) + i;
-    mok[i] = r < p.M;
-    mrow[i] = mok[i] ? r : p.M - 1;
-  }
-  const int NCH = p.N >> 6;                    // 64-channel chunks (even)
-  const int NST = NCH;                         // stages: stage s holds tile (chunk 2 (s >> 1) + q, u = s & 1) for q = 0, 1
-  const char* wg = reinterpret_cast<const char*>(p.wpk) + lane * 16;
-  // stage s -> slots (s & 1) * 2 + q: 80 pieces, 20 per wave (pieces 0-39 = parity 0's tile, 40-79 = parity 1's)
-  auto issue_stage = [&](int s) __attribute__((always_inline)) {
-    if (s >= NST) return;
-#pragma unroll
-    for (int j = 0; j < 20; ++j) {
-      const int piece = j * NW + wave;
-      const int q = piece >= 40 ? 1 : 0, pi = piece - 40 * q;
-      const long tile = 2 * (2 * (long)(s >> 1) + q) + (s & 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + tile * TB + pi * 1024),
-                                       (__attribute__((address_space(3))) void*)(smem + ((s & 1) * 2 + q) * TB + pi * 1024), 16, 0, 0);
-    }
-  };
-  issue_stage(0);
-
-  V8 B[KS];
-  {
-    const T* xp = reinterpret_cast<const T*>(p.x) + 32 * hi + 8 * qb;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) B[s] = *reinterpret_cast<const V8*>(xp + mrow[s & 3] * p.ldx + 64 * (s >> 2));
-#pragma unroll
-    for (int q = 0; q < KS / 4; ++q) quad_transpose(B[4 * q], B[4 * q + 1], B[4 * q + 2], B[4 * q + 3]);
-  }
-  float ln_rstd = 1.f, ln_std = 1.f, ln_nmean = 0.f;
-  if constexpr (LN) {
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += to_f32<T>(B[s][e]);
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.0f / 640.0f);
-    float c2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      asm volatile("" : "+v"(B[s]));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = to_f32<T>(B[s][e]) - mean; c2 = __builtin_fmaf(d, d, c2); }
-    }
-    c2 += __shfl_xor(c2, 32, 64);
-    const float var = c2 * (1.0f / 640.0f) + p.ln_eps;
-    ln_rstd = __builtin_amdgcn_rsqf(var);
-    ln_std = var * ln_rstd;
-    ln_nmean = -mean;
-  } else {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(B[s]));
-  }
-
-  const T* resp = reinterpret_cast<const T*>(p.res);
-  T* outp = reinterpret_cast<T*>(p.out);
-  V8 pend[4], half[2], r8[4];
-  long pend_ch = -1;
-  for (int s = 0; s < NST; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_stage(s + 1);
-    if (pend_ch >= 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + pend_ch + 8 * qb) = pend[i];
-      pend_ch = -1;
-    }
-    const int c = 2 * (s >> 1) + par, uu = s & 1;
-    const long ch0 = 64 * (long)c + 32 * hi;
-    if (uu == 0 && resp != nullptr) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r8[i] = *reinterpret_cast<const V8*>(resp + mrow[i] * p.ldres + ch0 + 8 * qb);
-    }
-    // seed: v (plain) or std * v - mean * u (fold)
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.v != nullptr) v4 = *reinterpret_cast<const f32x4*>(p.v + ch0 + 16 * uu + 4 * g);
-      if constexpr (LN) {
-        const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.u + ch0 + 16 * uu + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = __builtin_fmaf(ln_nmean, u4[e], ln_std * v4[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
-      }
-    }
-    const char* cb = smem + ((s & 1) * 2 + par) * TB + lane * 16;
-    constexpr int PD = 8;
-    V8 a[KS];
-#pragma unroll
-    for (int x = 0; x < PD; ++x) a[x] = *reinterpret_cast<const V8*>(cb + x * 1024);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int x = 0; x < KS; ++x) {
-      if (x + PD < KS) a[x + PD] = *reinterpret_cast<const V8*>(cb + (x + PD) * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      acc = mfma32(a[x], B[x], acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (LN) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
-    }
-    if (uu == 0) {
-      if (resp != nullptr) {
-        quad_transpose(r8[0], r8[1], r8[2], r8[3]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += to_f32<T>(r8[r >> 3][r & 7]);
-      }
-      half[0] = pack8r<T>(acc, 0);
-      half[1] = pack8r<T>(acc, 8);
-    } else {
-      if (resp != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += to_f32<T>(r8[2 + (r >> 3)][r & 7]);
-      }
-      pend[0] = half[0]; pend[1] = half[1]; pend[2] = pack8r<T>(acc, 0); pend[3] = pack8r<T>(acc, 8);
-      quad_transpose(pend[0], pend[1], pend[2], pend[3]);
-      pend_ch = ch0;
-    }
-  }
-  if (pend_ch >= 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + pend_ch + 8 * qb) = pend[i];
-  }
-}
-
-template <typename T>
-int launch_rc_linear_wide(const tg_rc_linear_desc* d, hipStream_t st) {
-  RcWideParams p;
-  p.x = d->x; p.ldx = d->ldx; p.wpk = d->wpk; p.v = d->v640; p.u = d->u640; p.res = d->res; p.ldres = d->ldres; p.out = d->out; p.ldc = d->ldc;
-  p.M = d->M; p.N = d->N; p.ln_eps = d->ln_eps;
-  const size_t lds = 4 * 40 * 1024;
-  const long grid = (d->M + 63) / 64;
-  if (d->ln) {
-    auto k = rc_linear_wide_kernel<T, true>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
-  } else {
-    auto k = rc_linear_wide_kernel<T, false>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
-  }
-  TG_LAUNCH_CHECK();
-  return TG_OK;
-}
-
+// (Round 4's rc_linear_wide_kernel — the K = 640 projections of the 32 x 32 level in row-chain form, one wave per SIMD — measured 37.3 us against tg_gemm's
+// 30.2 on 16384 x 640 x 640 + residual and was never selected; removed in round 5, where the 128 x 160 tiles take the same launches in 27.4 us.)
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})  (asm immediates need constants)
 template <int... X, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, X...>, F&& f) {
   (f(std::integral_constant<int, X>{}), ...);
@@ -1670,17 +1477,9 @@ inline bool rc_dev_enabled() {
 extern "C" int tg_rc_linear(const tg_rc_linear_desc* d, void* stream) {
   TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_rc_linear: null descriptor");
   TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_rc_linear: dtype %d", d->dtype);
-  TG_CHECK(d->K == 320 || d->K == 640, TG_ERR_ARG, "tg_rc_linear: K = %d (320 or 640: the token row lives in registers)", d->K);
-  TG_CHECK(d->variant >= 0 && ((d->variant >> 8) == 0 || rc_dev_enabled()), TG_ERR_ARG, "tg_rc_linear: variant %d carries dev bits (TG_RC_DEV=1 enables them)", d->variant);
+  TG_CHECK(d->K == 320, TG_ERR_ARG, "tg_rc_linear: K = %d (320: the token row lives in registers; the K = 640 variant of round 4 was removed)", d->K);
   TG_CHECK(d->N > 0 && d->N % 64 == 0, TG_ERR_ARG, "tg_rc_linear: N = %d must be a positive multiple of 64", d->N);
-  if (d->K == 640) {
-    TG_CHECK(d->N % 128 == 0, TG_ERR_ARG, "tg_rc_linear: K = 640 needs N %% 128 == 0 (the two waves of a pair split the 64-channel chunks), got %d", d->N);
-    TG_CHECK(d->M > 0 && d->x && d->wpk && d->out && (!d->ln || d->u640), TG_ERR_ARG, "tg_rc_linear: null operand");
-    TG_CHECK(d->ldx >= 640 && d->ldx % 8 == 0 && d->ldc >= d->N && d->ldc % 8 == 0 && (!d->res || (d->ldres >= d->N && d->ldres % 8 == 0)), TG_ERR_ARG,
-             "tg_rc_linear: row pitches");
-    hipStream_t st640 = reinterpret_cast<hipStream_t>(stream);
-    return d->dtype == TG_BF16 ? launch_rc_linear_wide<bf16_t>(d, st640) : launch_rc_linear_wide<f16_t>(d, st640);
-  }
+  TG_CHECK(d->variant >= 0 && ((d->variant >> 8) == 0 || rc_dev_enabled()), TG_ERR_ARG, "tg_rc_linear: variant %d carries dev bits (TG_RC_DEV=1 enables them)", d->variant);
   TG_CHECK(d->M > 0 && d->x && d->wpk && d->out, TG_ERR_ARG, "tg_rc_linear: null operand or M <= 0");
   TG_CHECK(d->ldx >= d->K && d->ldx % 8 == 0 && d->ldc >= d->N && d->ldc % 8 == 0, TG_ERR_ARG, "tg_rc_linear: row pitches must be multiples of 8 elements");
   TG_CHECK(!d->res || (d->ldres >= d->N && d->ldres % 8 == 0), TG_ERR_ARG, "tg_rc_linear: residual pitch");

@@ -137,8 +137,6 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         kname = "conv_halo_kernel<128x128>"
     elif kk.value == 4:
         kname = f"conv_slab_kernel<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
-    elif kk.value == 5:
-        kname = f"lc_gemm_kernel<{tm.value}x{tn.value}>"
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
     elif kk.value == 6:
@@ -190,14 +188,16 @@ def linear(x, w, bias=None, **kw):
     return gemm(x, w, M, N, K, bias=bias, **kw)
 
 
-def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0, v=None, u=None):
+def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0):
     """Row-chain projection (csrc/tg_rowchain.hip): out = [LayerNorm-folded] x @ W^T + v (+ res) with the token rows in registers;
     ``wpk`` = ``weights_pack.rc_pack(W, v, u)`` (uint8 chunk stream), x [M, 320]."""
     from ._lib import RcLinearDesc
     _need_cuda(x)
     M, K = x.shape
     assert x.stride(1) == 1 and wpk.dtype == torch.uint8
-    assert wpk.numel() == ((N // 64) * (128 * K + 1024) if K == 320 else (N // 32) * 64 * K), (wpk.numel(), N, K)
+    if K != 320:
+        raise RuntimeError(f"rc_linear: K = {K} (the row-chain projection keeps a 320-channel token row in registers)")
+    assert wpk.numel() == (N // 64) * (128 * K + 1024), (wpk.numel(), N, K)
     if out is None:
         out = torch.empty(M, N, dtype=x.dtype, device=x.device)
     d = RcLinearDesc()
@@ -208,7 +208,6 @@ def rc_linear(x, wpk, N, *, res=None, ln_eps=None, out=None, variant=0, v=None, 
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.ln, d.ln_eps = (1, float(ln_eps)) if ln_eps is not None else (0, 0.0)
     d.variant = int(variant)
-    d.v640, d.u640 = _ptr(v), _ptr(u)        # K = 640 only: fp32 vectors outside the tile stream
     _profiled(lambda: _lib.check(_lib.lib().tg_rc_linear(C.byref(d), _stream())), "rc_linear_kernel<320>" + ("+ln" if ln_eps is not None else ""),
               M, N, K, 2.0 * M * N * K, res is not None)
     return out

@@ -14,8 +14,7 @@ from .weights_pack import rc_pack, rc_pack_tiles
 # TG_RC: 0 = the row-chain kernels are never selected (old-path A/B), 1 = default.  TG_RC_MIN_ROWS: below this many token rows the
 # LDS-tiled GEMMs / the three-launch cross-attention stay (a row-chain workgroup is a long serial chain: it needs a full chip of them)
 ENABLED = os.environ.get("TG_RC", "1") != "0"
-# dev A/B bits: 0 tg_rc_linear swaps (K = 320), 1 tg_rc_xattn, 2 tg_rc_ff, 3 tg_rc_front, 4 tg_rc_linear at K = 640 (built, parity-tested, NOT selected:
-# 37.3 vs 30.2 us on 16384 x 640 x 640 + residual — profiles/r4_rowchain_findings.md)
+# dev A/B bits: 0 tg_rc_linear swaps (K = 320), 1 tg_rc_xattn, 2 tg_rc_ff, 3 tg_rc_front
 MODE = int(os.environ.get("TG_RC_MODE", "15"))
 MIN_ROWS = int(os.environ.get("TG_RC_MIN_ROWS", "8192"))
 # rc_linear / rc_front / rc_ff are one long serial chain per workgroup (a lone rc_ff workgroup needs ~95 us): below one full round of 128-token
@@ -103,12 +102,9 @@ def pack_xattn_out(wo, bo):
     return rc_pack_tiles(w2, bo.detach().float() if bo is not None else None)
 
 
-MIN_ROWS_WIDE = int(os.environ.get("TG_RC_MIN_ROWS_WIDE", "16384"))    # K = 640: 64-token workgroups, one full round at 16384 rows
-
-
 def linear320(x2d, lin_weight, bias, res, owner, name, cached):
-    """``x @ W^T + b (+ res)`` through ``tg_rc_linear`` when the shape pays — K = 320 (rows >= MIN_ROWS_CHAIN, N % 64 == 0) or K = 640
-    (MODE bit 4; rows >= MIN_ROWS_WIDE, N % 128 == 0) —, else None.  ``cached(owner, name, tensors, build)`` is the caller's packed-weight cache."""
+    """``x @ W^T + b (+ res)`` through ``tg_rc_linear`` when the shape pays — K = 320, rows >= MIN_ROWS_CHAIN, N % 64 == 0 —, else None.
+    ``cached(owner, name, tensors, build)`` is the caller's packed-weight cache."""
     M, K = x2d.shape
     N = lin_weight.shape[0]
     if not ENABLED or x2d.stride(1) != 1 or lin_weight.shape[1] != K:
@@ -118,23 +114,8 @@ def linear320(x2d, lin_weight, bias, res, owner, name, cached):
         trace("linear320 yes", name, M, N)
         wpk = cached(owner, "rc_" + name, ts, lambda: rc_pack(lin_weight.detach(), bias.detach().float() if bias is not None else None))
         return ops.rc_linear(x2d, wpk, N, res=res)
-    if K == 640 and (MODE & 16) and N % 128 == 0 and M >= MIN_ROWS_WIDE:
-        trace("linear640 yes", name, M, N)
-        wpk, v = cached(owner, "rc6_" + name, ts, lambda: (rc_pack_tiles(lin_weight.detach(), page=False),
-                                                          bias.detach().float().contiguous() if bias is not None else None))
-        return ops.rc_linear(x2d, wpk, N, res=res, v=v)
     trace("linear_rc no", name, M, K, N)
     return None
-
-
-def ln_linear640(x2d, wl, ul, vl, eps, owner, name, cached):
-    """LayerNorm-folded projection (``pack_ln_linear`` output W', u, v) at K = 640 through ``tg_rc_linear``, or None"""
-    M, K = x2d.shape
-    N = wl.shape[0]
-    if not ENABLED or not (MODE & 16) or K != 640 or N % 128 or M < MIN_ROWS_WIDE or x2d.stride(1) != 1:
-        return None
-    wpk = cached(owner, "rc6ln_" + name, [wl, ul, vl], lambda: rc_pack_tiles(wl, page=False))
-    return ops.rc_linear(x2d, wpk, N, ln_eps=eps, v=vl, u=ul)
 
 
 def xattn_eligible(attn, C, B, N, L, T, dtype):
