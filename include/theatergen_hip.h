@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 304
+#define TG_ABI_VERSION 305
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -497,6 +497,32 @@ typedef struct {
   tg_skinny_seg seg[3];
 } tg_skinny_desc;
 int tg_skinny_gemm(const tg_skinny_desc* d, void* stream);
+
+/* tg_xq_attn (round 5): norm2 + attn2.to_q + the (decoupled text + image) cross-attention of an inner-level BasicTransformerBlock in ONE launch —
+ * reference models/attention.py:206-224 (norm2 -> attn2), ip_adapter/attention_processor.py:282-393 (AttnProcessor) / :396-553 (IPAttnProcessor: two
+ * independent softmaxes, :482-516).  The LayerNorm-folded to_q GEMM runs on 128 x 160 tiles (two heads of 80 or one head of 160 channels) and its
+ * epilogue computes O = softmax(q Kt^T) Vt + scale * softmax(q Kip^T) Vip from the accumulators: q and the attention launch do not exist; `out` = O [M, C]
+ * (what attn.to_out consumes).  `wq` / `ln_u` / `ln_v`: LayerNorm fold of (softmax scale * log2 e) * to_q (host: weights_pack.pack_ln_linear);
+ * `kv`: the conditioning's K / V^T as MFMA fragments (tg_xq_kv_pack from the projections tg_gemm writes: k [B * L, C], vt [B, C, ldt], kip, vtip),
+ * tg_xq_kv_bytes bytes; `ip_scale`: device scalar or NULL (= 1.0).  head_dim 80 | 160, C % 320 == 0, M and rows_per_batch multiples of 128, text_len <= 96,
+ * ip_tokens <= 16. */
+typedef struct {
+  int32_t dtype;
+  const void* x; int64_t ldx;
+  const void* wq;
+  const float* ln_u;
+  const float* ln_v;
+  float ln_eps;
+  const void* kv;
+  const float* ip_scale;
+  void* out; int64_t ldc;
+  int64_t M;
+  int32_t C, head_dim, rows_per_batch, text_len, ip_tokens;
+} tg_xq_attn_desc;
+int tg_xq_attn(const tg_xq_attn_desc* d, void* stream);
+int64_t tg_xq_kv_bytes(int32_t batch, int32_t C, int32_t head_dim);
+int tg_xq_kv_pack(int32_t dtype, int32_t batch, int32_t C, int32_t head_dim, const void* k, const void* vt, int64_t ldt, int32_t text_len, const void* kip,
+                  const void* vtip, int64_t ldi, int32_t ip_tokens, void* out, void* stream);
 
 /* debugging aid: raw 32x32x16 MFMA on caller-provided fragments (64 lanes x 8 elements each) */
 int tg_debug_mfma32(int32_t dtype, const void* a_frags, const void* b_frags, float* d_out, void* stream);

@@ -225,3 +225,22 @@ def block_params(T, seed=900):
     x = torch.randn(BLOCK_B, C, BLOCK_H, BLOCK_W, generator=g) * 1.2 + 0.3
     enc = torch.randn(BLOCK_B, 77 + T, ctx, generator=g) * 0.5
     return sd, x, enc
+
+
+# ---- round 5: inner-level cross-attention sub-block geometry (32 x 32 level: 640 = 8 x 80; 16 x 16 level: 1280 = 8 x 160) with whole 128-token tiles per
+# batch item, so that the fixtures route through the fused norm2 + to_q + attention launch (tg_xq_attn).  (name, C, heads, ctx, N, T, scale, ip?)
+XQ_CASES = [
+    ("c640_ip4", 640, 8, 768, 128, 4, 0.4, True),
+    ("c640_plain", 640, 8, 768, 128, 0, 0.0, False),
+    ("c1280_ip16", 1280, 8, 768, 128, 16, 1.0, True),
+]
+
+
+def xq_params(ci):
+    name, C, heads, ctx, N, T, scale, ip = XQ_CASES[ci]
+    g = torch.Generator().manual_seed(1100 + ci)
+    w = attn_weights(C, ctx, seed=1200 + ci, with_ip=ip)
+    norm = {"weight": 1 + 0.2 * torch.randn(C, generator=g), "bias": 0.1 * torch.randn(C, generator=g)}
+    x = torch.randn(2, N, C, generator=g) * 1.2 + 0.3
+    enc = torch.randn(2, 77 + T, ctx, generator=g) * 0.5
+    return w, norm, x, enc

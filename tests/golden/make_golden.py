@@ -393,11 +393,31 @@ def gen_block(ref, out):
         print("block T", T, "done")
 
 
+def gen_xq(ref, out):
+    """inner-level cross-attention sub-block: the reference's Attention + IPAttnProcessor / AttnProcessor on torch's LayerNorm output
+    (models/attention.py:206-224 without the residual add: what the processor returns)"""
+    A = ref.attnproc
+    for ci, (name, C, heads, ctx, N, T, scale, ip) in enumerate(gc.XQ_CASES):
+        w, norm, x, enc = gc.xq_params(ci)
+        attn = A.Attention(query_dim=C, cross_attention_dim=ctx, heads=heads, dim_head=C // heads)
+        attn.load_state_dict({k: v for k, v in w.items() if "_ip" not in k})
+        ln = torch.nn.LayerNorm(C)
+        ln.load_state_dict(norm)
+        with torch.no_grad():
+            if ip:
+                proc = A.IPAttnProcessor(hidden_size=C, cross_attention_dim=ctx, scale=scale, num_tokens=T)
+                proc.load_state_dict({"to_k_ip.weight": w["to_k_ip.weight"], "to_v_ip.weight": w["to_v_ip.weight"]})
+            else:
+                proc = A.AttnProcessor()
+            out[f"{name}.out"] = proc(attn, ln(x), encoder_hidden_states=enc).numpy()
+        print("xq", name, "done")
+
+
 def main():
     ref = load_reference()
     torch.set_num_threads(8)
     jobs = {"attn": gen_attention, "attn_branches": gen_attention_branches, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
-            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half, "block": gen_block}
+            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half, "block": gen_block, "xq": gen_xq}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

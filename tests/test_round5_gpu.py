@@ -337,3 +337,94 @@ def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     check(old, got.float(), dtype, f"ln-folded 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(qk0, qk.float(), dtype, f"ln-folded q|k 128x160 vs 128x128 {(M, C)}", scale=0.5)
     check(vt0, vt.float(), dtype, f"ln-folded v^T 128x160 vs 128x128 {(M, C)}", scale=0.5)
+
+
+def _xq_reference(x, gamma, beta, wq, k, v, kip, vip, heads, scale, ip_w):
+    """fp32 restatement of norm2 -> to_q -> (decoupled) cross-attention of ip_adapter/attention_processor.py:445-529 (O before to_out)"""
+    import torch.nn.functional as F
+    M, C = x.shape
+    B = k.shape[0]
+    N = M // B
+    d = C // heads
+    q = (F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5) @ wq.float().t()).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    hd = lambda t: t.float().reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    o = torch.softmax(q @ hd(k).transpose(-1, -2) * scale, -1) @ hd(v)
+    if kip is not None:
+        o = o + ip_w * torch.softmax(q @ hd(kip).transpose(-1, -2) * scale, -1) @ hd(vip)
+    return o.permute(0, 2, 1, 3).reshape(M, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,B,N,T,ip_w", [(640, 2, 256, 4, 0.4), (640, 16, 1024, 4, 0.4), (640, 3, 128, 0, 0.0), (640, 2, 128, 16, 1.0),
+                                          (1280, 2, 256, 4, 0.4), (1280, 16, 256, 16, 0.7), (1280, 2, 128, 0, 0.0), (320, 2, 128, 4, 0.4)])
+def test_xq_attn_vs_fp32_reference(dtype, C, B, N, T, ip_w):
+    """tg_xq_attn + tg_xq_kv_pack: norm2 + to_q + the two softmaxes + PV in one launch (128 x 160 tiles, two heads of 80 / one head of 160 per tile; both
+    K-stage instances: <= 256 tiles and more) vs the fp32 restatement; the IP scale read from the device at run time; C = 320 is refused (head dim 40)."""
+    import math
+    from tests import parity_metrics as pm
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear
+    heads, L = 8, 77
+    d = C // heads
+    M = B * N
+    g = torch.Generator().manual_seed(C + B + N + T)
+    t = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = (t(M, C, sc=1.2) + 0.2).to(dtype).to(DEV)
+    wq = t(C, C, sc=C ** -0.5).to(dtype).to(DEV)
+    gamma, beta = (1 + 0.2 * t(C)).to(dtype).to(DEV), t(C, sc=0.1).to(dtype).to(DEV)
+    k, v = t(B, L, C).to(dtype).to(DEV), t(B, L, C).to(dtype).to(DEV)
+    kip, vip = (t(B, T, C).to(dtype).to(DEV), t(B, T, C).to(dtype).to(DEV)) if T else (None, None)
+    ldt, ldi = 80, 8 * ((max(T, 1) + 7) // 8)
+    vt = torch.zeros(B, C, ldt, device=DEV, dtype=dtype); vt[:, :, :L] = v.transpose(1, 2)
+    vtip = None
+    if T:
+        vtip = torch.zeros(B, C, ldi, device=DEV, dtype=dtype); vtip[:, :, :T] = vip.transpose(1, 2)
+    scale = d ** -0.5
+    wl, u, vv = pack_ln_linear(wq, None, gamma, beta, scale=scale * math.log2(math.e))
+    if d not in (80, 160):
+        with pytest.raises(RuntimeError):
+            ops.xq_kv_pack(k.reshape(B * L, C), vt, ldt, L, None, None, 0, 0, B, C, d)
+        return
+    blob = ops.xq_kv_pack(k.reshape(B * L, C), vt, ldt, L, kip.reshape(B * T, C) if T else None, vtip, ldi, T, B, C, d)
+    w = torch.full((1,), ip_w, device=DEV)
+    got = ops.xq_attn(x, wl, u, vv, 1e-5, blob, d, N, L, T, ip_scale=w if T else None)
+    ref = _xq_reference(x, gamma, beta, wq, k, v, kip, vip, heads, scale, ip_w)
+    l2, mx = (4e-3, 1.2e-2) if dtype == torch.bfloat16 else (6e-4, 3e-3)       # q, P and O are storage-dtype roundings on the way (rc_xattn's bar x 1.2)
+    pm.check(got.float().cpu(), ref.cpu(), f"xq_attn C{C} B{B} N{N} T{T} w{ip_w} {dtype}", l2, mx)
+    assert torch.equal(got, ops.xq_attn(x, wl, u, vv, 1e-5, blob, d, N, L, T, ip_scale=w if T else None))
+    if T:
+        w.fill_(0.0)                                       # the same launch with another device-side scale (graph-replay contract)
+        got0 = ops.xq_attn(x, wl, u, vv, 1e-5, blob, d, N, L, T, ip_scale=w)
+        pm.check(got0.float().cpu(), _xq_reference(x, gamma, beta, wq, k, v, kip, vip, heads, scale, 0.0).cpu(), f"xq_attn scale 0 C{C} {dtype}", l2, mx)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ci", range(len(gc.XQ_CASES)))
+def test_inner_level_cross_attention_fused_vs_reference_golden(dtype, ci, monkeypatch):
+    """the inner-level cross-attention sub-block (C = 640 / 8 x 80 and C = 1280 / 8 x 160) THROUGH the fused launch — our processors called
+    the way BasicTransformerBlock calls them (LayerNorm handed over for folding) — vs the imported reference's Attention + IPAttnProcessor / AttnProcessor on
+    torch's LayerNorm output (tests/golden/xq.npz); then the same call with the fused launch off (three launches): both against ONE reference value."""
+    from theatergen_amd import attention_processor as AP
+    gold = _load("xq")
+    name, C, heads, ctx, N, T, scale, ip = gc.XQ_CASES[ci]
+    w, norm_sd, x, enc = gc.xq_params(ci)
+    attn = AP.Attention(query_dim=C, cross_attention_dim=ctx, heads=heads, dim_head=C // heads)
+    attn.load_state_dict({k: v for k, v in w.items() if "_ip" not in k})
+    if ip:
+        proc = AP.IPAttnProcessor(hidden_size=C, cross_attention_dim=ctx, scale=scale, num_tokens=T)
+        proc.load_state_dict({"to_k_ip.weight": w["to_k_ip.weight"], "to_v_ip.weight": w["to_v_ip.weight"]})
+        attn.set_processor(proc)
+    attn = attn.to(DEV, dtype)
+    norm = torch.nn.LayerNorm(C)
+    norm.load_state_dict(norm_sd)
+    norm = norm.to(DEV, dtype)
+    xd, encd = x.to(DEV, dtype), enc.to(DEV, dtype)
+    monkeypatch.setattr(AP, "XQ_MIN_ROWS", 128)
+    calls = _count(monkeypatch, ["xq_attn", "attention"])
+    got = attn.processor(attn, xd, encoder_hidden_states=encd, _fused_ln=(norm, None))
+    assert calls["xq_attn"] == 1 and calls["attention"] == 0, calls
+    close(got, gold[f"{name}.out"], op_tol(dtype), f"fused inner cross-attention {name} {dtype}")
+    monkeypatch.setattr(AP, "XQ_ENABLED", False)
+    old = attn.processor(attn, xd, encoder_hidden_states=encd, _fused_ln=(norm, None))
+    assert calls["xq_attn"] == 1 and calls["attention"] == 1, calls
+    close(old, gold[f"{name}.out"], op_tol(dtype), f"three-launch inner cross-attention {name} {dtype}")

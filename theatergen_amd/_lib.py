@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 304          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 305          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -53,6 +53,13 @@ class RcXattnDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("h", vp), ("ldh", i64), ("wq", vp), ("kv", vp), ("wo", vp), ("out", vp), ("ldc", i64), ("M", i64),
         ("rows_per_batch", i32), ("text_len", i32), ("ip_tokens", i32), ("ln_eps", f32), ("ip_scale", vp),
+    ]
+
+
+class XqAttnDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("x", vp), ("ldx", i64), ("wq", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32), ("kv", vp), ("ip_scale", vp),
+        ("out", vp), ("ldc", i64), ("M", i64), ("C", i32), ("head_dim", i32), ("rows_per_batch", i32), ("text_len", i32), ("ip_tokens", i32),
     ]
 
 
@@ -147,6 +154,9 @@ SIGNATURES = {
     "tg_rc_ff": (i32, [C.POINTER(RcFfDesc), vp]),
     "tg_rc_front": (i32, [C.POINTER(RcFrontDesc), vp]),
     "tg_skinny_gemm": (i32, [C.POINTER(SkinnyDesc), vp]),
+    "tg_xq_attn": (i32, [C.POINTER(XqAttnDesc), vp]),
+    "tg_xq_kv_bytes": (i64, [i32, i32, i32]),
+    "tg_xq_kv_pack": (i32, [i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp]),
     "tg_debug_mfma32": (i32, [i32, vp, vp, vp, vp]),
 }
 

@@ -24,6 +24,7 @@ DROP-IN CONTRACT (INTEGRATION.md level 2): the processors read fr
 ``q|k|v`` / ``k|v`` / LayerNorm-folded weights live in a PROCESSOR-SIDE cache keyed by the ``attn`` object (weak reference) and the
 parameters' ``_version`` / storage, never on the module.
 """
+import os
 import weakref
 
 import torch
@@ -184,6 +185,38 @@ def ln_weight(attn, name, norm):
     bs = [l.bias for l in lins if l.bias is not None]
     return _cached(attn, "ln_" + name, ws + bs + [norm.weight, norm.bias],
                    lambda: pack_ln_linear(torch.cat([w.detach() for w in ws], dim=0), _cat_bias(lins, ws[0]), norm.weight, norm.bias))
+
+
+# ---- round 5: norm2 + to_q + cross-attention as ONE launch on the inner levels (tg_xq_attn: csrc/tg_xattn_epi.h) ------------------------------------------
+# TG_XQ=0 switches it off (old three-launch path); TG_XQ_MIN_ROWS: below this many token rows the 128 x 160 tiling leaves most of the chip idle
+XQ_ENABLED = os.environ.get("TG_XQ", "1") != "0"
+XQ_MIN_ROWS = int(os.environ.get("TG_XQ_MIN_ROWS", "4096"))
+
+
+def xq_eligible(attn, x2d, B, N, L, T, kwargs):
+    """inner-level geometry the fused launch is built for: square to_q with C % 320 == 0, head dim 80 | 160, whole 128-token tiles per batch item,
+    <= 96 text and <= 16 image keys; nothing that needs q or the probabilities afterwards (capture, masks)"""
+    if not XQ_ENABLED or x2d.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    inner, heads, d = attn_dims(attn)
+    C = x2d.shape[1]
+    if inner != C or attn.to_q.weight.shape[1] != C or C % 320 or d not in (80, 160) or N % 128 or B * N < XQ_MIN_ROWS:
+        return False
+    if L < 1 or L > 96 or T < 0 or T > 16 or x2d.stride(0) != C or x2d.stride(1) != 1:
+        return False
+    for k in ("save_attn_to_dict", "attention_mask", "attn_process_fn"):
+        if kwargs.get(k) is not None:
+            return False
+    return not kwargs.get("return_attntion_probs")
+
+
+def xq_weight(attn, norm):
+    """(W', u, v): LayerNorm fold of (softmax scale * log2 e) * to_q — the fused launch's exp2 takes the scores as they leave the MFMA"""
+    import math
+    from .weights_pack import pack_ln_linear
+    ts = [attn.to_q.weight, norm.weight, norm.bias] + ([attn.to_q.bias] if attn.to_q.bias is not None else [])
+    return _cached(attn, "xq_q", ts, lambda: pack_ln_linear(attn.to_q.weight.detach(), attn.to_q.bias, norm.weight, norm.bias,
+                                                            scale=float(attn.scale) * math.log2(math.e)))
 
 
 class Attention(nn.Module):
@@ -473,13 +506,21 @@ class AttnProcessor(nn.Module):
             enc, L, enc_bs = _enc_rows(encoder_hidden_states)
             mask = _prepare_mask(attention_mask, L, B, heads, N) if attention_mask is not None else None
             ctx = enc.shape[2]
-            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight, attn.to_q.bias)
             ldt = _round8(L)
             k = torch.empty((B * L, inner), dtype=x.dtype, device=x.device)
             vt = torch.empty((B, inner, ldt), dtype=x.dtype, device=x.device)
             w2, b2 = kv_weight(attn)
             ops.gemm(enc, w2, B * L, 2 * inner, ctx, bias=b2, rows_per_batch=L, out=k, n_split=inner,
                      out_t=vt, ldt=ldt, a_rows_per_batch=L, a_batch_stride=enc_bs)
+            ca_kw = dict(save_attn_to_dict=save_attn_to_dict, attention_mask=attention_mask, attn_process_fn=attn_process_fn,
+                         return_attntion_probs=return_attntion_probs)
+            if lnq and rows is None and xq_eligible(attn, x, B, N, L, 0, ca_kw):
+                # inner levels: norm2 + to_q + attention in ONE launch (q never exists)
+                wx, ux, vx = xq_weight(attn, norm)
+                blob = ops.xq_kv_pack(k, vt, ldt, L, None, None, 0, 0, B, inner, d)
+                ops.xq_attn(x, wx, ux, vx, norm.eps, blob, d, N, L, 0, out=o)
+                return _finish(attn, o, B, N, C, shape4, xin, _fused_residual)
+            q = ops.linear(x, wl, ln=lnq) if lnq else ops.linear(x, attn.to_q.weight, attn.to_q.bias)
             ops.attention(q, inner, N * inner, k, inner, L * inner, vt, ldt, inner * ldt, L, B, heads, d, N, attn.scale,
                           o, inner, N * inner, mask=mask)
             # like the reference (:371) self.return_attntion_probs is forced False; maps are still saved (:386-389)
@@ -586,12 +627,31 @@ class IPAttnProcessor(nn.Module):
         slot["key"] = (tensor_version(enc), self._weights_key(attn))
         if slot.get("kvpk") is not None:
             self._pack_frags(slot["kv"], enc.shape[0], slot["kvpk"])     # refreshed IN PLACE with the projections (graph-stable pointer)
+        if slot.get("xqpk") is not None:
+            self._pack_xq(attn, slot["kv"], enc.shape[0], slot["xqpk"])
         return slot["kv"]
 
     @staticmethod
     def _pack_frags(kv, B, out=None):
         k, vt, ldt, kip, vtip, ldi, L, T = kv
         return ops.rc_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, B, out=out)
+
+    @staticmethod
+    def _pack_xq(attn, kv, B, out=None):
+        k, vt, ldt, kip, vtip, ldi, L, T = kv
+        inner, _, d = attn_dims(attn)
+        return ops.xq_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, B, inner, d, out=out)
+
+    def project_kv_xq(self, attn, enc):
+        """K / V^T of ``enc`` as the MFMA fragments of the fused inner-level launch (``tg_xq_attn``): for a REGISTERED tensor they live in the
+        tensor's slot and are re-packed in place whenever the projections are; any other tensor is packed per call."""
+        kv = self.project_kv(attn, enc)
+        slot = self._kv.get(enc)
+        if slot is not None and slot["attn"]() is attn and slot.get("kv") is kv:
+            if slot.get("xqpk") is None:
+                slot["xqpk"] = self._pack_xq(attn, kv, enc.shape[0])
+            return slot["xqpk"]
+        return self._pack_xq(attn, kv, enc.shape[0])
 
     def project_kv_frags(self, attn, enc):
         """K / V^T of ``enc`` as the fragment blocks of the fused first-level cross-attention (``tg_rc_xattn``): for a REGISTERED
@@ -639,6 +699,14 @@ class IPAttnProcessor(nn.Module):
             encoder_hidden_states = _norm_encoder(attn, encoder_hidden_states)
         enc = encoder_hidden_states.contiguous()
         k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
+        if _fused_ln is not None and _fused_ln[1] is None and xq_eligible(attn, x, B, N, L, T, dict(
+                save_attn_to_dict=save_attn_to_dict, attn_process_fn=attn_process_fn, return_attntion_probs=return_attntion_probs)):
+            # inner levels (round 5): norm2 + to_q + the two softmaxes + PV in ONE launch; the K / V^T fragments live with the conditioning's slot
+            norm = _fused_ln[0]
+            wx, ux, vx = xq_weight(attn, norm)
+            o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
+            ops.xq_attn(x, wx, ux, vx, norm.eps, self.project_kv_xq(attn, enc), d, N, L, T, ip_scale=self.scale_device(x.device), out=o)
+            return _finish(attn, o, B, N, C, shape4, xin, _fused_residual)
         if _fused_ln is not None:
             norm, rows = _fused_ln
             wl, ul, vl = ln_weight(attn, "q", norm)

@@ -49,6 +49,10 @@ struct GemmParams {
   // slab conv PATCH tiles (tg_conv_slab.hip): a 128-pixel tile = patch_np patches of (128 / patch_np >> patch_pwl) rows x (1 << patch_pwl)
   // columns of an in_h x in_w image, patches numbered image-major / patch-row / patch-column.  patch_pwl = 0: tile rows are contiguous tokens.
   int patch_pwl, patch_np;
+  // cross-attention epilogue of the LayerNorm-folded to_q projection (gemm_glds_kernel<..., XA>, tg_xattn_epi.h, tg_xq_attn)
+  const void* xa_kv;          // [batch][N / 160 tiles][pieces of 1 KiB]: K / V^T MFMA fragments of the tile's heads (tg_xq_kv_pack)
+  const float* xa_ip_scale;   // device scalar (IPAttnProcessor.scale) or NULL (1.0)
+  int xa_rows_per_batch, xa_tiles_n, xa_L, xa_T;
   int slab_order;   // slab conv work order: 0 tile-major, 1 (column tile, split)-major / row-tile-minor (weight-heavy layers)
 };
 

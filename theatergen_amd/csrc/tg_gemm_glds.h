@@ -2,6 +2,7 @@
 // and tg_gemm_ln.hip (the LayerNorm-fused instances).  See tg_gemm.hip for the file-level description.
 #pragma once
 #include "tg_gemm_common.h"
+#include "tg_xattn_epi.h"
 
 namespace {
 
@@ -45,9 +46,12 @@ template <> __device__ __forceinline__ void ln_row_sums<f16_t>(f16x8 x, float& s
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, int LN = 0>
+// XA = 80 | 160 (tg_xattn_epi.h; LN = 1, 128 x 160 tiles only): the tile is the LayerNorm-folded to_q of two heads of 80 / one head of 160 channels and the
+// kernel's output is the cross-attention result O of those heads — W rows are read with bits 2 / 3 of the MFMA row swapped (q comes out as B fragments).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, int LN = 0, int XA = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu((LN != 0 && STAGES == 3 && BKT == 32) ? 3 : 2)))
 void gemm_glds_kernel(GemmParams p) {
+  static_assert(XA == 0 || (LN == 1 && BM == 128 && BN == 160 && WAVES_M == 4 && WAVES_N == 1 && BKT == 64 && !CONV && EPI == 0), "XA: the 128 x 160 LayerNorm-folded tile");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
   constexpr int CH = BKT / 8;                 // 16-byte chunks per LDS row (8 at BK = 64, 4 at BK = 32)
@@ -239,10 +243,12 @@ void gemm_glds_kernel(GemmParams p) {
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const int rkey = (l31 >> KSH) & (CH - 1);
+    const int l31w = XA != 0 ? xa_swap23(l31) : l31;            // XA: MFMA row i of a W tile = weight row swap23(i) (same 16-lane bank groups: conflict-free)
+    const int rkeyw = (l31w >> KSH) & (CH - 1);
     int buf = 0;
     for (int it = 0; it < nkt; ++it) {
       const T* bx = sX + buf * BM * BKT + (wave_m * TM * 32 + l31) * BKT;
-      const T* bw = sW + buf * BN * BKT + (wave_n * TN * 32 + l31) * BKT;
+      const T* bw = sW + buf * BN * BKT + (wave_n * TN * 32 + l31w) * BKT;
       // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
       // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
       // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
@@ -250,11 +256,11 @@ void gemm_glds_kernel(GemmParams p) {
       if constexpr (!BIGW) {
 #pragma unroll
         for (int ks = 0; ks < BKT / 16; ++ks) {
-          const int so = ((2 * ks + hi) ^ rkey) * 8;
+          const int so = ((2 * ks + hi) ^ rkey) * 8, sow = ((2 * ks + hi) ^ rkeyw) * 8;
 #pragma unroll
           for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
+          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + sow);
         }
       }
       // LN row sums: with the early refill the stage dies in the middle of this iteration, so the thread's slots are read up here
@@ -280,11 +286,11 @@ void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
       for (int ks = 0; ks < BKT / 16; ++ks) {
         if constexpr (BIGW) {
-          const int so = ((2 * ks + hi) ^ rkey) * 8;
+          const int so = ((2 * ks + hi) ^ rkey) * 8, sow = ((2 * ks + hi) ^ rkeyw) * 8;
 #pragma unroll
           for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + so);
+          for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const V8*>(bw + j * 32 * BKT + sow);
         }
         if constexpr (ER) {
           if (ks == BKT / 32) {
@@ -381,14 +387,24 @@ void gemm_glds_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 u4 = *reinterpret_cast<const f32x4*>(lnu + (wave_n * TN + j) * 32 + 8 * g + 4 * hi);
+            // (XA: the W rows are swapped, register quad g of lane half hi holds channels 16 (g >> 1) + 8 hi + 4 (g & 1) .. + 3 of the 32-column tile)
+            const f32x4 u4 = *reinterpret_cast<const f32x4*>(lnu + (wave_n * TN + j) * 32 + (XA != 0 ? 16 * (g >> 1) + 8 * hi + 4 * (g & 1) : 8 * g + 4 * hi));
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = __builtin_fmaf(acc[i][j][4 * g + e], a, b * u4[e]);
           }
       }
     }
-    epilogue_tile_lds<T, TM, TN, EPI, true>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
-                                            reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
+    if constexpr (XA != 0) {
+      // cross-attention of the tile's heads on the q the accumulators hold; O^T comes back in `acc` (standard layout) and leaves as a plain tile
+      xattn_epilogue<T, XA>(p, acc, smem, wave, lane, m0, n0, tile_n);
+      GemmParams po = p;
+      po.bias = nullptr; po.bvec = nullptr; po.res = nullptr; po.n_split = 0; po.out_scale = 1.0f; po.act = TG_ACT_NONE; po.geglu = 0;
+      epilogue_tile_lds<T, TM, TN, EPI, false>(po, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                                               reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), -1, m0, n0);
+    } else {
+      epilogue_tile_lds<T, TM, TN, EPI, true>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
+                                              reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
+    }
   } else {
     epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
                                      reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);

@@ -224,6 +224,43 @@ def rc_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, batch, out=None):
     return out
 
 
+def xq_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, batch, C_, head_dim, out=None):
+    """text K [batch * L, C] / V^T [batch, C, ldt] (+ image K / V^T) -> the MFMA fragments ``xq_attn`` streams (uint8 blob; tg_xq_kv_pack)"""
+    _need_cuda(k)
+    need = _lib.lib().tg_xq_kv_bytes(int(batch), int(C_), int(head_dim))
+    if need < 0:
+        raise RuntimeError(f"xq_kv_pack: C = {C_}, head_dim = {head_dim} not supported")
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=k.device)
+    assert out.numel() == need and out.dtype == torch.uint8
+    _lib.check(_lib.lib().tg_xq_kv_pack(_dt(k), int(batch), int(C_), int(head_dim), _ptr(k), _ptr(vt), int(ldt), int(L), _ptr(kip), _ptr(vtip),
+                                       int(ldi), int(T), _ptr(out), _stream()))
+    return out
+
+
+def xq_attn(x, wq, ln_u, ln_v, ln_eps, kv, head_dim, rows_per_batch, text_len, ip_tokens, ip_scale=None, out=None):
+    """norm2 + attn2.to_q + (decoupled text + image) cross-attention of an inner-level block in one launch -> O [M, C]; see tg_xq_attn"""
+    from ._lib import XqAttnDesc
+    _need_cuda(x)
+    M, Cc = x.shape
+    assert x.stride(1) == 1 and x.stride(0) == Cc and wq.shape == (Cc, Cc)
+    if out is None:
+        out = torch.empty(M, Cc, dtype=x.dtype, device=x.device)
+    d = XqAttnDesc()
+    d.dtype = _dt(x)
+    d.x, d.ldx, d.wq = _ptr(x), int(x.stride(0)), _ptr(wq)
+    d.ln_u, d.ln_v, d.ln_eps = _ptr(ln_u), _ptr(ln_v), float(ln_eps)
+    d.kv, d.ip_scale = _ptr(kv), _ptr(ip_scale)
+    d.out, d.ldc = _ptr(out), int(out.stride(0))
+    d.M, d.C, d.head_dim, d.rows_per_batch, d.text_len, d.ip_tokens = int(M), int(Cc), int(head_dim), int(rows_per_batch), int(text_len), int(ip_tokens)
+    heads = Cc // head_dim
+    L_ = text_len + ip_tokens
+    flops = 2.0 * M * Cc * Cc + 4.0 * M * L_ * Cc
+    _profiled(lambda: _lib.check(_lib.lib().tg_xq_attn(C.byref(d), _stream())), f"gemm_glds_kernel<plain+ln+xattn d{head_dim},128x160>", M, Cc, Cc, flops,
+              alg_bytes=2.0 * (2 * M * Cc + Cc * Cc) + 2.0 * (M // rows_per_batch) * 2 * L_ * Cc)
+    return out
+
+
 def rc_xattn(h, wq, kv, wo, rows_per_batch, ln_eps, ip_tokens, ip_scale=None, out=None, text_len=77):
     """norm2 + cross-attention (+ decoupled image keys) + to_out + residual in one launch; see tg_rc_xattn"""
     from ._lib import RcXattnDesc

@@ -32,18 +32,19 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor = None):
     return wp, bp
 
 
-def pack_ln_linear(w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor):
+def pack_ln_linear(w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, scale: float = 1.0):
     """LayerNorm folded into the Linear that consumes it (tg_gemm ``ln_u`` / ``ln_v``):
         Linear(LayerNorm(x)) = rstd * (x W'^T - mean * u) + v,   W' = W * gamma  (storage dtype),
         u[n] = sum_k W'[n, k]  summed from the ROUNDED W' (so that x W'^T - mean * u = (x - mean) W'^T exactly),
         v[n] = sum_k beta[k] W[n, k] + bias[n]                     (fp32).
-    One-off weight preprocessing at load / first use, like the conv repacks above; returns (W', u fp32, v fp32)."""
-    w32 = w.detach().float()
+    One-off weight preprocessing at load / first use, like the conv repacks above; returns (W', u fp32, v fp32).
+    ``scale`` multiplies W and the bias in fp32 BEFORE the rounding (tg_xq_attn: softmax scale * log2(e) folded into to_q)."""
+    w32 = w.detach().float() * float(scale)
     wp = (w32 * gamma.detach().float()[None, :]).to(w.dtype).contiguous()
     u = wp.float().sum(dim=1).contiguous()
     v = w32 @ beta.detach().float()
     if bias is not None:
-        v = v + bias.detach().float()
+        v = v + bias.detach().float() * float(scale)
     return wp, u, v.contiguous()
 
 
