@@ -32,11 +32,11 @@ FAMILIES = [
     ("gemm_glds_kernel<plain,128x128>", lambda n: _glds128(n) and "ELi0EEEvNS_10GemmParamsE" in n),
     ("gemm_glds_kernel<plain+ln,128x128>", lambda n: _glds128(n) and ("ELi1EEEvNS_10GemmParamsE" in n or "ELi2EEEvNS_10GemmParamsE" in n)),
     ("gemm_glds_kernel<plain,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0EEEvNS_10GemmParamsE" in n),
-    ("gemm_glds_kernel<plain+ln,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0EEEvNS_10GemmParamsE" not in n),
+    ("gemm_glds_kernel<plain+ln+xattn,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and ("ELi1ELi80EEEv" in n or "ELi1ELi160EEEv" in n)),
+    ("gemm_glds_kernel<plain+ln,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0EEEvNS_10GemmParamsE" not in n and "ELi1ELi80EEEv" not in n and "ELi1ELi160EEEv" not in n),
     ("bt_gemm_kernel<256x256>", lambda n: "bt_gemm_kernel" in n and "Li256ELi256E" in n),
     ("gemm_glds_kernel<conv,128x128>", lambda n: "gemm_glds_kernel" in n and "Li128ELi128ELi2ELi2ELb1E" in n),
-    ("conv_halo_kernel<128x160>", lambda n: "conv_halo_kernel" in n and "Li160E" in n),
-    ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n and "Li160E" not in n),
+    ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n),
     ("conv_slab_kernel<128x320>+gn", lambda n: "conv_slab_kernel" in n and "ELb1ELb" in n),
     ("conv_slab_kernel<128x320,w64>", lambda n: "conv_slab_kernel" in n and "Li64E" in n),
     ("conv_slab_kernel<128x320,w32>", lambda n: "conv_slab_kernel" in n and "Li32E" in n),
