@@ -29,11 +29,12 @@ def _glds128(n):
 
 FAMILIES = [
     # labels = the kernel labels of bench.py's roofline leg (ops.gemm profiling mode), so that `roofline.traffic` finds its kernel
-    ("gemm_glds_kernel<plain,128x128>", lambda n: _glds128(n) and "ELi0EEEvNS_10GemmParamsE" in n),
-    ("gemm_glds_kernel<plain+ln,128x128>", lambda n: _glds128(n) and ("ELi1EEEvNS_10GemmParamsE" in n or "ELi2EEEvNS_10GemmParamsE" in n)),
-    ("gemm_glds_kernel<plain,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0EEEvNS_10GemmParamsE" in n),
+    # template tail since round 5: ..., EPI, LN, XA> -> "ELi<epi>ELi<ln>ELi<xa>EEEvNS_10GemmParamsE"
+    ("gemm_glds_kernel<plain,128x128>", lambda n: _glds128(n) and "ELi0ELi0EEEvNS_10GemmParamsE" in n),
+    ("gemm_glds_kernel<plain+ln,128x128>", lambda n: _glds128(n) and ("ELi1ELi0EEEvNS_10GemmParamsE" in n or "ELi2ELi0EEEvNS_10GemmParamsE" in n)),
+    ("gemm_glds_kernel<plain,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0ELi0EEEvNS_10GemmParamsE" in n),
     ("gemm_glds_kernel<plain+ln+xattn,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and ("ELi1ELi80EEEv" in n or "ELi1ELi160EEEv" in n)),
-    ("gemm_glds_kernel<plain+ln,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and "ELi0EEEvNS_10GemmParamsE" not in n and "ELi1ELi80EEEv" not in n and "ELi1ELi160EEEv" not in n),
+    ("gemm_glds_kernel<plain+ln,128x160>", lambda n: "gemm_glds_kernel" in n and "Li128ELi160ELi4ELi1ELb0E" in n and ("ELi1ELi0EEEvNS" in n or "ELi2ELi0EEEvNS" in n)),
     ("bt_gemm_kernel<256x256>", lambda n: "bt_gemm_kernel" in n and "Li256ELi256E" in n),
     ("gemm_glds_kernel<conv,128x128>", lambda n: "gemm_glds_kernel" in n and "Li128ELi128ELi2ELi2ELb1E" in n),
     ("conv_halo_kernel<128x128>", lambda n: "conv_halo_kernel" in n),

@@ -45,9 +45,10 @@ def variant(name):
         m = re.search(r"attention_kernel<[^,]+,\s*(\d+),\s*(\d+)", n)
         return f"attention_kernel<{m.group(1)},{m.group(2)}>" if m else b
     if b == "gemm_glds_kernel":
-        m = re.search(r"gemm_glds_kernel<[^,]+,(\d+),(\d+),\d+,\d+,(true|false),\d+,\d+,(\d+),(\d+)>", n.replace(" ", ""))
+        m = re.search(r"gemm_glds_kernel<[^,]+,(\d+),(\d+),\d+,\d+,(true|false),\d+,\d+,(\d+),(\d+)(?:,(\d+))?>", n.replace(" ", ""))
         if m:
-            return f"gemm_glds_kernel<{m.group(1)}x{m.group(2)},{'conv' if m.group(3) == 'true' else 'plain'},epi{m.group(4)},ln{m.group(5)}>"
+            xa = f",xattn{m.group(6)}" if m.group(6) not in (None, "0") else ""
+            return f"gemm_glds_kernel<{m.group(1)}x{m.group(2)},{'conv' if m.group(3) == 'true' else 'plain'},epi{m.group(4)},ln{m.group(5)}{xa}>"
     return b
 
 
