@@ -132,6 +132,12 @@ typedef struct {
   const float* ln_v;
   float ln_eps;
   const float* ln_rows;  /* optional with ln_u: precomputed row statistics (tg_layernorm_stats, fp32 [M][2]); NULL = taken inside the kernel */
+  /* round 5, mode 0 with one A source only (plain GEMM kernels; 0 = K): row pitches of A and W in elements, multiples of 8, >= K.  A row pitch that is a large
+   * power-of-two multiple (K = 2560 / 5120: the FeedForward hidden tensor and net.2's weight) puts the rows of a K-tile on few L2 channels when the workgroups of a
+   * single-round launch run in lockstep (profiles/r5_operand_pitch.txt: 594 -> 718 TFLOP/s at K = 5120 with the pitch padded by 64 elements); the caller
+   * (unet.FeedForward) pads the hidden tensor it owns and its packed copy of net.2's weight. */
+  int64_t lda;
+  int64_t ldw;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);

@@ -428,3 +428,26 @@ def test_inner_level_cross_attention_fused_vs_reference_golden(dtype, ci, monkey
     old = attn.processor(attn, xd, encoder_hidden_states=encd, _fused_ln=(norm, None))
     assert calls["xq_attn"] == 1 and calls["attention"] == 1, calls
     close(old, gold[f"{name}.out"], op_tol(dtype), f"three-launch inner cross-attention {name} {dtype}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 5120), (16384, 640, 2560), (1000, 320, 1280), (256, 128, 64)])
+def test_gemm_padded_row_pitches(dtype, M, N, K):
+    """round 5: ``lda`` / ``ldw`` of tg_gemm (plain single-source GEMM): A and W as [:, :K] views of buffers whose rows are 64 elements longer (what
+    unet.FeedForward does with its hidden tensor and net.2's weight) — same bits as the contiguous operands, every tile the planner may pick"""
+    import math
+    from tests.test_kernels_gpu import check, rnd
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = rnd((M, K), dtype, g).to(DEV), rnd((N, K), dtype, g, 1 / math.sqrt(K)).to(DEV)
+    bias, res = rnd((N,), dtype, g).to(DEV), rnd((M, N), dtype, g).to(DEV)
+    ap = torch.full((M, K + 64), float("nan"), dtype=dtype, device=DEV); ap[:, :K] = a
+    wp = torch.full((N, K + 64), float("nan"), dtype=dtype, device=DEV); wp[:, :K] = w
+    ref = (a.float() @ w.float().t() + bias.float() + res.float()).cpu()
+    for tile in (0, 1, 7, 21, 23):
+        base = ops.linear(a, w, bias, res=res, force_tile=tile)
+        got = ops.linear(ap[:, :K], wp[:, :K], bias, res=res, force_tile=tile)
+        check(got, ref, dtype, f"padded pitches {(M, N, K)} tile {tile}")
+        assert torch.equal(got, base), f"tile {tile}: padded operands differ from contiguous ones"
+    with pytest.raises(RuntimeError):
+        ops.gemm(ap[:, :K], wp[:, :K], M, N, K, lda=K + 64, ldw=K + 64, force_tile=10)          # the big tile does not take padded pitches

@@ -393,6 +393,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.full_tiles = pl.full; p.tail_s = pl.s; p.kt_per_split = pl.kps; p.tiles_n = (int)pl.tiles_n;
   p.tile_bm = kTiles[pl.tile].bm; p.tile_bn = kTiles[pl.tile].bn;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
+  p.lda = d->lda > 0 ? d->lda : p.c0; p.ldw = d->ldw > 0 ? d->ldw : d->K;
   {
     const char* e = getenv("TG_GEMM_FLAGS");          // dev experiments; read per launch so one process can A/B
     p.flags = e ? (int)strtol(e, nullptr, 0) : 0;
@@ -443,6 +444,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
              "tg_gemm: the K-split tail needs %lld workspace bytes, got %lld", (long long)need, (long long)d->workspace_bytes);
   }
   if (const int bt = bt_tile_of(d); bt >= 0) {
+    TG_CHECK(d->lda <= 0 && d->ldw <= 0, TG_ERR_UNSUPPORTED, "tg_gemm: lda / ldw are taken by the 128 x 128 / 128 x 160 plain kernels only");
     TG_CHECK(!d->geglu || bt == 2, TG_ERR_ARG, "tg_gemm: the GEGLU epilogue needs the 256 x 256 big tile (force_tile 10)");
     TG_CHECK(d->n_split <= 0 || d->n_split % 128 == 0, TG_ERR_ARG, "tg_gemm: the big tile needs n_split on a wave-tile boundary");
     return tg_gemm_bt_launch(d, &p, bt, st);
@@ -508,6 +510,12 @@ int validate(const tg_gemm_desc* d) {
   }
   if (d->n_split > 0) {
     TG_CHECK(d->out_t && d->n_split % 4 == 0 && d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bad transposed-output args");
+  }
+  if (d->lda > 0 || d->ldw > 0) {
+    TG_CHECK(d->mode == 0 && d->a1 == nullptr && d->a_rows_per_batch <= 0 && d->ln_u == nullptr, TG_ERR_ARG,
+             "tg_gemm: lda / ldw belong to the plain single-source GEMM (no conv, no second source, no batched A, no LayerNorm fold)");
+    TG_CHECK((d->lda <= 0 || (d->lda >= d->K && d->lda % 8 == 0)) && (d->ldw <= 0 || (d->ldw >= d->K && d->ldw % 8 == 0)), TG_ERR_ARG,
+             "tg_gemm: lda = %lld / ldw = %lld must be >= K and multiples of 8", (long long)d->lda, (long long)d->ldw);
   }
   if (d->bvec) TG_CHECK(d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bvec needs rows_per_batch");
   if (d->ln_u != nullptr || d->ln_v != nullptr || d->ln_rows != nullptr) {

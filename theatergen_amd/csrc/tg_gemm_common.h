@@ -37,6 +37,7 @@ struct GemmParams {
   int kt_per_split;
   int tiles_n;
   long a_rpb, a_bs;
+  long lda, ldw;    // gemm_glds_kernel, plain single-source GEMM: row pitches of A / W in elements (= K unless the caller padded them)
   int epi_lds;      // operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue
   const void* a_coef;   // conv slab kernel: GroupNorm coefficients [batch][2][c0 + c1] fp32 (a, d): A' = act(A * a + d) while staging, or NULL
   int a_silu;           // ... with SiLU

@@ -124,7 +124,7 @@ void gemm_glds_kernel(GemmParams p) {
   for (int j = 0; j < XJ; ++j) {
     const long m = m0 + (j * NW + wave) * RPI + lrow;
     x_ok[j] = m < p.M;
-    xbase[j] = m * p.c0;
+    xbase[j] = CONV ? m * p.c0 : m * p.lda;         // (plain: lda = c0 unless the caller padded the rows; the two-source form keeps pitch = channel count)
     xrow[j] = m;
     if (!CONV && p.a_rpb > 0) { const long bb = m / p.a_rpb; xbase[j] = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
     if (CONV) {
@@ -140,7 +140,7 @@ void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
   for (int j = 0; j < WJ; ++j) {
     const long n = n0 + (j * NW + wave) * RPI + lrow;
-    wrow[j] = n < p.N ? Wp + n * p.K : nullptr;
+    wrow[j] = n < p.N ? Wp + n * (CONV ? p.K : p.ldw) : nullptr;
   }
 
   auto dma = [&](const T* src, T* lds_row_base) {
@@ -345,7 +345,7 @@ void gemm_glds_kernel(GemmParams p) {
       // fast path of every other row is untouched; tg_layernorm takes the same two-pass form)
       if (var < 1e-4f * mean * mean && m0 + srow < p.M) {
         const long m = m0 + srow;
-        long off = m * p.c0;
+        long off = m * p.lda;
         if (p.a_rpb > 0) { const long bb = m / p.a_rpb; off = bb * p.a_bs + (m - bb * p.a_rpb) * p.c0; }
         const T* xr = A0 + off;
         float c2 = 0.f;

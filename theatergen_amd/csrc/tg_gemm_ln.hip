@@ -141,7 +141,7 @@ extern "C" int tg_xq_attn(const tg_xq_attn_desc* d, void* stream) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   TG_CHECK(al16(d->x) && al16(d->wq) && al16(d->ln_u) && al16(d->ln_v) && al16(d->kv) && al16(d->out), TG_ERR_ARG, "tg_xq_attn: operands must be 16-byte aligned");
   GemmParams p{};
-  p.a0 = d->x; p.c0 = d->C; p.w = d->wq; p.M = d->M; p.N = d->C; p.K = d->C;
+  p.a0 = d->x; p.c0 = d->C; p.w = d->wq; p.M = d->M; p.N = d->C; p.K = d->C; p.lda = d->C; p.ldw = d->C;
   p.rows_per_batch = d->M; p.out = d->out; p.ldc = d->ldc; p.out_scale = 1.0f; p.act = TG_ACT_NONE;
   p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps;
   const int tiles_n = d->C / 160;

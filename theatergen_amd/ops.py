@@ -68,7 +68,7 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False, ln=None):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False, ln=None, lda=0, ldw=0):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -106,6 +106,7 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     d.pad_mode = int(pad_mode)
     d.a_coef = _ptr(a_coef)
     d.a_silu = 1 if a_silu else 0
+    d.lda, d.ldw = int(lda), int(ldw)                    # row pitches of A / W when the caller padded them (plain single-source GEMM only; 0 = K)
     if ln is not None:                  # (u fp32 [N], v fp32 [N], eps[, rows]): LayerNorm of the A rows folded into this GEMM (``pack_ln_linear``);
         d.ln_u, d.ln_v, d.ln_eps = _ptr(ln[0]), _ptr(ln[1]), float(ln[2])     # rows = ``layernorm_stats`` output, None: taken inside the kernel
         if len(ln) > 3 and ln[3] is not None:
@@ -184,7 +185,10 @@ def linear(x, w, bias=None, **kw):
     """x [rows, K] (row pitch = K) @ w[N, K]^T"""
     M, K = x.shape
     N = w.shape[0]
-    assert x.stride(0) == K and w.shape[1] == K
+    if x.stride(0) != K or w.shape[1] != K or w.stride(0) != K:
+        # padded row pitches (round 5: the FeedForward hidden tensor and its packed net.2 weight): views [:, :K] of wider buffers
+        assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K and x.stride(0) >= K and w.stride(0) >= K
+        return gemm(x, w, M, N, K, bias=bias, lda=x.stride(0), ldw=w.stride(0), **kw)
     return gemm(x, w, M, N, K, bias=bias, **kw)
 
 

@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from . import ops
 from . import rowchain
-from .attention_processor import (Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, front_eligible, fused_cross_block,
+from .attention_processor import (tensor_version, Attention, AttnProcessor, CNAttnProcessor, IPAttnProcessor, _cached, front_eligible, fused_cross_block,
                                   ln_weight, self_attention_from_qkv)
 from .config import UNetConfig
 from .weights_pack import pack_conv1x1, pack_conv3x3, pack_geglu, pack_ln_linear, rc_pack_tiles
@@ -61,7 +61,7 @@ class _Packed:
         self._c = {}
 
     def get(self, name, tensors, build):
-        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in tensors)
+        key = tuple((t.data_ptr(), tensor_version(t), t.dtype, t.device) for t in tensors)
         hit = self._c.get(name)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -82,6 +82,7 @@ _LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_M
 # norm3 folded into the GEGLU GEMM for row counts up to this (0 = never): where the plain GEGLU GEMM runs on the 128 x 128 kernel anyway (not the 256 x 256 big tile of
 # the 32 x 32 level) the fold costs no tile choice and removes the layernorm launch
 _LN_FF_MAX_ROWS = int(os.environ.get("TG_LN_FF_MAX_ROWS", "0"))
+_FF_PAD = os.environ.get("TG_FF_PAD", "1") != "0"      # round 5: pad the FeedForward hidden tensor's / net.2 weight's row pitch (see FeedForward._hidden)
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
 
@@ -201,10 +202,31 @@ class FeedForward(nn.Module):
                               lambda: rc_pack_tiles(w_out.detach(), b_out.detach().float() if b_out is not None else None))
         return ops.rc_ff(x2d, s1, s2, b2, inner, norm.eps, wpo=wpo, res0=res0)
 
+    def _hidden(self, M, inner, like):
+        """the [M, inner] hidden tensor.  Round 5: when its row pitch would be a multiple of 1 KiB (inner = 2560 / 5120: the 32 x 32 / 16 x 16 levels) the rows are
+        padded by 64 elements (and net.2's weight likewise, ``_w2``) — its only consumers are the two FeedForward GEMMs, and the lockstep workgroups of those
+        single-round launches otherwise crowd a few L2 channels (profiles/r5_operand_pitch.txt); TG_FF_PAD=0 switches it off"""
+        if _FF_PAD and inner % 512 == 0:
+            return torch.empty((M, inner + 64), dtype=like.dtype, device=like.device)[:, :inner]
+        return torch.empty((M, inner), dtype=like.dtype, device=like.device)
+
+    def _w2(self):
+        w2 = self.net[2].weight
+        inner = w2.shape[1]
+        if not (_FF_PAD and inner % 512 == 0):
+            return w2
+
+        def build():
+            wp = torch.zeros((w2.shape[0], inner + 64), dtype=w2.dtype, device=w2.device)
+            wp[:, :inner] = w2.detach()
+            return wp
+        return self._p.get("w2pad", [w2], build)[:, :inner]
+
     def run(self, x2d, residual, ln=None):
         """``ln`` = (nn.LayerNorm, row statistics or None): ``x2d`` is the un-normalised stream and the norm is folded into the GEGLU GEMM"""
         proj = self.net[0].proj
         M, K = x2d.shape
+        inner = proj.weight.shape[0] // 2
         if ln is not None:
             norm, rows = ln
 
@@ -212,14 +234,15 @@ class FeedForward(nn.Module):
                 wp, bp = pack_geglu(proj.weight.detach(), proj.bias.detach())
                 return pack_ln_linear(wp, bp, norm.weight, norm.bias)
             wl, ul, vl = self._p.get("geglu_ln", [proj.weight, proj.bias, norm.weight, norm.bias], build)
-            g = ops.gemm(x2d, wl, M, wl.shape[0], K, geglu=True, ln=(ul, vl, norm.eps, rows))
-        elif M > 64 and (proj.weight.shape[0] // 2) % 32 == 0:
+            g = ops.gemm(x2d, wl, M, wl.shape[0], K, geglu=True, ln=(ul, vl, norm.eps, rows), out=self._hidden(M, inner, x2d))
+        elif M > 64 and inner % 32 == 0:
             # GEGLU fused into the C -> 8C GEMM epilogue: the [M, 8C] pre-activation is never written
             wp, bp = self._p.get("geglu", [proj.weight, proj.bias], lambda: pack_geglu(proj.weight.detach(), proj.bias.detach()))
-            g = ops.gemm(x2d, wp, M, wp.shape[0], K, bias=bp, geglu=True)
+            g = ops.gemm(x2d, wp, M, wp.shape[0], K, bias=bp, geglu=True, out=self._hidden(M, inner, x2d))
         else:
             g = ops.geglu(ops.linear(x2d, proj.weight, proj.bias))
-        return ops.linear(g, self.net[2].weight, self.net[2].bias, res=residual)
+            return ops.linear(g, self.net[2].weight, self.net[2].bias, res=residual)
+        return ops.linear(g, self._w2(), self.net[2].bias, res=residual)
 
 
 class BasicTransformerBlock(nn.Module):
