@@ -285,35 +285,6 @@ def test_gemm_128x160_tiles(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(1024, 1280, 1280), (2048, 1280, 5120), (1000, 1270, 200), (96, 320, 64), (2048, 640, 2560)])
-def test_gemm_k_group_tiles(dtype, shape):
-    """round 5: 64 x 160 / 32 x 160 tiles whose four waves split every K-tile's k-steps two / four ways (gemm_glds_kernel<..., KG>, force_tile 24 / 25):
-    the partial accumulators are summed through LDS in group order, so the result differs from the 128 x 128 kernel's only by fp32 summation order;
-    ragged M / N / K, bias + per-batch vector + residual, and a forced K split (the partials then go through the reduce kernel)."""
-    import math
-    from tests.test_kernels_gpu import check, rnd
-    from theatergen_amd import ops
-    M, N, K = shape
-    g = torch.Generator().manual_seed(M + N + K + 1)
-    rows = 100 if M % 100 == 0 else M
-    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
-    bias, res, bvec = rnd((N,), dtype, g), rnd((M, N), dtype, g), rnd((M // rows, N), dtype, g)
-    ad, wd, bd, rd, vd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), bvec.to(DEV)
-    ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
-    base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
-    for tile in (24, 25):
-        out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
-        check(out, ref, dtype, f"k-group tile {tile} {shape}")
-        again = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
-        assert torch.equal(out, again), f"tile {tile} {shape}: not deterministic"
-        ulp = (out.float() - base.float()).abs().max().item()
-        assert ulp <= 2 ** -6 * max(1.0, base.float().abs().max().item()), (tile, shape, ulp)
-        if K >= 1024 and K % 64 == 0:
-            sp = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile, force_split_k=2)
-            check(sp, ref, dtype, f"k-group tile {tile} split 2 {shape}")
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,C", [(16384, 640), (4096, 1280), (65536, 320)])
 def test_gemm_layernorm_folded_on_128x160_tiles(dtype, M, C, monkeypatch):
     """round 5: the LayerNorm-folded projections (attn2.to_q, attn1 q | k | v^T) on the tile-count-aware 128 x 160 tiles vs

@@ -24,8 +24,8 @@ namespace {
 
 struct TileCfg { int bm, bn, bk; };
 const TileCfg kTiles[] = {{128, 128, 64}, {64, 64, 64}, {128, 64, 64}, {64, 128, 64}, {128, 128, 64}, {256, 256, 64}, {128, 128, 32},
-                          {128, 160, 64}, {128, 160, 64}, {128, 160, 64}, {64, 160, 64}, {32, 160, 64}};
-constexpr int kNumTiles = 12;
+                          {128, 160, 64}, {128, 160, 64}, {128, 160, 64}};
+constexpr int kNumTiles = 10;
 // ids 7 / 8 / 9 (round 5, force_tile 21 / 22 / 23): 128 x 160 tiles, four waves of 32 tokens x 160 channels (1 x 5 MFMA tiles, fragments per k-step).
 // TILE COUNT, not tile shape, is what they are for: the UNet's mid-level projections are M x N = 16384 x 640 and 4096 x 1280 — 640 / 320 tiles of
 // 128 x 128 on 512 (768) co-resident slots = one round at 62 .. 83 % with the busiest CUs holding three tiles, but 512 / 256 tiles of 128 x 160:
@@ -160,7 +160,7 @@ Plan make_plan(const tg_gemm_desc* d) {
       const bool ragged128 = N % 128 != 0 && K >= 640 && (t160_mode() & 4);          // N = 320 / 960: the last 128-column tile is half padding
       if (d->force_split_k <= 1 && t160 >= 192 && (((t160_mode() & 1) && eff160 >= eff128 + 0.1) || (ragged128 && eff160 >= eff128 - 0.01))) t = one_per_cu ? 7 : 9;
     }
-    if (d->force_tile >= 21 && d->force_tile <= 25) t = d->force_tile - 14;
+    if (d->force_tile >= 21 && d->force_tile <= 23) t = d->force_tile - 14;
     else if (d->force_tile > 0) t = d->force_tile - 1;
     if (t >= kNumTiles || t < 0) t = 0;
   }
@@ -180,7 +180,7 @@ Plan make_plan(const tg_gemm_desc* d) {
   // longest-K 8x8 projections; every other layer measured faster unsplit (partials cost more than the idle CUs).
   long S = 512;
   if (!halo && (t == 1 || t == 6)) S = 768;
-  if (!halo && (t == 4 || t == 5 || t == 7 || t == 10 || t == 11)) S = 256;
+  if (!halo && (t == 4 || t == 5 || t == 7)) S = 256;
   long full = (T / S) * S, rem = T - full;
   int s = 1;
   if (d->force_split_k > 0) {
@@ -461,7 +461,7 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
     case 3: return launch_cfg2<T, 64, 128, 1, 4, 3>(d, p, pl, st);
     case 4: return launch_cfg2<T, 128, 128, 2, 2, 3>(d, p, pl, st);   // 3 stages, 96 KB: 1 block / CU (forced only)
     case 6: return launch_cfg2<T, 128, 128, 2, 2, 3, 32>(d, p, pl, st);   // three 16 KB K stages: 3 blocks / CU
-    case 7: case 8: case 9: case 10: case 11: {                                             // 128 x 160 tiles (tg_gemm_t160.hip): 7 = 1 block / CU, 8 / 9 = 2 blocks / CU
+    case 7: case 8: case 9: {                                             // 128 x 160 tiles (tg_gemm_t160.hip): 7 = 1 block / CU, 8 / 9 = 2 blocks / CU
       TG_CHECK(d->mode == 0 && !d->geglu && d->act == TG_ACT_NONE, TG_ERR_ARG, "tg_gemm: the 128 x 160 tiles take plain GEMMs with a linear epilogue");
       const int rc = tg_gemm_t160_launch(d, &p, pl.tile - 7, pl.full + pl.tail * pl.s, st);
       if (rc != TG_OK) return rc;

@@ -48,17 +48,11 @@ template <> __device__ __forceinline__ void ln_row_sums<f16_t>(f16x8 x, float& s
 
 // XA = 80 | 160 (tg_xattn_epi.h; LN = 1, 128 x 160 tiles only): the tile is the LayerNorm-folded to_q of two heads of 80 / one head of 160 channels and the
 // kernel's output is the cross-attention result O of those heads — W rows are read with bits 2 / 3 of the MFMA row swapped (q comes out as B fragments).
-// KG = 2 | 4 (round 5; tg_gemm_t160.hip, 64 x 160 and 32 x 160 tiles): K GROUPS.  The tile has only WAVES_M x WAVES_N = 2 or 1 wave tiles of 32 x 160; the
-// workgroup still runs four waves — the KG waves of a wave tile split the k-steps of every K-tile among themselves (all four fetch the operand stages) and
-// their accumulators are summed through LDS, in a fixed order, before the epilogue.  Tile COUNT again: M = 2048 / 1024 rows x 1280 columns = 256 tiles.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, int LN = 0, int XA = 0, int KG = 1>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * KG * 64) __attribute__((amdgpu_waves_per_eu((LN != 0 && STAGES == 3 && BKT == 32) ? 3 : 2)))
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int STAGES, int BKT, int EPI, int LN = 0, int XA = 0>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu((LN != 0 && STAGES == 3 && BKT == 32) ? 3 : 2)))
 void gemm_glds_kernel(GemmParams p) {
   static_assert(XA == 0 || (LN == 1 && BM == 128 && BN == 160 && WAVES_M == 4 && WAVES_N == 1 && BKT == 64 && !CONV && EPI == 0), "XA: the 128 x 160 LayerNorm-folded tile");
-  constexpr int NW = WAVES_M * WAVES_N * KG;
-  constexpr int KPG = BKT / 16 / KG;          // k-steps of a K-tile per K group
-  static_assert(KG == 1 || ((KG == 2 || KG == 4) && STAGES >= 3 && LN == 0 && !CONV && BKT == 64 && (size_t)(NW - NW / KG) * 64 * (BM / (WAVES_M * 32)) * (BN / (WAVES_N * 32)) * 64 <= (size_t)STAGES * (BM + BN) * BKT * sizeof(T)),
-                "K groups: plain GEMM, no early refill, partial accumulators must fit the operand stages");
+  constexpr int NW = WAVES_M * WAVES_N;
   constexpr int PF = STAGES - 1;              // K-tiles kept in flight ahead of the one being multiplied
   constexpr int CH = BKT / 8;                 // 16-byte chunks per LDS row (8 at BK = 64, 4 at BK = 32)
   constexpr int RPI = 64 / CH;                // tile rows covered by one 1-KiB DMA instruction (8 or 16)
@@ -83,10 +77,8 @@ void gemm_glds_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = KG == 1 ? 0 : wave % KG;     // K group of this wave
-  const int wtile = wave / KG;                // wave tile
-  const int wave_m = wtile / WAVES_N;
-  const int wave_n = wtile % WAVES_N;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
   // work item -> (tile, K range): the first full_tiles blocks compute whole tiles (XCD-chunked order); the tail tiles
   // are cut tail_s ways along K so that the last, partially filled round of the grid is spread over all CUs
   int lbid, split = 0, part = -1;
@@ -260,11 +252,11 @@ void gemm_glds_kernel(GemmParams p) {
       // all fragment reads of the K-tile first (16 ds_read_b128 = 64 VGPRs at 2x2 tiles), then one uninterrupted
       // MFMA chain: the compiler's counted lgkmcnt waits then expose the LDS latency once per tile instead of once
       // per k-step (it otherwise emits read-4 / wait-all / mfma-4 groups and the matrix pipe idles ~50 % per wave).
-      V8 xf[KPG][TM], wf[KPG][TN];
+      V8 xf[BKT / 16][TM], wf[BKT / 16][TN];
       if constexpr (!BIGW) {
 #pragma unroll
-        for (int ks = 0; ks < KPG; ++ks) {
-          const int so = ((2 * (kg * KPG + ks) + hi) ^ rkey) * 8, sow = ((2 * (kg * KPG + ks) + hi) ^ rkeyw) * 8;
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+          const int so = ((2 * ks + hi) ^ rkey) * 8, sow = ((2 * ks + hi) ^ rkeyw) * 8;
 #pragma unroll
           for (int i = 0; i < TM; ++i) xf[ks][i] = *reinterpret_cast<const V8*>(bx + i * 32 * BKT + so);
 #pragma unroll
@@ -292,7 +284,7 @@ void gemm_glds_kernel(GemmParams p) {
       }
       if (p.flags & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < KPG; ++ks) {
+      for (int ks = 0; ks < BKT / 16; ++ks) {
         if constexpr (BIGW) {
           const int so = ((2 * ks + hi) ^ rkey) * 8, sow = ((2 * ks + hi) ^ rkeyw) * 8;
 #pragma unroll
@@ -336,32 +328,6 @@ void gemm_glds_kernel(GemmParams p) {
     }
   }
 
-  if constexpr (KG > 1) {
-    // K groups: groups 1 .. KG-1 park their accumulators (register-major, lane-contiguous) in the dead operand stages; group 0 adds them in group order
-    float* park = reinterpret_cast<float*>(smem) + (size_t)(wtile * (KG - 1)) * (64 * TM * TN * 16) + lane;
-    if (kg != 0) {
-      float* dst = park + (size_t)(kg - 1) * (64 * TM * TN * 16);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (kg == 0) {
-#pragma unroll
-      for (int g = 0; g < KG - 1; ++g)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += park[(size_t)g * (64 * TM * TN * 16) + ((i * TN + j) * 16 + r) * 64];
-    }
-    __syncthreads();                          // the epilogue's LDS bounce overwrites the parked partials
-    if (kg != 0) return;
-  }
   if constexpr (LN != 0) {
     // row statistics -> (a, b) = (rstd, -rstd * mean) and this tile's u[n] into LDS behind the epilogue scratch (the operand stages
     // are dead); then, still in accumulator layout (lane & 31 = row: a, b are per-lane scalars; a register quad = 4 consecutive

@@ -18,25 +18,9 @@ int launch_t160(const GemmParams& p, int grid, hipStream_t st) {
   return TG_OK;
 }
 
-// 64 x 160 / 32 x 160 tiles (M = 2048 / 1024 rows x 1280 columns = 256 tiles, one per CU): two / one wave tiles of 32 x 160, the four waves of the workgroup
-// split every K-tile's k-steps two / four ways (gemm_glds_kernel<..., KG>)
-template <typename T, int BM, int STAGES>
-int launch_kg160(const GemmParams& p, int grid, hipStream_t st) {
-  constexpr int BN = 160, KG = 128 / BM;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 64 * sizeof(T);
-  auto k = gemm_glds_kernel<T, BM, BN, BM / 32, 1, false, STAGES, 64, 0, 0, 0, KG>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)attr;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p);
-  TG_LAUNCH_CHECK();
-  return TG_OK;
-}
-
 template <typename T>
 int dispatch_t160(const GemmParams& p, int variant, int grid, hipStream_t st) {
   switch (variant) {
-    case 3: return launch_kg160<T, 64, 4>(p, grid, st);      // 112 KB
-    case 4: return launch_kg160<T, 32, 4>(p, grid, st);      // 96 KB
     case 0: return launch_t160<T, 3, 64>(p, grid, st);       // 108 KB: one workgroup per CU, two K-tiles in flight
     default: return launch_t160<T, 2, 64>(p, grid, st);      // 72 KB: two per CU, one K-tile in flight each
   }
