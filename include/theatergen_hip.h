@@ -258,6 +258,13 @@ int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, int32_t bat
                const void* weight, const void* bias, int32_t cout, void* out, void* stream);
 int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_t h, int32_t w, const void* weight,
                 const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream);
+/* round 5 (ABI 306): conv_norm_out + SiLU + conv_out in one launch (models/unet_2d_condition.py:1015-1018): x is the RAW block output, `coef` the
+ * tg_groupnorm_coef coefficients of conv_norm_out (fp32 [batch][2][cin]); A'[b, p, c] = act(x[b, p, c] * a[b, c] + d[b, c]) is formed while the tile's
+ * window is staged (same fp32 expression and rounding as tg_groupnorm: the normalised tensor never exists in HBM).  Only for problems the matrix-core
+ * kernel takes — tg_conv_out_takes_coef(cin, h, w, cout) == 1 (cin % 64 == 0, cin <= 320, cout <= 8, h % 8 == 0, w % 16 == 0) — else TG_ERR_UNSUPPORTED. */
+int tg_conv_out_gn(int32_t dtype, const void* x, const float* coef, int32_t a_silu, int32_t batch, int32_t cin, int32_t h, int32_t w,
+                   const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream);
+int tg_conv_out_takes_coef(int32_t cin, int32_t h, int32_t w, int32_t cout);
 
 /* Sinusoidal timestep embedding (diffusers Timesteps; call site models/unet_2d_condition.py:315-316, 819):
  * out[r, :] for r < rows; t read from DEVICE fp32 array `t` (stride t_stride, 0 = broadcast one value).  When

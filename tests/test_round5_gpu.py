@@ -480,3 +480,28 @@ def test_groupnorm_coef_one_launch(dtype, batch, hw, c0, c1, monkeypatch):
     a = rstd * gamma.float()
     d = beta.float() - mean.expand(batch, 1, 32, C // 32).reshape(batch, C) * a
     assert torch.allclose(one[:, 0], a, rtol=2e-4, atol=2e-5) and torch.allclose(one[:, 1], d, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,h,w,cout,sdt", [(16, 64, 64, 320, torch.float32), (2, 96, 96, 320, torch.float32), (3, 17, 23, 320, torch.float32),
+                                            (2, 128, 128, 320, None), (1, 8, 8, 160, torch.float32), (2, 16, 16, 640, torch.float32)])
+def test_conv_in_on_matrix_cores(dtype, B, h, w, cout, sdt):
+    """round 5: conv_in (4 -> 320, UNet2DConditionModel.conv_in; models/unet_2d_condition.py:820) as three MFMA k-steps per 32-pixel block with the fp32
+    sample split into a storage-dtype head + tail — vs fp32 F.conv2d on the UNROUNDED sample: the result must be the correctly rounded fp32 convolution
+    up to fp32 summation order (<= 1 ulp of the storage dtype, almost everywhere exact), ragged pixel counts, image borders, bias."""
+    import torch.nn.functional as F
+    from tests.test_kernels_gpu import rnd
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    g = torch.Generator().manual_seed(B + h + w + cout)
+    sdt = sdt or dtype
+    smp = (torch.randn(B, 4, h, w, generator=g) * 3.0).to(sdt)
+    wt, bias = rnd((cout, 4, 3, 3), dtype, g, 1 / 6), rnd((cout,), dtype, g)
+    ref = F.conv2d(smp.double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    out = ops.conv_in(smp.to(DEV), pack_conv3x3(wt).to(DEV), bias.to(DEV), cout, dtype).cpu()
+    assert out.shape == ref.shape
+    want = ref.float().to(dtype)
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    err = (out.double() - ref).abs()
+    assert bool((err <= ulp * ref.abs().clamp_min(2.0 ** -14) * 1.01 + 1e-6).all()), err.max().item()
+    assert (out == want).float().mean().item() > 0.97

@@ -131,6 +131,8 @@ SIGNATURES = {
     "tg_softmax_rows": (i32, [i32, vp, i64, i32, i64, f32, vp, i64, vp]),
     "tg_conv_in": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
     "tg_conv_out": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "tg_conv_out_gn": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "tg_conv_out_takes_coef": (i32, [i32, i32, i32, i32]),
     "tg_timestep_embedding": (i32, [i32, vp, vp, i32, i32, i32, i32, f32, vp, i64, vp]),
     "tg_step_epilogue": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp]),
     "tg_blend_latents": (i32, [vp, vp, vp, i32, i32, f32, f32, i32, vp, vp]),

@@ -399,6 +399,86 @@ __global__ __launch_bounds__(256) void conv_in_fast_kernel(const void* sample, i
   }
 }
 
+// conv_in on the matrix cores (round 5; cin = 4: K = 36 -> three k-steps of 16, cout a multiple of 160).  The fp32-FMA kernel above is LDS-read bound at ~70 us
+// for a tensor that takes ~8 us to write (16 x 64 x 64 x 320).  A wave owns 32 consecutive pixels: B fragments = the pixels' 3 x 3 x 4 patches gathered from
+// the NCHW sample — split into a storage-dtype head and tail (x = hi + lo, two MFMAs per fragment) so that an fp32 sample keeps ~16 mantissa bits, as the
+// fp32 kernel kept all of them —; A fragments = the weight rows [cout][36] zero-padded to 48 in LDS (112-byte rows: conflict-free ds_read_b128); 160
+// channels at a time (5 accumulator tiles); bias, rounding, then a per-wave LDS bounce so that every store instruction covers 320-byte runs of pixel rows.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const void* sample, int src_dtype, int batch, int h, int w, const T* weight, const T* bias,
+                                                           int cout, T* out) {
+  typedef typename Vec<T>::v8 V8;
+  typedef typename Vec<T>::v4 V4;
+  constexpr int CIN = 4, K = 36, KP = 48, WP = 56, OP = 168;        // LDS pitches (elements): weight rows 112 B, bounce rows 336 B
+  extern __shared__ __attribute__((aligned(16))) char cim_smem[];
+  T* sw = reinterpret_cast<T*>(cim_smem);                           // [cout][WP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  T* so = sw + (size_t)cout * WP + (size_t)wave * 32 * OP;          // [32][OP] per wave
+  for (int i = tid; i < cout * KP; i += 256) {
+    const int n = i / KP, k = i - n * KP;
+    sw[n * WP + k] = k < K ? weight[n * K + k] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  const long npix = (long)batch * h * w;
+  for (long base = ((long)blockIdx.x * 4 + wave) * 32; base < npix; base += (long)gridDim.x * 128) {
+    const long pix = base + l31;
+    const bool ok = pix < npix;
+    const long pp = ok ? pix : 0;
+    const int b = (int)(pp / ((long)h * w));
+    const int r = (int)(pp - (long)b * h * w);
+    const int y = r / w, x = r - y * w;
+    V8 bh[3], bl[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * ks + 8 * hi + e, tap = k >> 2, c = k & 3;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        float v = 0.f;
+        if (ok && tap < 9 && yy >= 0 && yy < h && xx >= 0 && xx < w) v = load_src(sample, src_dtype, (((long)b * CIN + c) * h + yy) * w + xx);
+        const T vh = from_f32<T>(v);
+        bh[ks][e] = vh;
+        bl[ks][e] = from_f32<T>(v - to_f32<T>(vh));
+      }
+    for (int half = 0; half < cout / 160; ++half) {
+      f32x16 acc[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const V8 a = *reinterpret_cast<const V8*>(sw + (size_t)(half * 160 + 32 * j + l31) * WP + 16 * ks + 8 * hi);
+          acc[j] = mfma32(a, bl[ks], acc[j]);       // tails first: small terms into the accumulator before the large ones
+          acc[j] = mfma32(a, bh[ks], acc[j]);
+        }
+      }
+      // accumulator layout: lane & 31 = pixel, register quad g of lane half hi = channels 32 j + 8 g + 4 hi .. + 3
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = 32 * j + 8 * g + 4 * hi;
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(acc[j][4 * g + e] + (bias != nullptr ? to_f32<T>(bias[half * 160 + ch + e]) : 0.f));
+          *reinterpret_cast<V4*>(so + l31 * OP + ch) = o;
+        }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 10; ++it) {
+        const int q = it * 64 + lane, px = q / 20, cn = q - px * 20;
+        const V8 v = *reinterpret_cast<const V8*>(so + px * OP + cn * 8);
+        if (base + px < npix) *reinterpret_cast<V8*>(out + (base + px) * cout + half * 160 + cn * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 __device__ __forceinline__ float dot8_acc(bf16x8 a, bf16x8 b, float acc) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #pragma unroll
@@ -481,6 +561,107 @@ __global__ __launch_bounds__(256) void conv_out_fast_kernel(const T* x, int batc
         }
       }
     }
+  }
+}
+
+// conv_out on the matrix cores (round 5; cin <= 320 a multiple of 64, cout <= 8, h % 8 == 0, w % 16 == 0), optionally with conv_norm_out + SiLU applied
+// while the window is staged (`coef`: tg_groupnorm_coef's a / d per (image, channel); the same fp32 expression and rounding as tg_groupnorm, so the
+// normalised tensor is never written or read: UNet2DConditionModel.forward's conv_norm_out -> conv_act -> conv_out, models/unet_2d_condition.py:1015-1018).
+// The dot-product kernel above re-reads every pixel nine times from L2 and reduces 8 accumulators across the wave per pixel pair: ~80 us (+ 15 us of
+// GroupNorm apply) for a 42 MB tensor.  Here a workgroup owns an 8 x 16-pixel tile: its 10 x 18-pixel window (all channels, 115 KB) goes through LDS once
+// (128-byte swizzle on the 16-byte slot, key = (pixel >> 1) & 7: conflict-free ds_read_b128 for 16 consecutive pixels), the weights [cout][9 cin] sit next to
+// it, and a wave's 32 pixels x 9 taps x cin / 16 k-steps run as 32 x 32 x 16 MFMAs whose A operand carries the cout <= 8 real rows (the other rows are
+// zero registers — the matrix pipe has cycles to spare here, the LDS pipe does not).  Output: NCHW, 16 consecutive pixels per 64-byte run.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const float* coef, int a_silu, int batch, int cin, int h, int w, const T* weight,
+                                                            const T* bias, int cout, void* out, int out_f32) {
+  typedef typename Vec<T>::v8 V8;
+  constexpr int TH = 8, TW = 16, WW = TW + 2, WIN = (TH + 2) * WW;       // 180 window pixels
+  extern __shared__ __attribute__((aligned(16))) char com_smem[];
+  const int K = 9 * cin, ch8 = cin >> 3;
+  T* sx = reinterpret_cast<T*>(com_smem);                 // [WIN][cin], swizzled
+  T* sw = sx + (size_t)WIN * cin;                         // [cout][K]
+  float* sc = reinterpret_cast<float*>(sw + (size_t)cout * K);   // [2][cin] coefficients of this tile's image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tiles_x = w / TW, tiles_y = h / TH;
+  const int tile = blockIdx.x;
+  const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+  for (int i = tid; i < cout * K / 8; i += 256) reinterpret_cast<V8*>(sw)[i] = reinterpret_cast<const V8*>(weight)[i];
+  if (coef != nullptr) {
+    for (int i = tid; i < 2 * cin; i += 256) sc[i] = coef[(long)b * 2 * cin + i];
+    __syncthreads();
+  }
+  // ---- window: global -> registers (-> GroupNorm + SiLU) -> LDS, four chunks in flight per thread
+  const T* xb = x + (long)b * h * w * cin;
+  const int nchunk = WIN * ch8;
+  for (int q0 = tid; q0 < nchunk; q0 += 4 * 256) {
+    V8 v[4];
+    int wp[4], c[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * 256;
+      wp[u] = q / ch8; c[u] = q - wp[u] * ch8;
+      const int wy = wp[u] / WW, wx = wp[u] - wy * WW;
+      const int yy = y0 + wy - 1, xx = x0 + wx - 1;
+      ok[u] = q < nchunk && yy >= 0 && yy < h && xx >= 0 && xx < w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = from_f32<T>(0.f);
+      if (ok[u]) v[u] = *reinterpret_cast<const V8*>(xb + ((long)yy * w + xx) * cin + c[u] * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q0 + u * 256 >= nchunk) continue;
+      if (coef != nullptr && ok[u]) {
+        const float* ca = sc + c[u] * 8;
+        const float* cd = sc + cin + c[u] * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = to_f32<T>(v[u][e]) * ca[e] + cd[e];       // tg_norm.hip gn_apply_kernel: the same expression, the same rounding
+          v[u][e] = from_f32<T>(a_silu ? silu_f(f) : f);
+        }
+      }
+      const int slot = (c[u] & ~7) | ((c[u] ^ (wp[u] >> 1)) & 7);
+      *reinterpret_cast<V8*>(sx + (size_t)wp[u] * cin + slot * 8) = v[u];
+    }
+  }
+  __syncthreads();
+  // ---- 32 pixels per wave (tile rows 2 wave, 2 wave + 1) x 9 taps x cin / 16 k-steps
+  const int ty = 2 * wave + (l31 >> 4), tx = l31 & 15;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  V8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = from_f32<T>(0.f);
+  const bool arow = l31 < cout;
+  const T* wrow = sw + (size_t)(arow ? l31 : 0) * K + 8 * hi;
+  const int nks = cin >> 4;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int wpx = (ty + ky) * WW + tx + kx, key = (wpx >> 1) & 7;
+    const T* xrow = sx + (size_t)wpx * cin;
+    const T* wt = wrow + tap * cin;
+#pragma unroll 4
+    for (int ks = 0; ks < nks; ++ks) {
+      const int cc = 2 * ks + hi;
+      const V8 bfrag = *reinterpret_cast<const V8*>(xrow + (((cc & ~7) | ((cc ^ key) & 7)) << 3));
+      V8 afrag = zero8;
+      if (arow) afrag = *reinterpret_cast<const V8*>(wt + 16 * ks);
+      acc = mfma32(afrag, bfrag, acc);
+    }
+  }
+  // accumulator: lane & 31 = pixel, register r of lane half hi = output channel 8 (r >> 2) + 4 hi + (r & 3): channels 0 .. 7 are registers 0 .. 3 of the two halves
+  const int yy = y0 + ty, xx = x0 + tx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = 4 * hi + r;
+    if (n >= cout) continue;
+    const float val = acc[r] + (bias != nullptr ? to_f32<T>(bias[n]) : 0.f);
+    const long o = (((long)b * cout + n) * h + yy) * w + xx;
+    if (out_f32) reinterpret_cast<float*>(out)[o] = val;
+    else reinterpret_cast<T*>(out)[o] = from_f32<T>(val);
   }
 }
 
@@ -583,6 +764,28 @@ extern "C" int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long npix = (long)batch * h * w;
   {
+    // matrix-core path (round 5): cin = 4, cout a multiple of 160 (dev A/B knob TG_CONV_IN_MFMA=0: the fp32-FMA kernels below)
+    static const bool mfma_on = [] { const char* e = getenv("TG_CONV_IN_MFMA"); return !(e && e[0] == '0'); }();
+    if (mfma_on && cin == 4 && cout % 160 == 0 && cout <= 640 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      const size_t lds = ((size_t)cout * 56 + 4 * 32 * 168) * 2;
+      long nb = (npix + 127) / 128;
+      if (nb > 1024) nb = 1024;
+      if (dtype == TG_BF16) {
+        auto k = conv_in_mfma_kernel<bf16_t>;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr;
+        hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, st, sample, src_dtype, batch, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, (bf16_t*)out);
+      } else {
+        auto k = conv_in_mfma_kernel<f16_t>;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr;
+        hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, st, sample, src_dtype, batch, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, (f16_t*)out);
+      }
+      TG_LAUNCH_CHECK();
+      return TG_OK;
+    }
+  }
+  {
     // fast path: 8 output channels x 2 pixels per thread, fp32 weights resident in LDS
     const int K = 9 * cin, G = cout / 8;
     const int groups = G > 0 ? 256 / G : 0;
@@ -611,12 +814,40 @@ extern "C" int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, 
   return TG_OK;
 }
 
-extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_t h, int32_t w,
-                           const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream) {
+namespace {
+// the matrix-core kernel takes the problem (dev A/B knob TG_CONV_OUT_MFMA=0: the dot-product kernels)
+bool conv_out_mfma_ok(int cin, int h, int w, int cout) {
+  static const bool on = [] { const char* e = getenv("TG_CONV_OUT_MFMA"); return !(e && e[0] == '0'); }();
+  return on && cin % 64 == 0 && cin <= 320 && cout > 0 && cout <= 8 && h % 8 == 0 && w % 16 == 0;
+}
+}  // namespace
+
+extern "C" int tg_conv_out_takes_coef(int32_t cin, int32_t h, int32_t w, int32_t cout) { return conv_out_mfma_ok(cin, h, w, cout) ? 1 : 0; }
+
+static int conv_out_impl(int32_t dtype, const void* x, const float* coef, int32_t a_silu, int32_t batch, int32_t cin, int32_t h, int32_t w,
+                         const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream) {
   TG_CHECK((dtype == TG_BF16 || dtype == TG_F16) && x && weight && out, TG_ERR_ARG, "tg_conv_out: bad args");
   TG_CHECK(batch > 0 && cin % 8 == 0 && cout > 0 && cout <= 8, TG_ERR_ARG, "tg_conv_out: bad shape cin=%d cout=%d", cin, cout);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long npix = (long)batch * h * w;
+  if (conv_out_mfma_ok(cin, h, w, cout) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(weight) & 15) == 0) {
+    const size_t lds = ((size_t)180 * cin + (size_t)cout * 9 * cin) * 2 + (size_t)2 * cin * 4;
+    const dim3 g((unsigned)(batch * (h / 8) * (w / 16)));
+    if (dtype == TG_BF16) {
+      auto k = conv_out_mfma_kernel<bf16_t>;
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)attr;
+      hipLaunchKernelGGL(k, g, dim3(256), lds, st, (const bf16_t*)x, coef, a_silu, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
+    } else {
+      auto k = conv_out_mfma_kernel<f16_t>;
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)attr;
+      hipLaunchKernelGGL(k, g, dim3(256), lds, st, (const f16_t*)x, coef, a_silu, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
+    }
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+  }
+  TG_CHECK(coef == nullptr, TG_ERR_UNSUPPORTED, "tg_conv_out_gn: the GroupNorm prologue needs a problem the matrix-core kernel takes (tg_conv_out_takes_coef)");
   {
     const size_t lds = (size_t)cout * 9 * cin * 2;
     if (lds <= 64 * 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(weight) & 15) == 0) {
@@ -641,6 +872,17 @@ extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t 
     hipLaunchKernelGGL(conv_out_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
   TG_LAUNCH_CHECK();
   return TG_OK;
+}
+
+extern "C" int tg_conv_out(int32_t dtype, const void* x, int32_t batch, int32_t cin, int32_t h, int32_t w,
+                           const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream) {
+  return conv_out_impl(dtype, x, nullptr, 0, batch, cin, h, w, weight, bias, cout, out, out_f32, stream);
+}
+
+extern "C" int tg_conv_out_gn(int32_t dtype, const void* x, const float* coef, int32_t a_silu, int32_t batch, int32_t cin, int32_t h, int32_t w,
+                              const void* weight, const void* bias, int32_t cout, void* out, int32_t out_f32, void* stream) {
+  TG_CHECK(coef != nullptr, TG_ERR_ARG, "tg_conv_out_gn: null coef");
+  return conv_out_impl(dtype, x, coef, a_silu, batch, cin, h, w, weight, bias, cout, out, out_f32, stream);
 }
 
 extern "C" int tg_timestep_embedding(int32_t dtype, const float* t, const int32_t* index, int32_t t_stride, int32_t rows, int32_t dim,

@@ -595,9 +595,20 @@ def conv_in(sample, weight_packed, bias, cout, dtype):
     return out
 
 
-def conv_out(x, weight_packed, bias, batch, h, w, cout, out_dtype):
+def conv_out_takes_gn(cin, h, w, cout):
+    """True when conv_out runs on the matrix-core kernel, which can apply conv_norm_out + SiLU while it stages its window (``conv_out(..., coef=)``)."""
+    return bool(_lib.lib().tg_conv_out_takes_coef(int(cin), int(h), int(w), int(cout)))
+
+
+def conv_out(x, weight_packed, bias, batch, h, w, cout, out_dtype, coef=None, silu=True):
+    """token-major [B*h*w, cin] -> NCHW [B, cout, h, w]; ``coef`` (groupnorm_coef of conv_norm_out): x is the raw block output, GroupNorm (+SiLU) applied
+    inside the launch (only where conv_out_takes_gn)."""
     cin = x.shape[-1]
     out = torch.empty((batch, cout, h, w), dtype=out_dtype, device=x.device)
+    if coef is not None:
+        _lib.check(_lib.lib().tg_conv_out_gn(_dt(x), _ptr(x), _ptr(coef), 1 if silu else 0, batch, cin, h, w, _ptr(weight_packed), _ptr(bias), cout,
+                                             _ptr(out), 1 if out_dtype == torch.float32 else 0, _stream()))
+        return out
     _lib.check(_lib.lib().tg_conv_out(_dt(x), _ptr(x), batch, cin, h, w, _ptr(weight_packed), _ptr(bias), cout, _ptr(out),
                                       1 if out_dtype == torch.float32 else 0, _stream()))
     return out

@@ -82,6 +82,7 @@ _LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_M
 # norm3 folded into the GEGLU GEMM for row counts up to this (0 = never): where the plain GEGLU GEMM runs on the 128 x 128 kernel anyway (not the 256 x 256 big tile of
 # the 32 x 32 level) the fold costs no tile choice and removes the layernorm launch
 _LN_FF_MAX_ROWS = int(os.environ.get("TG_LN_FF_MAX_ROWS", "0"))
+_CONV_OUT_GN = os.environ.get("TG_CONV_OUT_GN", "1") != "0"      # dev A/B knob: 0 = GroupNorm apply launch + conv_out
 _FF_PAD = os.environ.get("TG_FF_PAD", "1") != "0"      # round 5: pad the FeedForward hidden tensor's / net.2 weight's row pitch (see FeedForward._hidden)
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
@@ -673,10 +674,16 @@ class UNet2DConditionModel(nn.Module):
             if blk.upsamplers is not None:
                 x = blk.upsamplers[0].run(x)
 
-        y = ops.groupnorm(x.t, x.b, x.hw, cfg.norm_num_groups, cfg.norm_eps, self.conv_norm_out.weight, self.conv_norm_out.bias,
-                          silu=True)
         w_out = self._p.get("conv_out", [self.conv_out.weight], lambda: pack_conv3x3(self.conv_out.weight.detach()))
-        out = ops.conv_out(y, w_out, self.conv_out.bias, B, x.h, x.w, cfg.out_channels, out_dtype if out_dtype is not None else dt)
+        odt = out_dtype if out_dtype is not None else dt
+        if _CONV_OUT_GN and ops.conv_out_takes_gn(x.t.shape[-1], x.h, x.w, cfg.out_channels):
+            # conv_norm_out + SiLU inside conv_out's window staging: statistics launch only, the normalised tensor never exists
+            coef = ops.groupnorm_coef(x.t, x.b, x.hw, cfg.norm_num_groups, cfg.norm_eps, self.conv_norm_out.weight, self.conv_norm_out.bias)
+            out = ops.conv_out(x.t, w_out, self.conv_out.bias, B, x.h, x.w, cfg.out_channels, odt, coef=coef, silu=True)
+        else:
+            y = ops.groupnorm(x.t, x.b, x.hw, cfg.norm_num_groups, cfg.norm_eps, self.conv_norm_out.weight, self.conv_norm_out.bias,
+                              silu=True)
+            out = ops.conv_out(y, w_out, self.conv_out.bias, B, x.h, x.w, cfg.out_channels, odt)
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
