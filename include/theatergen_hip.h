@@ -138,10 +138,6 @@ typedef struct {
    * (unet.FeedForward) pads the hidden tensor it owns and its packed copy of net.2's weight. */
   int64_t lda;
   int64_t ldw;
-  /* round 5 (ABI 306), optional: >= 4096 uint32 arrival counters, ZERO on entry and left zero (one set per stream that may run concurrently, like
-   * `workspace`).  With them the K-split work items finish their own tiles — the last one of a tile to arrive sums the tile's fp32 partials in split
-   * order and runs the epilogue — and the separate reduce launch disappears; same additions in the same order, bit-identical.  NULL = reduce launch. */
-  uint32_t* tickets;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);

@@ -271,11 +271,6 @@ def test_gemm_tail_split(kind, shape, monkeypatch):
     again = fn()
     same = torch.equal(out, again)
     assert same
-    # round 5: the split work items finish their own tiles (arrival counters, default) == partials + reduce launch, bit for bit; counters left at zero
-    assert ops.SPLITK_FINISH
-    monkeypatch.setattr(ops, "SPLITK_FINISH", False)
-    assert torch.equal(out, fn()), "in-kernel K-split finish differs from the reduce launch"
-    assert int(ops._tickets(4096, out.device).abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -743,17 +738,6 @@ def test_conv_slab_kernel(dtype, case):
     out = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
     got = out.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     check(got, ref, dtype, f"slab conv {case}")
-    if plan[2] > 1:
-        # round 5: split work items finishing their own tiles (default) == partials + reduce launch, bit for bit, every time; counters left at zero
-        for _ in range(3):
-            assert torch.equal(out, ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw))
-        ops.SPLITK_FINISH = False
-        try:
-            two = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
-        finally:
-            ops.SPLITK_FINISH = True
-        assert torch.equal(out, two), "in-kernel K-split finish differs from the reduce launch"
-        assert int(ops._tickets(4096, out.device).abs().sum().item()) == 0
     old = os.environ.get("TG_GEMM_FLAGS")
     os.environ["TG_GEMM_FLAGS"] = "128"                     # dev flag: the planner skips the slab kernel
     try:

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
         ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
         ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32), ("ln_rows", vp),
-        ("lda", i64), ("ldw", i64), ("tickets", vp),
+        ("lda", i64), ("ldw", i64),
     ]
 
 

@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
 
   epilogue_tile_lds<T, TM, TN, 0>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
                                  reinterpret_cast<float*>(smem) + wave * (32 * (TN * 32 + 4)), part, m0, n0);
-  if (part >= 0 && p.tickets != nullptr) splitk_finish_tile<T>(p, part);        // the last split of a tile to arrive sums and stores the tile
 }
 
 template <typename T, int WI, bool UPS>

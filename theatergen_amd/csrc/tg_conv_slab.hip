@@ -429,7 +429,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (patch) epilogue_tile_lds<T, TM, TN, 0, false, true>(p, acc, mw, nw, lane, scr, -1, mbase, n0, 32, p.patch_pwl);
       else epilogue_tile_lds<T, TM, TN, 0>(p, acc, mw, nw, lane, scr, part, mbase, n0);
     }
-    if (part >= 0 && p.tickets != nullptr) splitk_finish_tile<T>(p, part);      // the last split of a tile to arrive sums and stores the tile
   }
 }
 

@@ -54,7 +54,7 @@ inline int64_t plan_workspace_bytes(const Plan& pl) {
 
 template <typename T>
 int launch_reduce(const GemmParams& p, const Plan& pl, hipStream_t st) {
-  if (pl.s > 1 && p.tickets == nullptr) {        // (with arrival counters the split work items finish their own tiles: splitk_finish)
+  if (pl.s > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)pl.tail * 8), dim3(256), 0, st, p);
     TG_LAUNCH_CHECK();
   }
@@ -390,7 +390,6 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.res = d->res; p.ldres = d->ldres; p.act = d->act; p.geglu = d->geglu; p.out_scale = d->out_scale;
   p.out = d->out; p.ldc = d->ldc; p.n_split = d->n_split; p.out_t = d->out_t; p.ldt = d->ldt;
   p.ws = reinterpret_cast<float*>(d->workspace);
-  p.tickets = d->tickets;
   p.full_tiles = pl.full; p.tail_s = pl.s; p.kt_per_split = pl.kps; p.tiles_n = (int)pl.tiles_n;
   p.tile_bm = kTiles[pl.tile].bm; p.tile_bn = kTiles[pl.tile].bn;
   p.a_rpb = d->mode == 0 ? d->a_rows_per_batch : 0; p.a_bs = d->a_batch_stride;
@@ -431,10 +430,9 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
       p.patch_np = np;
       if (patch) { int l = 0; while ((1 << l) < pw) ++l; p.patch_pwl = l; }
     }
-    p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;          // partial layout of the split work items (splitk_finish / the reduce kernel)
     int rc = tg_conv_slab_launch(d, &p, sp, st);
     if (rc != TG_OK || sp == 1) return rc;
-    p.tiles_n = (int)(d->N / 320);
+    p.tiles_n = (int)(d->N / 320); p.full_tiles = 0; p.tail_s = sp; p.tile_bm = 128; p.tile_bn = 320;
     Plan rp = pl;
     rp.tail = (int)tiles; rp.s = sp;
     return launch_reduce<T>(p, rp, st);

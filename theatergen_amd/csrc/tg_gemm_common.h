@@ -31,7 +31,6 @@ struct GemmParams {
   void* out_t;
   long ldt;
   float* ws;
-  unsigned int* tickets;   // K-split work items finish their own tile (splitk_finish): arrival counters per tail tile, zero between launches; NULL = reduce launch
   int full_tiles;   // tiles [0, full_tiles) are computed whole; each later tile is cut into tail_s K-ranges
   int tail_s;
   int tile_bm, tile_bn;
@@ -202,16 +201,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, f32x16 (&acc)
         for (int g = 0; g < 4; ++g) {
           const long lc = n_base + 32 * j + 8 * g - pn0;
           f32x4 o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (p.tickets == nullptr) {
-            *reinterpret_cast<f32x4*>(wsp + lr * p.tile_bn + lc) = o;
-          } else {
-            // read back by another workgroup of THIS launch (splitk_finish): device-scope stores (sc1: past the XCD's non-coherent L2)
-            typedef unsigned long long u64;
-            u64* dst = reinterpret_cast<u64*>(wsp + lr * p.tile_bn + lc);
-            const f32x2 lo2 = {o[0], o[1]}, hi2 = {o[2], o[3]};
-            __hip_atomic_store(dst, __builtin_bit_cast(u64, lo2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, __builtin_bit_cast(u64, hi2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          *reinterpret_cast<f32x4*>(wsp + lr * p.tile_bn + lc) = o;
         }
     }
     return;
@@ -702,43 +692,6 @@ __device__ __forceinline__ void epilogue_tile_lds(const GemmParams& p, f32x16 (&
     if constexpr (TN == 5) epilogue_chunk_lds<T, TM, TN, EPI, 4, 1, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
     if constexpr (TN == 3) epilogue_chunk_lds<T, TM, TN, EPI, 2, 1, LN, PR>(p, acc, m_wave, n_wave, lane, scr, part, pm0, pn0, mstride, pwl);
     static_assert(TN <= 5, "wave tiles wider than 160 columns are not instantiated");
-  }
-}
-
-// K-SPLIT WITHOUT THE REDUCE LAUNCH (round 5).  A split work item has just written its fp32 partial (epilogue with part >= 0).  With arrival counters
-// (p.tickets, one per tail tile, zero between launches) the LAST work item of a tile to arrive does what a block group of splitk_reduce_kernel would do
-// for that tile: sums the tile's tail_s partials from zero, in split order — whichever item it is: the same fp32 additions in the same order, bit-identical
-// and deterministic — and applies the epilogue through the same epilogue_store4.  The accumulators are dead by then: no register cost in the K loop.
-// No fences (a device-scope release / acquire pair writes back and invalidates the whole XCD L2 under everybody else's reads — see gn_partial_kernel):
-// the partials are written and read with device-scope accesses (sc1), and a work item's stores have completed (vmcnt) before its arrival is counted.
-// The reduce launch it replaces was 26 launches of ~10 us in the graph-replayed SD-1.5 step.  Must be reached by every thread of the workgroup.
-template <typename T>
-__device__ __forceinline__ void splitk_finish_tile(const GemmParams& p, int part) {
-  __shared__ int s_last;
-  const int t = part / p.tail_s;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&p.tickets[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.tail_s - 1u;
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) p.tickets[t] = 0u;
-  typedef unsigned long long u64;
-  const int lbid = p.full_tiles + t;
-  const long m0 = (long)(lbid / p.tiles_n) * p.tile_bm, n0 = (long)(lbid % p.tiles_n) * p.tile_bn;
-  const int q4 = p.tile_bn / 4;
-  const long tile_elems = (long)p.tile_bm * p.tile_bn;
-  const float* base = p.ws + (long)t * p.tail_s * tile_elems;
-  for (int q = threadIdx.x; q < p.tile_bm * q4; q += blockDim.x) {
-    const int lr = q / q4, lc = (q % q4) * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.tail_s; ++z) {
-      const u64* src = reinterpret_cast<const u64*>(base + z * tile_elems + (long)lr * p.tile_bn + lc);
-      const f32x2 lo2 = __builtin_bit_cast(f32x2, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const f32x2 hi2 = __builtin_bit_cast(f32x2, __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      s[0] += lo2[0]; s[1] += lo2[1]; s[2] += hi2[0]; s[3] += hi2[1];
-    }
-    const long m = p.patch_pwl > 0 ? patch_token(p, lbid / p.tiles_n, lr) : m0 + lr;
-    epilogue_store4<T>(p, m, n0 + lc, s[0], s[1], s[2], s[3]);
   }
 }
 

@@ -408,7 +408,6 @@ void gemm_glds_kernel(GemmParams p) {
   } else {
     epilogue_tile_lds<T, TM, TN, EPI>(p, acc, m0 + wave_m * TM * 32, n0 + wave_n * TN * 32, lane,
                                      reinterpret_cast<float*>(smem) + wave * (32 * (SCW * 32 + 4)), part, m0, n0);
-    if (part >= 0 && p.tickets != nullptr) splitk_finish_tile<T>(p, part);      // the last split of a tile to arrive sums and stores the tile
   }
 }
 

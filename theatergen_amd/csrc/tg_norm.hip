@@ -105,24 +105,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
     float s = 0.f, q = 0.f;
     for (int j = 0; j < cpg; ++j) { s += sh[g * cpg + j]; q += sh[C + g * cpg + j]; }
     float* o = p.partials + (((long)b * p.nblk + blk) * p.groups + g) * 2;
-    // device-scope (write-through) stores: read by another workgroup, possibly of this launch and through another XCD's L2
-    __hip_atomic_store(o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(o + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o[0] = s;
+    o[1] = q;
   }
   if (p.tickets != nullptr) {
     // ONE-LAUNCH statistics -> coefficients (round 5): the LAST slab block of a batch item to arrive folds the item's partials (the same fixed-order
     // fp64 fold as gn_coef_kernel, whichever block it is: deterministic) instead of a 16-block launch of its own behind this one (27 per UNet call,
-    // ~6 us each in the graph-replayed step).  NO fences: a device-scope release / acquire pair (__threadfence) writes back and invalidates the
-    // whole XCD L2 — per block, under the other blocks' reads: measured 4 % SLOWER end to end (904.6 -> 942.6 ms, profiles/r5_findings_tickets.md).
-    // The partials are written and read with device-scope accesses instead (sc1: past the non-coherent L2), completed (vmcnt) before the arrival
-    // counter moves.
+    // ~6 us each in the graph-replayed step).  Release / acquire at device scope around the arrival counter: the partials of the other slabs were
+    // written through other XCDs' L2s.
     __shared__ float s_stats[2 * 256];
     __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&p.tickets[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.nblk - 1u;
+    if (threadIdx.x == 0) s_last = atomicAdd(&p.tickets[b], 1u) == (unsigned)p.nblk - 1u;
     __syncthreads();
     if (!s_last) return;
+    __threadfence();
     gn_block_stats(p, b, s_stats);
     gn_write_coef<T>(p, b, s_stats);
     if (threadIdx.x == 0) p.tickets[b] = 0u;       // ready for the next launch on this stream
@@ -145,8 +143,8 @@ __device__ __forceinline__ void gn_block_stats(const GnParams& p, int b, float* 
     if (g < p.groups)
       for (int k = part; k < p.nblk; k += 8) {
         const float* o = p.partials + (((long)b * p.nblk + k) * p.groups + g) * 2;
-        s += (double)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q += (double)__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s += (double)o[0];
+        q += (double)o[1];
       }
     sh[part][gl][0] = s;
     sh[part][gl][1] = q;

@@ -56,20 +56,6 @@ class workspace_slot:
         return False
 
 
-SPLITK_FINISH = os.environ.get("TG_SPLITK_FINISH", "1") != "0"     # dev A/B knob: 0 = K-split tails go through the reduce launch
-
-
-def _tickets(n, device):
-    """Arrival counters (tg_gemm_desc.tickets, tg_groupnorm_coef): zero between launches — the kernels that use them leave them zero — one set per
-    (device, workspace slot), like the scratch: chains that run concurrently on different streams must not share them."""
-    key = (device.index, "tickets", _ws_slot)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(max(int(n), 4096), dtype=torch.int32, device=device)
-        _workspaces[key] = buf
-    return buf
-
-
 def workspace(nbytes, device):
     """Persistent fp32 scratch per (device, slot) (split-K partials, GroupNorm partial sums)."""
     key = (device.index, "ws", _ws_slot)
@@ -138,8 +124,6 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
         ws = workspace(need, a0.device)
         d.workspace = ws.data_ptr()
         d.workspace_bytes = ws.numel() * 4
-        if SPLITK_FINISH:
-            d.tickets = _tickets(4096, a0.device).data_ptr()
     if _gemm_profile is None:
         _lib.check(L.tg_gemm(C.byref(d), _stream()))
         return out
@@ -469,7 +453,13 @@ GN_ONE_LAUNCH = os.environ.get("TG_GN_ONE_LAUNCH", "1") != "0"      # dev A/B kn
 
 
 def _gn_tickets(batch, device):
-    return _tickets(batch, device)
+    """Arrival counters of the one-launch tg_groupnorm_coef: zero between launches, one set per (device, workspace slot) like the scratch."""
+    key = (device.index, "gn_tickets", _ws_slot)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < batch:
+        buf = torch.zeros(max(int(batch), 1024), dtype=torch.int32, device=device)
+        _workspaces[key] = buf
+    return buf
 
 
 def groupnorm_coef(x0, batch, hw, groups, eps, gamma, beta, x1=None):
