@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 306
+#define TG_ABI_VERSION 305
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -214,13 +214,9 @@ int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t 
 int tg_layernorm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream);
 /* GroupNorm statistics only: coef[b][0][c] = rstd(b, group(c)) * gamma[c], coef[b][1][c] = beta[c] - mean(b, group(c)) * coef[b][0][c]
  * (fp32 [batch][2][c0 + c1]; the same reductions, in the same order, as tg_groupnorm) for tg_gemm_desc.a_coef: the apply pass
- * (normalise + SiLU, one HBM write + read of the activation per conv) moves into the consumer conv's window staging.
- * `tickets` (ABI 306; NULL = statistics launch + coefficient launch): >= batch uint32 arrival counters, ZERO on entry and left zero — the last slab
- * block of a batch item folds the partials and writes the coefficients itself, in the same fixed order (bit-identical), one launch instead of two.
- * Launches that may run concurrently (different streams) need their own counters, like `partials`. */
+ * (normalise + SiLU, one HBM write + read of the activation per conv) moves into the consumer conv's window staging. */
 int tg_groupnorm_coef(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch, int64_t hw,
-                      int32_t groups, float eps, const void* gamma, const void* beta, float* coef, void* partials, uint32_t* tickets,
-                      void* stream);
+                      int32_t groups, float eps, const void* gamma, const void* beta, float* coef, void* partials, void* stream);
 
 /* out[m, j] = x[m, j] * gelu(x[m, inner + j])  (GEGLU.forward, models/attention.py:337-338) */
 int tg_geglu(int32_t dtype, const void* x, int64_t rows, int64_t inner, void* out, void* stream);

@@ -452,36 +452,6 @@ def test_gemm_padded_row_pitches(dtype, M, N, K):
     with pytest.raises(RuntimeError):
         ops.gemm(ap[:, :K], wp[:, :K], M, N, K, lda=K + 64, ldw=K + 64, force_tile=10)          # the big tile does not take padded pitches
 
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("batch,hw,c0,c1", [(16, 4096, 320, 0), (16, 4096, 320, 320), (16, 1024, 1280, 640), (2, 16384, 320, 0), (3, 1000, 640, 320)])
-def test_groupnorm_coef_one_launch(dtype, batch, hw, c0, c1, monkeypatch):
-    """round 5: tg_groupnorm_coef in ONE launch — the last slab block of every batch item folds the partials and writes the coefficients (device-scope
-    release / acquire around an arrival counter) — must be BIT-identical to the statistics launch + coefficient launch (same fixed-order folds whichever
-    block arrives last), every time, and leave the counters at zero."""
-    from theatergen_amd import ops
-    g = torch.Generator().manual_seed(batch + hw + c0 + c1)
-    x0 = (torch.randn(batch * hw, c0, generator=g) * 1.7 + 0.4).to(dtype).to(DEV)
-    x1 = (torch.randn(batch * hw, c1, generator=g) * 0.6 - 0.2).to(dtype).to(DEV) if c1 else None
-    C = c0 + c1
-    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype).to(DEV), (0.2 * torch.randn(C, generator=g)).to(dtype).to(DEV)
-    monkeypatch.setattr(ops, "GN_ONE_LAUNCH", False)
-    two = ops.groupnorm_coef(x0, batch, hw, 32, 1e-5, gamma, beta, x1=x1).clone()
-    monkeypatch.setattr(ops, "GN_ONE_LAUNCH", True)
-    for _ in range(20):
-        one = ops.groupnorm_coef(x0, batch, hw, 32, 1e-5, gamma, beta, x1=x1)
-        assert torch.equal(one, two)
-    assert int(ops._gn_tickets(batch, x0.device)[:batch].abs().sum().item()) == 0
-    # fp32 reference of the coefficients
-    xf = (torch.cat([x0, x1], 1) if c1 else x0).float().view(batch, hw, 32, C // 32)
-    mean = xf.mean((1, 3), keepdim=True)
-    var = xf.var((1, 3), unbiased=False, keepdim=True)
-    rstd = (var + 1e-5).rsqrt().expand(batch, 1, 32, C // 32).reshape(batch, C)
-    a = rstd * gamma.float()
-    d = beta.float() - mean.expand(batch, 1, 32, C // 32).reshape(batch, C) * a
-    assert torch.allclose(one[:, 0], a, rtol=2e-4, atol=2e-5) and torch.allclose(one[:, 1], d, rtol=2e-4, atol=2e-4)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,h,w,cout,sdt", [(16, 64, 64, 320, torch.float32), (2, 96, 96, 320, torch.float32), (3, 17, 23, 320, torch.float32),
                                             (2, 128, 128, 320, None), (1, 8, 8, 160, torch.float32), (2, 16, 16, 640, torch.float32)])

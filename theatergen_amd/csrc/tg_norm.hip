@@ -28,7 +28,6 @@ struct GnParams {
   int nblk;
   int cx, ry;       // thread grid: cx channel-chunk columns x ry pixel rows
   float* coef;      // tg_groupnorm_coef: [batch][2][C] (a = rstd * gamma, d = beta - mean * a) instead of the normalised tensor
-  unsigned int* tickets;   // tg_groupnorm_coef, one-launch form: [batch] arrival counters (zero between launches)
 };
 
 template <typename T>
@@ -37,9 +36,6 @@ __device__ __forceinline__ typename Vec<T>::v8 gn_load8(const GnParams& p, int b
   if (ch < p.c0) return *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.x0) + ((long)b * p.hw + pix) * p.c0 + ch);
   return *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(p.x1) + ((long)b * p.hw + pix) * p.c1 + (ch - p.c0));
 }
-
-__device__ __forceinline__ void gn_block_stats(const GnParams& p, int b, float* s_stats);
-template <typename T> __device__ __forceinline__ void gn_write_coef(const GnParams& p, int b, const float* s_stats);
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
@@ -107,23 +103,6 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
     float* o = p.partials + (((long)b * p.nblk + blk) * p.groups + g) * 2;
     o[0] = s;
     o[1] = q;
-  }
-  if (p.tickets != nullptr) {
-    // ONE-LAUNCH statistics -> coefficients (round 5): the LAST slab block of a batch item to arrive folds the item's partials (the same fixed-order
-    // fp64 fold as gn_coef_kernel, whichever block it is: deterministic) instead of a 16-block launch of its own behind this one (27 per UNet call,
-    // ~6 us each in the graph-replayed step).  Release / acquire at device scope around the arrival counter: the partials of the other slabs were
-    // written through other XCDs' L2s.
-    __shared__ float s_stats[2 * 256];
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&p.tickets[b], 1u) == (unsigned)p.nblk - 1u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    gn_block_stats(p, b, s_stats);
-    gn_write_coef<T>(p, b, s_stats);
-    if (threadIdx.x == 0) p.tickets[b] = 0u;       // ready for the next launch on this stream
   }
 }
 
@@ -245,9 +224,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
 
 // statistics -> per-(batch, channel) coefficients, the prologue of gn_apply_kernel as a launch of its own (one block per
 // batch item): a = rstd * gamma, d = beta - mean * a, the expressions gn_apply_kernel evaluates per thread
-template <typename T> __device__ __forceinline__ void gn_write_coef(const GnParams& p, int b, const float* s_stats) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_coef_kernel(GnParams p) {
+  __shared__ float s_stats[2 * 256];
   const int C = p.c0 + p.c1;
   const int cpg = C / p.groups;
+  const int b = blockIdx.x;
+  gn_block_stats(p, b, s_stats);
   const T* gam = reinterpret_cast<const T*>(p.gamma);
   const T* bet = reinterpret_cast<const T*>(p.beta);
   float* ca = p.coef + (long)b * 2 * C;
@@ -261,12 +244,6 @@ template <typename T> __device__ __forceinline__ void gn_write_coef(const GnPara
     ca[ch] = a;
     ca[C + ch] = be - mean * a;
   }
-}
-template <typename T>
-__global__ __launch_bounds__(256) void gn_coef_kernel(GnParams p) {
-  __shared__ float s_stats[2 * 256];
-  gn_block_stats(p, (int)blockIdx.x, s_stats);
-  gn_write_coef<T>(p, (int)blockIdx.x, s_stats);
 }
 
 // SMALL MAPS (hw <= 256: the 16x16 and 8x8 levels) in ONE launch: a block owns one batch item x `gpb` whole groups
@@ -516,7 +493,7 @@ extern "C" int64_t tg_groupnorm_scratch_bytes(int32_t batch, int64_t hw, int32_t
 namespace {
 int groupnorm_impl(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
                    int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu,
-                   void* out, float* coef, void* partials, void* stream, unsigned int* tickets = nullptr) {
+                   void* out, float* coef, void* partials, void* stream) {
   TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_groupnorm: bad dtype");
   TG_CHECK(x0 && (out || coef) && partials, TG_ERR_ARG, "tg_groupnorm: null pointer");
   if (!x1) c1 = 0;
@@ -549,7 +526,6 @@ int groupnorm_impl(int32_t dtype, const void* x0, const void* x1, int32_t c0, in
     }
   }
   p.nblk = gn_nblk(batch, hw);
-  p.tickets = coef != nullptr ? tickets : nullptr;
   p.partials = reinterpret_cast<float*>(partials);
   p.stats = p.partials + (long)batch * p.nblk * groups * 2;
   const int cpr = C / 8;
@@ -561,7 +537,6 @@ int groupnorm_impl(int32_t dtype, const void* x0, const void* x1, int32_t c0, in
   else hipLaunchKernelGGL(gn_partial_kernel<f16_t>, grid, dim3(256), lds, st, p);
   TG_LAUNCH_CHECK();
   if (coef != nullptr) {
-    if (p.tickets != nullptr) return TG_OK;       // the partial kernel's last blocks wrote the coefficients
     if (dtype == TG_BF16) hipLaunchKernelGGL(gn_coef_kernel<bf16_t>, dim3(batch), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(gn_coef_kernel<f16_t>, dim3(batch), dim3(256), 0, st, p);
     TG_LAUNCH_CHECK();
@@ -584,9 +559,9 @@ extern "C" int tg_groupnorm(int32_t dtype, const void* x0, const void* x1, int32
 
 extern "C" int tg_groupnorm_coef(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch,
                                  int64_t hw, int32_t groups, float eps, const void* gamma, const void* beta, float* coef,
-                                 void* partials, uint32_t* tickets, void* stream) {
+                                 void* partials, void* stream) {
   TG_CHECK(coef != nullptr, TG_ERR_ARG, "tg_groupnorm_coef: null coef");
-  return groupnorm_impl(dtype, x0, x1, c0, c1, batch, hw, groups, eps, gamma, beta, 0, nullptr, coef, partials, stream, tickets);
+  return groupnorm_impl(dtype, x0, x1, c0, c1, batch, hw, groups, eps, gamma, beta, 0, nullptr, coef, partials, stream);
 }
 
 extern "C" int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps,

@@ -449,19 +449,6 @@ def groupnorm(x0, batch, hw, groups, eps, gamma, beta, silu=False, x1=None, out=
     return out
 
 
-GN_ONE_LAUNCH = os.environ.get("TG_GN_ONE_LAUNCH", "1") != "0"      # dev A/B knob: 0 = statistics launch + coefficient launch
-
-
-def _gn_tickets(batch, device):
-    """Arrival counters of the one-launch tg_groupnorm_coef: zero between launches, one set per (device, workspace slot) like the scratch."""
-    key = (device.index, "gn_tickets", _ws_slot)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < batch:
-        buf = torch.zeros(max(int(batch), 1024), dtype=torch.int32, device=device)
-        _workspaces[key] = buf
-    return buf
-
-
 def groupnorm_coef(x0, batch, hw, groups, eps, gamma, beta, x1=None):
     """GroupNorm statistics only -> fp32 [batch, 2, C]: a = rstd * gamma, d = beta - mean * a (``conv3x3(..., a_coef=)``)."""
     _need_cuda(x0)
@@ -470,9 +457,8 @@ def groupnorm_coef(x0, batch, hw, groups, eps, gamma, beta, x1=None):
     L = _lib.lib()
     coef = torch.empty((batch, 2, c0 + c1), dtype=torch.float32, device=x0.device)
     scratch = workspace(L.tg_groupnorm_scratch_bytes(batch, hw, groups), x0.device)
-    tickets = _gn_tickets(batch, x0.device) if GN_ONE_LAUNCH else None
     _lib.check(L.tg_groupnorm_coef(_dt(x0), _ptr(x0), _ptr(x1), c0, c1, batch, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
-                                   _ptr(coef), _ptr(scratch), _ptr(tickets), _stream()))
+                                   _ptr(coef), _ptr(scratch), _stream()))
     return coef
 
 
