@@ -475,3 +475,37 @@ def test_conv_in_on_matrix_cores(dtype, B, h, w, cout, sdt):
     err = (out.double() - ref).abs()
     assert bool((err <= ulp * ref.abs().clamp_min(2.0 ** -14) * 1.01 + 1e-6).all()), err.max().item()
     assert (out == want).float().mean().item() > 0.97
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,h,w,cin,cout,odt", [(16, 64, 64, 320, 4, torch.float32), (2, 96, 96, 320, 4, torch.float32), (2, 128, 128, 320, 4, None),
+                                                (3, 8, 16, 64, 4, torch.float32), (2, 16, 32, 128, 8, torch.float32), (1, 24, 48, 256, 3, None)])
+def test_conv_out_on_matrix_cores_with_groupnorm_prologue(dtype, B, h, w, cin, cout, odt):
+    """round 5: conv_norm_out + SiLU + conv_out (models/unet_2d_condition.py:1015-1018) in one launch on the matrix cores: vs fp32
+    conv2d(silu(group_norm(x))) ; BIT-identical to tg_groupnorm followed by the plain tg_conv_out (same expression, same rounding of the normalised
+    activations, same kernel); image borders, tiles of several images, cout up to 8, both output dtypes."""
+    import torch.nn.functional as F
+    from tests.test_kernels_gpu import rnd
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_conv3x3
+    g = torch.Generator().manual_seed(B + h + w + cin + cout)
+    odt = odt or dtype
+    x = (rnd((B, cin, h, w), dtype, g) * 1.5 + 0.3)
+    gamma, beta = (1 + 0.2 * torch.randn(cin, generator=g)).to(dtype), (0.1 * torch.randn(cin, generator=g)).to(dtype)
+    wt, bias = rnd((cout, cin, 3, 3), dtype, g, 1 / (3 * cin ** 0.5)), rnd((cout,), dtype, g)
+    assert ops.conv_out_takes_gn(cin, h, w, cout)
+    tok = x.permute(0, 2, 3, 1).reshape(B * h * w, cin).contiguous().to(DEV)
+    wp = pack_conv3x3(wt).to(DEV)
+    coef = ops.groupnorm_coef(tok, B, h * w, 32, 1e-5, gamma.to(DEV), beta.to(DEV))
+    fused = ops.conv_out(tok, wp, bias.to(DEV), B, h, w, cout, odt, coef=coef, silu=True)
+    y = ops.groupnorm(tok, B, h * w, 32, 1e-5, gamma.to(DEV), beta.to(DEV), silu=True)
+    two = ops.conv_out(y, wp, bias.to(DEV), B, h, w, cout, odt)
+    assert torch.equal(fused, two), "conv_out with the GroupNorm prologue differs from tg_groupnorm + tg_conv_out"
+    # fp32 reference on the ROUNDED normalised activations (what both paths feed the conv) and, looser, on the unrounded ones
+    yn = y.float().cpu().reshape(B, h, w, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(yn.double(), wt.double(), bias.double(), padding=1)
+    err = (fused.double().cpu() - ref).abs().max().item()
+    tol = 2e-3 if odt == torch.float32 else (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9) * max(1.0, ref.abs().max().item())
+    assert err <= tol, (err, tol)
+    full = F.conv2d(F.silu(F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-5)), wt.float(), bias.float(), padding=1)
+    assert (fused.float().cpu() - full).abs().max().item() <= 0.05 * max(1.0, full.abs().max().item())

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 305          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 306          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
