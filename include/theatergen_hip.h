@@ -186,6 +186,26 @@ typedef struct {
 
 int tg_attention(const tg_attn_desc* d, void* stream);
 
+/* Reverse pass of SELF-attention without materialised probabilities (round 5, ABI 306; csrc/tg_attention_bwd.hip), head_dim <= 64, n % 8 == 0:
+ *     dQ = dS K,  dK = dS^T Q,  dV = P^T dO   with  P = softmax(scale Q K^T),  dS = scale P o (dO V^T - rowsum(P o dO V^T))
+ * — what `torch.autograd.grad(loss, latents)` of the guidance step (models/pipelines.py:62-128) computes through `Attention` / AttnProcessor
+ * (ip_adapter/attention_processor.py:113-219).  Three launches of one kernel (row statistics lse / D, dQ, dK + dV); scores are recomputed from Q / K
+ * tiles, nothing n x n exists in memory.  q, k, v, dout, dq, dk, dv: [batch][n][>= heads * head_dim] rows of pitch `ld`, batch stride `bs` (elements);
+ * qt, kt, doutt: the TRANSPOSES [batch][heads * head_dim][n] (tg_transpose) with row pitch `t_ld`, batch stride `t_bs`; stats: fp32 scratch
+ * [batch][heads][n][2].  P and dS are rounded to the storage dtype where they enter a product (as a materialised implementation stores them).
+ * TG_ERR_UNSUPPORTED for other head dims / ragged n: the caller keeps its materialised path. */
+typedef struct {
+  int32_t dtype, batch, heads, head_dim, n;
+  const void* q; const void* k; const void* v; const void* dout;
+  int64_t ld, bs;
+  const void* qt; const void* kt; const void* doutt;
+  int64_t t_ld, t_bs;
+  float* stats;
+  void* dq; void* dk; void* dv;
+  float scale;
+} tg_attn_bwd_desc;
+int tg_attention_bwd(const tg_attn_bwd_desc* d, void* stream);
+
 /* Attention-probability export (the save_attn_to_dict side channel, attention_processor.py:532-551):
  * probs[b - b0, h, i, t] = softmax_j(s q_i . k_j)[tokens[t]] for batch items b in [b0, batch), fp32 out
  * [batch - b0, heads, n_q, n_tokens].  tokens == NULL: all `len` columns.  */

@@ -63,7 +63,7 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if short(r[2]) == "conv_in_fast_kernel"]
+    starts = [i for i, r in enumerate(rows) if short(r[2]) in ("conv_in_fast_kernel", "conv_in_mfma_kernel", "conv_in_kernel")]
     steps = []
     for a, b in zip(starts[:-1], starts[1:]):
         ks = rows[a:b]

@@ -511,3 +511,52 @@ def test_conv_out_on_matrix_cores_with_groupnorm_prologue(dtype, B, h, w, cin, c
     assert err <= tol, (err, tol)
     full = F.conv2d(F.silu(F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-5)), wt.float(), bias.float(), padding=1)
     assert (fused.float().cpu() - full).abs().max().item() <= 0.05 * max(1.0, full.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,heads,d", [(2, 576, 5, 64), (1, 2304, 5, 64), (2, 200, 3, 40), (1, 136, 2, 64), (2, 64, 4, 32), (1, 8, 1, 8), (1, 1096, 10, 64)])
+def test_attention_reverse_pass_without_materialised_probabilities(dtype, B, N, heads, d):
+    """round 5: tg_attention_bwd (statistics / dQ / dK + dV launches of one recompute kernel) vs fp32 autograd of softmax(s Q K^T) V on the same
+    storage-dtype operands: ragged last tiles (N not a multiple of 64 / 128), head dims below 64, one-tile problems."""
+    from tests import parity_metrics as pm
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(B + N + heads + d)
+    inner = heads * d
+    q, k, v, do = [(torch.randn(B * N, inner, generator=g) * s_).to(dtype) for s_ in (1.0, 1.0, 1.0, 0.5)]
+    scale = d ** -0.5
+    def heads_(t):
+        return t.float().reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    qr, kr, vr = [heads_(t).clone().requires_grad_(True) for t in (q, k, v)]
+    o = torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1) @ vr
+    rq, rk, rv = torch.autograd.grad(o, [qr, kr, vr], heads_(do))
+    dq, dk, dv = ops.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV), B, N, heads, d, scale)
+    l2, mx = (2e-2, 6e-2) if dtype == torch.bfloat16 else (3e-3, 1.5e-2)
+    for name, got, ref in (("dQ", dq, rq), ("dK", dk, rk), ("dV", dv, rv)):
+        pm.check(got.float().cpu().reshape(B, N, heads, d).permute(0, 2, 1, 3), ref, f"attention_bwd {name} {(B, N, heads, d)} {dtype}", l2, mx)
+    again = ops.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV), B, N, heads, d, scale)
+    assert all(torch.equal(a, b) for a, b in zip((dq, dk, dv), again)), "not deterministic"
+
+
+def test_attention_reverse_pass_matches_the_materialised_path(monkeypatch):
+    """the recompute-based self-attention reverse pass (default) and the per-(item, head) materialised one (TG_FLASH_BWD=0) through
+    backward.attention_input_grad on an SD-2.1-shaped layer; refusal of shapes the kernel does not take."""
+    from tests import parity_metrics as pm
+    from theatergen_amd import backward, ops
+    from theatergen_amd.attention_processor import Attention, AttnProcessor
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    C, heads, B, N = 320, 5, 2, 576
+    attn = Attention(query_dim=C, heads=heads, dim_head=C // heads).to(DEV, dtype)
+    for p_ in attn.parameters():
+        p_.data = (torch.randn(p_.shape, generator=g) * (0.06 if p_.dim() == 2 else 0.02)).to(DEV, dtype)
+    h = (torch.randn(B * N, C, generator=g)).to(dtype).to(DEV)
+    dout = (torch.randn(B * N, C, generator=g) * 0.5).to(dtype).to(DEV)
+    assert backward.FLASH_BWD and ops.attention_bwd_supported(C // heads, N)
+    new = backward.attention_input_grad(attn, AttnProcessor(), h, B, N, None, dout, None)
+    monkeypatch.setattr(backward, "FLASH_BWD", False)
+    old = backward.attention_input_grad(attn, AttnProcessor(), h, B, N, None, dout, None)
+    pm.check(new, old.float(), "flash vs materialised self-attention input grad", 1.5e-2, 6e-2)
+    assert not ops.attention_bwd_supported(80, 1024) and not ops.attention_bwd_supported(64, 100)
+    x = torch.zeros(100, 64, dtype=dtype, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.attention_bwd(x, x, x, x, 1, 100, 1, 64, 0.125)

@@ -43,6 +43,15 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("batch", i32), ("heads", i32), ("head_dim", i32), ("n", i32),
+        ("q", vp), ("k", vp), ("v", vp), ("dout", vp), ("ld", i64), ("bs", i64),
+        ("qt", vp), ("kt", vp), ("doutt", vp), ("t_ld", i64), ("t_bs", i64),
+        ("stats", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("scale", f32),
+    ]
+
+
 class RcLinearDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("x", vp), ("ldx", i64), ("wpk", vp), ("res", vp), ("ldres", i64),
@@ -117,6 +126,7 @@ SIGNATURES = {
     "tg_gemm_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
     "tg_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "tg_attention": (i32, [C.POINTER(AttnDesc), vp]),
+    "tg_attention_bwd": (i32, [C.POINTER(AttnBwdDesc), vp]),
     "tg_attn_probs": (i32, [i32, i32, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, f32, vp, i32, vp, vp]),
     "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),
     "tg_groupnorm": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, i32, vp, vp, vp]),

@@ -27,6 +27,9 @@ from .unet import BasicTransformerBlock, DeviceSchedule, _Act  # noqa: F401
 from .weights_pack import pack_conv1x1, pack_conv3x3
 
 
+FLASH_BWD = os.environ.get("TG_FLASH_BWD", "1") != "0"     # dev A/B knob: 0 = the materialised per-(item, head) reverse pass for every layer
+
+
 class _StopForward(Exception):
     pass
 
@@ -155,6 +158,15 @@ def attention_input_grad(attn, proc, h2d, B, N, enc, dout, extra):
         else:
             e2 = enc.contiguous().reshape(B * Ltot, ctx)
             segs.append((ops.linear(e2, attn.to_k.weight), ops.linear(e2, attn.to_v.weight), Ltot, 1.0, extra))
+    if self_attn and FLASH_BWD and ops.attention_bwd_supported(d, N):
+        # recompute-based reverse pass (round 5, tg_attention_bwd): no N x N matrix, three launches for all (item, head) pairs
+        k2d, v2d = segs[0][0], segs[0][1]
+        dq, dk, dv = ops.attention_bwd(q, k2d, v2d, do.contiguous(), B, N, heads, d, attn.scale)
+        dx = _dgrad_lin(dq, _lin_t(attn, "q", attn.to_q.weight))
+        wk, wv = _lin_t(attn, "k", attn.to_k.weight), _lin_t(attn, "v", attn.to_v.weight)
+        dx = ops.gemm(dk, wk, B * N, wk.shape[0], wk.shape[1], res=dx)
+        dx = ops.gemm(dv, wv, B * N, wv.shape[0], wv.shape[1], res=dx)
+        return dx
     qh, doh = _heads(q, B, N, heads, d), _heads(do, B, N, heads, d)
     dqh = torch.zeros((B, heads, N, d), dtype=dt, device=dev)
     Np = _r8(N)

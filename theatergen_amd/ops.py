@@ -530,6 +530,36 @@ def add(a, b, out=None):
     return out
 
 
+def attention_bwd_supported(head_dim, n):
+    """True when tg_attention_bwd (recompute-based self-attention reverse pass) takes the problem."""
+    return head_dim % 8 == 0 and head_dim <= 64 and n % 8 == 0
+
+
+def attention_bwd(q, k, v, dout, batch, n, heads, head_dim, scale):
+    """Self-attention reverse pass without materialised probabilities: q, k, v, dout [batch * n, heads * head_dim] (contiguous rows) ->
+    (dq, dk, dv) in the same layout.  Three launches of one kernel (+ three tg_transpose launches for the streamed K^T / Q^T / dO^T tiles)."""
+    _need_cuda(q)
+    inner = heads * head_dim
+    for t in (q, k, v, dout):
+        if t.shape != (batch * n, inner) or not t.is_contiguous() or t.dtype != q.dtype:
+            raise RuntimeError("attention_bwd: q, k, v, dout must be contiguous [batch * n, heads * head_dim] tensors of one dtype")
+    L = _lib.lib()
+    qt, kt, dot = transpose(q, batch, n, inner), transpose(k, batch, n, inner), transpose(dout, batch, n, inner)
+    stats = torch.empty((batch, heads, n, 2), dtype=torch.float32, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    d = _lib.AttnBwdDesc()
+    d.dtype, d.batch, d.heads, d.head_dim, d.n = _dt(q), batch, heads, head_dim, n
+    d.q, d.k, d.v, d.dout = _ptr(q), _ptr(k), _ptr(v), _ptr(dout)
+    d.ld, d.bs = inner, n * inner
+    d.qt, d.kt, d.doutt = _ptr(qt), _ptr(kt), _ptr(dot)
+    d.t_ld, d.t_bs = n, inner * n
+    d.stats = _ptr(stats)
+    d.dq, d.dk, d.dv = _ptr(dq), _ptr(dk), _ptr(dv)
+    d.scale = float(scale)
+    _lib.check(L.tg_attention_bwd(C.byref(d), _stream()))
+    return dq, dk, dv
+
+
 def transpose(src, batch, rows, cols, out=None):
     """out[b, c, r] = src[b, r, c]"""
     if out is None:
