@@ -414,9 +414,14 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const void* sample, i
   T* sw = reinterpret_cast<T*>(cim_smem);                           // [cout][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   T* so = sw + (size_t)cout * WP + (size_t)wave * 32 * OP;          // [32][OP] per wave
-  for (int i = tid; i < cout * KP; i += 256) {
-    const int n = i / KP, k = i - n * KP;
-    sw[n * WP + k] = k < K ? weight[n * K + k] : from_f32<T>(0.f);
+  // weight rows (72 bytes) in 8-byte pieces, 12 per padded row (the last three are the zero padding of k = 36 .. 47)
+  for (int i = tid; i < cout * (KP / 4); i += 256) {
+    const int n = i / (KP / 4), c = i - n * (KP / 4);
+    V4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(0.f);
+    if (c < K / 4) v = *reinterpret_cast<const V4*>(weight + n * K + 4 * c);
+    *reinterpret_cast<V4*>(sw + n * WP + 4 * c) = v;
   }
   __syncthreads();
   const long npix = (long)batch * h * w;
@@ -592,15 +597,17 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
     for (int i = tid; i < 2 * cin; i += 256) sc[i] = coef[(long)b * 2 * cin + i];
     __syncthreads();
   }
-  // ---- window: global -> registers (-> GroupNorm + SiLU) -> LDS, four chunks in flight per thread
+  // ---- window: global -> registers (-> GroupNorm + SiLU) -> LDS, NU 16-byte chunks in flight per thread (the staging is latency-bound: 28 chunks per
+  // thread at cin = 320; four in flight measured 47 us for the whole launch against ~6 us of LDS-pipe time)
+  constexpr int NU = 7;
   const T* xb = x + (long)b * h * w * cin;
   const int nchunk = WIN * ch8;
-  for (int q0 = tid; q0 < nchunk; q0 += 4 * 256) {
-    V8 v[4];
-    int wp[4], c[4];
-    bool ok[4];
+  for (int q0 = tid; q0 < nchunk; q0 += NU * 256) {
+    V8 v[NU];
+    int wp[NU], c[NU];
+    bool ok[NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int q = q0 + u * 256;
       wp[u] = q / ch8; c[u] = q - wp[u] * ch8;
       const int wy = wp[u] / WW, wx = wp[u] - wy * WW;
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
       if (ok[u]) v[u] = *reinterpret_cast<const V8*>(xb + ((long)yy * w + xx) * cin + c[u] * 8);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       if (q0 + u * 256 >= nchunk) continue;
       if (coef != nullptr && ok[u]) {
         const float* ca = sc + c[u] * 8;
@@ -766,7 +773,7 @@ extern "C" int tg_conv_in(int32_t dtype, const void* sample, int32_t src_dtype, 
   {
     // matrix-core path (round 5): cin = 4, cout a multiple of 160 (dev A/B knob TG_CONV_IN_MFMA=0: the fp32-FMA kernels below)
     static const bool mfma_on = [] { const char* e = getenv("TG_CONV_IN_MFMA"); return !(e && e[0] == '0'); }();
-    if (mfma_on && cin == 4 && cout % 160 == 0 && cout <= 640 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    if (mfma_on && cin == 4 && cout % 160 == 0 && cout <= 640 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(weight) & 7) == 0) {
       const size_t lds = ((size_t)cout * 56 + 4 * 32 * 168) * 2;
       long nb = (npix + 127) / 128;
       if (nb > 1024) nb = 1024;
