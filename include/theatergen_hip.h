@@ -205,6 +205,22 @@ typedef struct {
   float scale;
 } tg_attn_bwd_desc;
 int tg_attention_bwd(const tg_attn_bwd_desc* d, void* stream);
+/* The same for one softmax segment of CROSS-attention (text keys, or the IP-Adapter's image keys: ip_adapter/attention_processor.py:445-529): K / V are
+ * constants of the conditioning, so only dQ is produced (statistics + dQ launches), over n_k keys (any count; `kt` = K^T [batch][heads * head_dim][t_ld]
+ * zero-padded to a multiple of 8 columns).  `extra` (optional, fp32 [batch][heads][n_q][extra_ld >= n_k]): d loss / d P of a loss that reads the
+ * probabilities (the guidance loss on the text maps, utils/guidance.py:91-286) — it joins dO V^T before the softmax Jacobian.  `scale`: softmax scale;
+ * `ds_scale`: scale x the segment's output weight (the IP scale for the image segment).  dq is written (not accumulated). */
+typedef struct {
+  int32_t dtype, batch, heads, head_dim, n_q, n_k;
+  const void* q; const void* dout; int64_t q_ld, q_bs;
+  const void* k; const void* v; int64_t k_ld, k_bs;
+  const void* kt; int64_t t_ld, t_bs;
+  const float* extra; int64_t extra_ld;
+  float* stats;                /* fp32 scratch [batch][heads][n_q][2] */
+  void* dq;
+  float scale, ds_scale;
+} tg_attn_bwd_cross_desc;
+int tg_attention_bwd_cross(const tg_attn_bwd_cross_desc* d, void* stream);
 
 /* Attention-probability export (the save_attn_to_dict side channel, attention_processor.py:532-551):
  * probs[b - b0, h, i, t] = softmax_j(s q_i . k_j)[tokens[t]] for batch items b in [b0, batch), fp32 out

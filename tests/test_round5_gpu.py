@@ -560,3 +560,33 @@ def test_attention_reverse_pass_matches_the_materialised_path(monkeypatch):
     x = torch.zeros(100, 64, dtype=dtype, device=DEV)
     with pytest.raises(RuntimeError):
         ops.attention_bwd(x, x, x, x, 1, 100, 1, 64, 0.125)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,L,heads,d,with_extra", [(2, 576, 77, 5, 64, True), (1, 2304, 77, 10, 64, False), (2, 200, 4, 3, 40, False), (1, 1000, 16, 2, 64, True),
+                                                     (2, 64, 93, 4, 32, True)])
+def test_cross_attention_reverse_pass_segment(dtype, B, N, L, heads, d, with_extra):
+    """round 5: tg_attention_bwd_cross — dQ of one softmax segment over a short constant key set (77 text keys / the IP-Adapter's image keys), with the
+    guidance loss's d loss / d P joining dO V^T and a segment weight on dS — vs fp32 autograd of  w * softmax(s Q K^T) V  (+ <extra, P>)."""
+    from tests import parity_metrics as pm
+    from theatergen_amd import ops
+    g = torch.Generator().manual_seed(B + N + L + heads + d)
+    inner = heads * d
+    q, do = (torch.randn(B * N, inner, generator=g)).to(dtype), (torch.randn(B * N, inner, generator=g) * 0.5).to(dtype)
+    k, v = (torch.randn(B * L, inner, generator=g)).to(dtype), (torch.randn(B * L, inner, generator=g)).to(dtype)
+    extra = (torch.randn(B, heads, N, L, generator=g) * 0.3) if with_extra else None
+    scale, wgt = d ** -0.5, 0.4
+    def hd(t, n):
+        return t.float().reshape(B, n, heads, d).permute(0, 2, 1, 3)
+    qr = hd(q, N).clone().requires_grad_(True)
+    P = torch.softmax(qr @ hd(k, L).transpose(-1, -2) * scale, -1)
+    outs, grads = [wgt * (P @ hd(v, L))], [hd(do, N)]
+    if with_extra:
+        outs.append(P)
+        grads.append(extra)
+    ref = torch.autograd.grad(outs, qr, grads)[0]
+    dq = ops.attention_bwd_cross(q.to(DEV), do.to(DEV), k.to(DEV), v.to(DEV), B, N, L, heads, d, scale, scale * wgt,
+                                 extra=(extra / wgt).to(DEV) if with_extra else None)
+    # (the kernel's dS = ds_scale * P o (dP + extra - D): with a segment weight the caller's extra is per unit of weight)
+    l2, mx = (2e-2, 6e-2) if dtype == torch.bfloat16 else (3e-3, 1.5e-2)
+    pm.check(dq.float().cpu().reshape(B, N, heads, d).permute(0, 2, 1, 3), ref, f"attention_bwd_cross {(B, N, L, heads, d, with_extra)} {dtype}", l2, mx)

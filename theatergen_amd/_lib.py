@@ -52,6 +52,16 @@ class AttnBwdDesc(C.Structure):
     ]
 
 
+class AttnBwdCrossDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("batch", i32), ("heads", i32), ("head_dim", i32), ("n_q", i32), ("n_k", i32),
+        ("q", vp), ("dout", vp), ("q_ld", i64), ("q_bs", i64),
+        ("k", vp), ("v", vp), ("k_ld", i64), ("k_bs", i64),
+        ("kt", vp), ("t_ld", i64), ("t_bs", i64),
+        ("extra", vp), ("extra_ld", i64), ("stats", vp), ("dq", vp), ("scale", f32), ("ds_scale", f32),
+    ]
+
+
 class RcLinearDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("x", vp), ("ldx", i64), ("wpk", vp), ("res", vp), ("ldres", i64),
@@ -127,6 +137,7 @@ SIGNATURES = {
     "tg_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "tg_attention": (i32, [C.POINTER(AttnDesc), vp]),
     "tg_attention_bwd": (i32, [C.POINTER(AttnBwdDesc), vp]),
+    "tg_attention_bwd_cross": (i32, [C.POINTER(AttnBwdCrossDesc), vp]),
     "tg_attn_probs": (i32, [i32, i32, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, f32, vp, i32, vp, vp]),
     "tg_groupnorm_scratch_bytes": (i64, [i32, i64, i32]),
     "tg_groupnorm": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, i32, vp, vp, vp]),

@@ -167,6 +167,19 @@ def attention_input_grad(attn, proc, h2d, B, N, enc, dout, extra):
         dx = ops.gemm(dk, wk, B * N, wk.shape[0], wk.shape[1], res=dx)
         dx = ops.gemm(dv, wv, B * N, wv.shape[0], wv.shape[1], res=dx)
         return dx
+    if not self_attn and FLASH_BWD and d % 8 == 0 and d <= 64:
+        # cross-attention: constant K / V, one softmax per segment (text, IP-Adapter image keys): statistics + dQ launches per segment (tg_attention_bwd_cross)
+        dq = None
+        doc = do.contiguous()
+        for k2d, v2d, L, wgt, ex in segs:
+            if wgt == 0.0:
+                continue
+            part = ops.attention_bwd_cross(q, doc, k2d, v2d, B, N, L, heads, d, attn.scale, attn.scale * wgt,
+                                           extra=ex.contiguous() if ex is not None else None)
+            dq = part if dq is None else dq + part
+        if dq is None:
+            dq = torch.zeros_like(q)
+        return _dgrad_lin(dq, _lin_t(attn, "q", attn.to_q.weight))
     qh, doh = _heads(q, B, N, heads, d), _heads(do, B, N, heads, d)
     dqh = torch.zeros((B, heads, N, d), dtype=dt, device=dev)
     Np = _r8(N)

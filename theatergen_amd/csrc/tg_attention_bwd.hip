@@ -22,6 +22,9 @@ __device__ __attribute__((aligned(16))) unsigned int attn_bwd_zero_page[4] = {0u
 
 struct AttnBwdParams {
   int heads, hd, n_r, n_s, n_rblk;
+  int n_z;                                               // columns of the transposed streamed tensors that may be read (n_s rounded up to 8: zero padding)
+  const float* extra; long e_ld;                         // MODE 0 / 2, optional: d loss / d P added to dP, fp32 [batch][heads][n_r][e_ld >= n_s] (cross-attention guidance term)
+  float ds_scale;                                        // dS = ds_scale * P o (dP - D)   (softmax scale x the segment's output weight)
   const void* r1; const void* r2; long r_ld, r_bs;       // register-side rows [n_r][...]: MODE 0 / 2: Q, dO;  MODE 1: K, V
   const void* s1; const void* s2; long s_ld, s_bs;       // streamed rows [n_s][...]:      MODE 0 / 2: K, V;   MODE 1: Q, dO
   const void* z1; const void* z2; long z_ld, z_bs;       // streamed tensors transposed [inner][n_s]: MODE 0: K^T;  MODE 1: Q^T, dO^T
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         const int q = j * 4 + wave;
         const int d = 8 * q + lrow;
         const int c0 = s0 + ((slot ^ ((d >> 1) & 7)) << 3);
-        const bool ok = d < HD && c0 < p.n_s;                // n_s % 8 == 0: a 16-byte chunk is wholly inside or wholly outside
+        const bool ok = d < HD && c0 < p.n_z;                // n_z % 8 == 0: a 16-byte chunk is wholly inside or wholly outside (columns >= n_s: zero padding)
         dma(ok ? z1b + (long)d * p.z_ld + c0 : zero, st + 2 * PANEL + q * 512);
         if constexpr (MODE == 1) dma(ok ? z2b + (long)d * p.z_ld + c0 : zero, st + 3 * PANEL + q * 512);
       }
@@ -152,6 +155,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       }
     }
     const bool ragged = s0 + KV > p.n_s;
+    if constexpr (MODE != 1) {
+      if (p.extra != nullptr && r_ok) {
+        // the guidance loss reads the probabilities themselves: d loss / d P joins dP (same (query, key) element; fp32 rows of this lane's query)
+        const float* ex = p.extra + (((long)b * p.heads + h) * p.n_r + rrow) * p.e_ld;
+#pragma unroll
+        for (int kvt = 0; kvt < 2; ++kvt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int sidx = s0 + kvt * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+            if (sidx < p.n_s) s2[kvt][r] += ex[sidx];
+          }
+      }
+    }
     if constexpr (MODE == 2) {
       // online statistics over this lane half's keys of the tile (register r of tile kvt = streamed row kvt*32 + 16 (r >> 3) + 8 hi + (r & 7))
       float tm = -INFINITY;
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
           float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[kvt][r], p.scale_log2, -lse8[j]));
           if (ragged && s0 + kvt * 32 + 16 * cc + 8 * hi + j >= p.n_s) pe = 0.f;
           pf[j] = from_f32<T>(pe);
-          dsf[j] = from_f32<T>(pe * (s2[kvt][r] - d8[j]) * p.scale);
+          dsf[j] = from_f32<T>(pe * (s2[kvt][r] - d8[j]) * p.ds_scale);
         }
 #pragma unroll
         for (int t2 = 0; t2 < DT; ++t2) {
@@ -270,7 +286,8 @@ void launch_bwd(const AttnBwdParams& p, int batch, hipStream_t st) {
 template <typename T>
 int run_bwd(const tg_attn_bwd_desc* d, hipStream_t st) {
   AttnBwdParams p{};
-  p.heads = d->heads; p.hd = d->head_dim; p.n_r = d->n; p.n_s = d->n; p.n_rblk = (d->n + 127) / 128;
+  p.heads = d->heads; p.hd = d->head_dim; p.n_r = d->n; p.n_s = d->n; p.n_z = d->n; p.n_rblk = (d->n + 127) / 128;
+  p.extra = nullptr; p.e_ld = 0; p.ds_scale = d->scale;
   p.r_ld = p.s_ld = p.o_ld = d->ld; p.r_bs = p.s_bs = p.o_bs = d->bs;
   p.z_ld = d->t_ld; p.z_bs = d->t_bs;
   p.stats = d->stats;
@@ -290,7 +307,42 @@ int run_bwd(const tg_attn_bwd_desc* d, hipStream_t st) {
   return TG_OK;
 }
 
+// cross-attention: the keys / values are constants of the conditioning — only dQ, over a short key set, optionally with the guidance term on the probabilities
+template <typename T>
+int run_bwd_cross(const tg_attn_bwd_cross_desc* d, hipStream_t st) {
+  AttnBwdParams p{};
+  p.heads = d->heads; p.hd = d->head_dim; p.n_r = d->n_q; p.n_s = d->n_k; p.n_z = (d->n_k + 7) & ~7; p.n_rblk = (d->n_q + 127) / 128;
+  p.r_ld = p.o_ld = d->q_ld; p.r_bs = p.o_bs = d->q_bs;
+  p.s_ld = d->k_ld; p.s_bs = d->k_bs;
+  p.z_ld = d->t_ld; p.z_bs = d->t_bs;
+  p.stats = d->stats;
+  p.extra = d->extra; p.e_ld = d->extra_ld;
+  p.scale = d->scale; p.scale_log2 = d->scale * 1.4426950408889634f; p.ds_scale = d->ds_scale;
+  p.r1 = d->q; p.r2 = d->dout; p.s1 = d->k; p.s2 = d->v; p.z1 = d->kt; p.z2 = d->kt;
+  p.out1 = d->dq; p.out2 = nullptr;
+  launch_bwd<T, 2>(p, d->batch, st);
+  TG_LAUNCH_CHECK();
+  launch_bwd<T, 0>(p, d->batch, st);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
 }  // namespace
+
+extern "C" int tg_attention_bwd_cross(const tg_attn_bwd_cross_desc* d, void* stream) {
+  TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_attention_bwd_cross: null descriptor");
+  TG_CHECK(d->dtype == TG_BF16 || d->dtype == TG_F16, TG_ERR_ARG, "tg_attention_bwd_cross: bad dtype");
+  TG_CHECK(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->n_k > 0, TG_ERR_ARG, "tg_attention_bwd_cross: empty problem");
+  TG_CHECK(d->head_dim > 0 && d->head_dim % 8 == 0 && d->head_dim <= 64, TG_ERR_UNSUPPORTED,
+           "tg_attention_bwd_cross: head_dim %d unsupported (multiple of 8, <= 64)", d->head_dim);
+  TG_CHECK(d->q && d->dout && d->k && d->v && d->kt && d->stats && d->dq, TG_ERR_ARG, "tg_attention_bwd_cross: null pointer");
+  TG_CHECK(d->q_ld % 8 == 0 && d->k_ld % 8 == 0 && d->t_ld % 8 == 0 && d->t_ld >= ((d->n_k + 7) & ~7), TG_ERR_ARG,
+           "tg_attention_bwd_cross: pitches must keep 16-byte alignment; the transposed keys are zero-padded to a multiple of 8 columns");
+  TG_CHECK(d->extra == nullptr || d->extra_ld >= d->n_k, TG_ERR_ARG, "tg_attention_bwd_cross: extra rows shorter than the key set");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return run_bwd_cross<bf16_t>(d, st);
+  return run_bwd_cross<f16_t>(d, st);
+}
 
 extern "C" int tg_attention_bwd(const tg_attn_bwd_desc* d, void* stream) {
   TG_CHECK(d != nullptr, TG_ERR_ARG, "tg_attention_bwd: null descriptor");

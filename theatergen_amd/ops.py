@@ -560,6 +560,31 @@ def attention_bwd(q, k, v, dout, batch, n, heads, head_dim, scale):
     return dq, dk, dv
 
 
+def attention_bwd_cross(q, dout, k, v, batch, n_q, n_k, heads, head_dim, scale, ds_scale, extra=None):
+    """dQ of one softmax segment of cross-attention (constant K / V): q, dout [batch * n_q, inner], k, v [batch * n_k, inner];
+    ``extra`` fp32 [batch, heads, n_q, n_k] = d loss / d P or None.  Two launches (row statistics, dQ) for all (item, head) pairs."""
+    _need_cuda(q)
+    inner = heads * head_dim
+    lp = (n_k + 7) // 8 * 8
+    kt = torch.zeros((batch, inner, lp), dtype=q.dtype, device=q.device)
+    kt[:, :, :n_k] = k.reshape(batch, n_k, inner).transpose(1, 2)
+    stats = torch.empty((batch, heads, n_q, 2), dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q)
+    d = _lib.AttnBwdCrossDesc()
+    d.dtype, d.batch, d.heads, d.head_dim, d.n_q, d.n_k = _dt(q), batch, heads, head_dim, n_q, n_k
+    d.q, d.dout, d.q_ld, d.q_bs = _ptr(q), _ptr(dout), inner, n_q * inner
+    d.k, d.v, d.k_ld, d.k_bs = _ptr(k), _ptr(v), inner, n_k * inner
+    d.kt, d.t_ld, d.t_bs = _ptr(kt), lp, inner * lp
+    if extra is not None:
+        if extra.dtype != torch.float32 or extra.shape != (batch, heads, n_q, n_k) or not extra.is_contiguous():
+            raise RuntimeError("attention_bwd_cross: extra must be a contiguous fp32 [batch, heads, n_q, n_k] tensor")
+        d.extra, d.extra_ld = _ptr(extra), n_k
+    d.stats, d.dq = _ptr(stats), _ptr(dq)
+    d.scale, d.ds_scale = float(scale), float(ds_scale)
+    _lib.check(_lib.lib().tg_attention_bwd_cross(C.byref(d), _stream()))
+    return dq
+
+
 def transpose(src, batch, rows, cols, out=None):
     """out[b, c, r] = src[b, r, c]"""
     if out is None:
