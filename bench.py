@@ -566,7 +566,7 @@ def bench_sd21_editing(args):
             gig.run(lat1)
         torch.cuda.synchronize()
         guide_graph_ms = (time.perf_counter() - t1) / 3 * 1e3
-        guide_graph_note = "GraphedInputGrad, per-head chains on 8 forked streams; " + (
+        guide_graph_note = "GraphedInputGrad (per-head chains, where a layer still has them, on 8 forked streams); " + (
             "bit-identical to the eager iteration" if torch.equal(gg2, gg) and torch.equal(gl2, gl) else
             f"max |graph - eager| = {float((gg2 - gg).abs().max()):.3e}")
         del gig
@@ -591,7 +591,7 @@ def bench_sd21_editing(args):
         "latent_backward_guidance_iteration_graph_ms": None if guide_graph_ms is None else round(guide_graph_ms, 1),
         "latent_backward_guidance_graph_note": guide_graph_note,
         "latent_backward_guidance_note": "one iteration = cond-only UNet forward to the last guidance key + compute_ca_lossv3 + d loss / d latents "
-                                         "(explicit reverse pass, materialised attention probabilities per head: 9216-key self-attention rows at level 0); "
+                                         "(explicit reverse pass; round 5: attention differentiated by recompute kernels, tg_attention_bwd / tg_attention_bwd_cross — no N x N tensor; TG_FLASH_BWD=0 = the materialised per-head path); "
                                          "host wall time, eager; the reference runs up to 5 per step for the first 10 steps (dead code in its shipped flow)",
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": None, "kernel": "whole CFG-batch-2 UNet call incl. attention capture (4.30 TFLOP algorithmic, SURVEY 8(d))",
