@@ -140,6 +140,9 @@ HOT_GATES = [
     ("rc_front_kernel<", 0, 216),                                  # round 4's first version spilled 108 registers (30 % of its launch)
     ("rc_linear_kernel<", 0, 256),                                 # every instance (the UNet launches <T,20,8,2,false,0>, plain / + residual)
     ("skinny_gemm_kernel<", 0, 256),                               # round 5: the CK = 16 / 20 instances spilled 44 .. 164 bytes
+    ("attn_bwd_kernel<", 0, 224),                                  # round 5: reverse pass of attention (statistics / dQ / dK + dV instances: 156 / 198 / 216 VGPRs)
+    ("conv_in_mfma_kernel<", 0, 256),                              # round 5: boundary convs on the matrix cores
+    ("conv_out_mfma_kernel<", 0, 128),
 ]
 
 
