@@ -578,10 +578,12 @@ __global__ __launch_bounds__(256) void conv_out_fast_kernel(const T* x, int batc
 // it, and a wave's 32 pixels x 9 taps x cin / 16 k-steps run as 32 x 32 x 16 MFMAs whose A operand carries the cout <= 8 real rows (the other rows are
 // zero registers — the matrix pipe has cycles to spare here, the LDS pipe does not).  Output: NCHW, 16 consecutive pixels per 64-byte run.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const float* coef, int a_silu, int batch, int cin, int h, int w, const T* weight,
+__global__ __launch_bounds__(512) void conv_out_mfma_kernel(const T* x, const float* coef, int a_silu, int batch, int cin, int h, int w, const T* weight,
                                                             const T* bias, int cout, void* out, int out_f32) {
   typedef typename Vec<T>::v8 V8;
   constexpr int TH = 8, TW = 16, WW = TW + 2, WIN = (TH + 2) * WW;       // 180 window pixels
+  constexpr int NT = 512;      // EIGHT waves stage the window (two per SIMD: one's GroupNorm + SiLU arithmetic — ~70 VALU cycles per element, the staging's
+                               // bound — runs under the other's loads; four waves: 77 us per launch in the replayed step); waves 0 .. 3 then own the 128 pixels
   extern __shared__ __attribute__((aligned(16))) char com_smem[];
   const int K = 9 * cin, ch8 = cin >> 3;
   T* sx = reinterpret_cast<T*>(com_smem);                 // [WIN][cin], swizzled
@@ -592,9 +594,9 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
   const int tile = blockIdx.x;
   const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
   const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
-  for (int i = tid; i < cout * K / 8; i += 256) reinterpret_cast<V8*>(sw)[i] = reinterpret_cast<const V8*>(weight)[i];
+  for (int i = tid; i < cout * K / 8; i += NT) reinterpret_cast<V8*>(sw)[i] = reinterpret_cast<const V8*>(weight)[i];
   if (coef != nullptr) {
-    for (int i = tid; i < 2 * cin; i += 256) sc[i] = coef[(long)b * 2 * cin + i];
+    for (int i = tid; i < 2 * cin; i += NT) sc[i] = coef[(long)b * 2 * cin + i];
     __syncthreads();
   }
   // ---- window: global -> registers (-> GroupNorm + SiLU) -> LDS, NU 16-byte chunks in flight per thread (the staging is latency-bound: 28 chunks per
@@ -602,13 +604,13 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
   constexpr int NU = 7;
   const T* xb = x + (long)b * h * w * cin;
   const int nchunk = WIN * ch8;
-  for (int q0 = tid; q0 < nchunk; q0 += NU * 256) {
+  for (int q0 = tid; q0 < nchunk; q0 += NU * NT) {
     V8 v[NU];
     int wp[NU], c[NU];
     bool ok[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int q = q0 + u * 256;
+      const int q = q0 + u * NT;
       wp[u] = q / ch8; c[u] = q - wp[u] * ch8;
       const int wy = wp[u] / WW, wx = wp[u] - wy * WW;
       const int yy = y0 + wy - 1, xx = x0 + wx - 1;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      if (q0 + u * 256 >= nchunk) continue;
+      if (q0 + u * NT >= nchunk) continue;
       if (coef != nullptr && ok[u]) {
         const float* ca = sc + c[u] * 8;
         const float* cd = sc + cin + c[u] * 8;
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const T* x, const fl
     }
   }
   __syncthreads();
+  if (wave >= 4) return;
   // ---- 32 pixels per wave (tile rows 2 wave, 2 wave + 1) x 9 taps x cin / 16 k-steps
   const int ty = 2 * wave + (l31 >> 4), tx = l31 & 15;
   f32x16 acc;
@@ -844,12 +847,12 @@ static int conv_out_impl(int32_t dtype, const void* x, const float* coef, int32_
       auto k = conv_out_mfma_kernel<bf16_t>;
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)attr;
-      hipLaunchKernelGGL(k, g, dim3(256), lds, st, (const bf16_t*)x, coef, a_silu, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
+      hipLaunchKernelGGL(k, g, dim3(512), lds, st, (const bf16_t*)x, coef, a_silu, batch, cin, h, w, (const bf16_t*)weight, (const bf16_t*)bias, cout, out, out_f32);
     } else {
       auto k = conv_out_mfma_kernel<f16_t>;
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)attr;
-      hipLaunchKernelGGL(k, g, dim3(256), lds, st, (const f16_t*)x, coef, a_silu, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
+      hipLaunchKernelGGL(k, g, dim3(512), lds, st, (const f16_t*)x, coef, a_silu, batch, cin, h, w, (const f16_t*)weight, (const f16_t*)bias, cout, out, out_f32);
     }
     TG_LAUNCH_CHECK();
     return TG_OK;
