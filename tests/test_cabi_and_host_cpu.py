@@ -719,3 +719,32 @@ def test_skinny_pack_layout():
             bfr = x[:, 16 * ks:16 * ks + 16].reshape(32, 2, 8).float()   # [token, hi, j]
             got[:, 32 * nt:32 * nt + 32] += torch.einsum("hrj,thj->tr", a, bfr)
     assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """Every descriptor the ctypes binding mirrors has the C header's size and field offsets (a probe compiled with gcc from include/theatergen_hip.h):
+    a field added on one side only would shift every later argument silently."""
+    import ctypes, os, shutil, subprocess
+    from theatergen_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("tg_gemm_desc", _lib.GemmDesc), ("tg_attn_desc", _lib.AttnDesc), ("tg_attn_bwd_desc", _lib.AttnBwdDesc),
+             ("tg_attn_bwd_cross_desc", _lib.AttnBwdCrossDesc), ("tg_rc_linear_desc", _lib.RcLinearDesc), ("tg_rc_xattn_desc", _lib.RcXattnDesc),
+             ("tg_xq_attn_desc", _lib.XqAttnDesc), ("tg_rc_ff_desc", _lib.RcFfDesc), ("tg_skinny_seg", _lib.SkinnySeg), ("tg_skinny_desc", _lib.SkinnyDesc),
+             ("tg_rc_front_desc", _lib.RcFrontDesc), ("tg_guidance_item", _lib.GuidanceItem), ("tg_guidance_pitem", _lib.GuidancePItem)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/theatergen_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines())
+    for cname, cls in pairs:
+        assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
