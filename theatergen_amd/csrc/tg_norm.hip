@@ -56,23 +56,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
       float s[8], q[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-      // 16 pixels per trip, then 4: independent 16-byte loads in flight per lane.  The launch is 512 blocks (two per CU; more blocks cost the consumers' partial
-      // folds more than they win here) and a lane owns only ~21 pixels of a 64 x 64 map: with four loads per lane ~30 KB are in flight per CU — half of what
-      // 8 TB/s x ~2 us of latency asks for (round 5: measured 4.2 TB/s on a tensor the previous kernel just wrote) — and the lane pays five round trips.
-      // The additions of every accumulator stay in pixel order: bit-identical sums.
+      // 4 pixels per trip: four independent 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
       long pix = p_begin + ty;
-      for (; pix + 15 * (long)p.ry < p_end; pix += 16 * (long)p.ry) {
-        typename Vec<T>::v8 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = gn_load8<T>(p, b, pix + u * (long)p.ry, c * 8);
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float f = to_f32<T>(v[u][j]);
-            s[j] += f; q[j] += f * f;
-          }
-      }
       for (; pix + 3 * (long)p.ry < p_end; pix += 4 * (long)p.ry) {
         typename Vec<T>::v8 v0 = gn_load8<T>(p, b, pix, c * 8);
         typename Vec<T>::v8 v1 = gn_load8<T>(p, b, pix + p.ry, c * 8);
