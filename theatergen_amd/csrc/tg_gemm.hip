@@ -247,6 +247,8 @@ int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, in
 int tg_gemm_t160_launch(const tg_gemm_desc* d, const void* params, int variant, int grid, void* stream);
 // LDS-halo conv (tg_conv_halo.hip): grid = full tiles + tail tiles * K splits
 int tg_conv_halo_launch(const tg_gemm_desc* d, const void* params, int grid, void* stream);
+// ping-pong 256 x 256 tiles (tg_gemm_pp.hip, round 6): 8 waves in two groups one barrier apart, persistent
+int tg_gemm_pp_launch(const tg_gemm_desc* d, const void* params, void* stream);
 namespace {
 
 // Tile geometry of the slab kernel for an out_h x out_w map: patch width *pw and patches per 128-pixel tile *np (tg_conv_slab.hip).
@@ -362,6 +364,38 @@ inline int bt_tile_of(const tg_gemm_desc* d) {
   return -1;
 }
 
+// Ping-pong 256 x 256 tiles (tg_gemm_pp.hip; force_tile 24): plain single-source GEMMs with M, N multiples of 256 and K of 64 whose tile count fills
+// the persistent grid's rounds; linear / activation / GEGLU epilogues, V^T columns on a 64-column boundary, the LayerNorm fold only with precomputed
+// row statistics (ln_rows).  Dev A/B knob TG_PP (bit mask, default 7): 1 = GEGLU launches, 2 = linear / activation launches, 4 = LayerNorm-folded ones.
+inline int pp_mode() {
+  const char* e = getenv("TG_PP");
+  return e ? (int)strtol(e, nullptr, 0) : 7;
+}
+inline bool pp_eligible(const tg_gemm_desc* d) {
+  if (d->mode != 0 || d->a1 != nullptr || d->force_split_k > 1 || d->a_coef != nullptr) return false;
+  if (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0 || d->K < 128) return false;
+  if (d->n_split > 0 && d->n_split % 64 != 0) return false;
+  if (d->ln_u != nullptr && d->ln_rows == nullptr) return false;
+  if (d->geglu && d->n_split > 0) return false;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const long lda = d->lda > 0 ? d->lda : d->c0, ldw = d->ldw > 0 ? d->ldw : d->K;
+  if (!(al16(d->a0) && al16(d->w) && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res)) || lda % 8 != 0 || ldw % 8 != 0 || d->ldc % 8 != 0) return false;
+  if ((d->bvec != nullptr && d->ldbvec % 8 != 0) || (d->res != nullptr && d->ldres % 8 != 0)) return false;
+  if (d->a_rows_per_batch > 0 && d->a_batch_stride % 8 != 0) return false;
+  return true;
+}
+inline bool pp_selected(const tg_gemm_desc* d) {
+  if (d->force_tile == 24) return pp_eligible(d);
+  if (d->force_tile != 0 || !pp_eligible(d)) return false;
+  const int mode = pp_mode();
+  if (d->ln_u != nullptr ? !(mode & 4) : (d->geglu ? !(mode & 1) : !(mode & 2))) return false;
+  const long tiles = (d->M / 256) * (d->N / 256);
+  const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+  // measured (scripts/dev_gemm8.py, profiles/r6_pp_gemm.txt): the ping-pong loop wins where a workgroup's K loop is long enough to pay for its
+  // prologue and the grid fills its rounds; short-K / ragged-N projections stay on the 128 x 160 / 128 x 128 tiles
+  return tiles >= 192 && eff >= 0.74 && d->K >= 640;
+}
+
 // LayerNorm-folded projections on 128 x 160 tiles: 0 = no, 160 = three stages / one workgroup per CU, 161 = two stages / two per CU (tg_gemm_ln.hip)
 inline int ln_t160_of(const tg_gemm_desc* d) {
   // (attn2.to_q only: measured in situ, same box — profiles/r5_t160_findings.md — the q | k | v^T projections, whose V^T third leaves through the
@@ -407,6 +441,8 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
+  if (pp_selected(d)) return tg_gemm_pp_launch(d, &p, st);
+  TG_CHECK(d->force_tile != 24, TG_ERR_UNSUPPORTED, "tg_gemm: force_tile 24 (ping-pong 256 x 256 tiles) needs a plain single-source GEMM with M %% 256 == 0, N %% 256 == 0, K %% 64 == 0 and 16-byte aligned operands");
   if (d->ln_u != nullptr) {
     // LayerNorm-fused projection: whole rows per workgroup (no K split), 128 x 128 tiles — or 128 x 160 where those fill whole rounds — in XCD-chunked order
     const int t160 = ln_t160_of(d);
@@ -483,7 +519,7 @@ int validate(const tg_gemm_desc* d) {
     TG_CHECK(d->N % 64 == 0 && d->n_split <= 0 && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1,
              TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs N %% 64 == 0 (packed a|gate groups) and no other epilogue terms");
     const int ft = d->force_tile;
-    TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6 || ft == 10, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
+    TG_CHECK(ft == 0 || ft == 1 || ft == 5 || ft == 6 || ft == 10 || ft == 24, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs a tile with 64-column wave tiles");
     TG_CHECK(d->M > 64, TG_ERR_ARG, "tg_gemm: GEGLU epilogue needs M > 64");
   }
   const int ctot = d->c0 + (d->a1 ? d->c1 : 0);
@@ -520,7 +556,7 @@ int validate(const tg_gemm_desc* d) {
   if (d->bvec) TG_CHECK(d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bvec needs rows_per_batch");
   if (d->ln_u != nullptr || d->ln_v != nullptr || d->ln_rows != nullptr) {
     TG_CHECK(d->ln_u && d->ln_v, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs both ln_u and ln_v");
-    TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && d->force_tile == 0,
+    TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && (d->force_tile == 0 || d->force_tile == 24),
              TG_ERR_ARG, "tg_gemm: the LayerNorm fold takes a plain single-source GEMM with a linear or GEGLU epilogue (no residual / per-batch vector / split)");
     TG_CHECK(d->K % 32 == 0 && d->N % 8 == 0 && d->ln_eps > 0.f, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs K %% 32 == 0, N %% 8 == 0, eps > 0");
     TG_CHECK((reinterpret_cast<uintptr_t>(d->ln_u) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_v) & 15) == 0 &&
@@ -534,6 +570,13 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
+  if (pp_selected(d)) {
+    if (tile_m) *tile_m = 256;
+    if (tile_n) *tile_n = 256;
+    if (splits) *splits = 1;
+    if (kernel_kind) *kernel_kind = 7;
+    return TG_OK;
+  }
   if (d->ln_u != nullptr) {
     if (tile_m) *tile_m = 128;
     if (tile_n) *tile_n = ln_t160_of(d) ? 160 : 128;
@@ -565,7 +608,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (d->ln_u != nullptr) return 0;
+  if (pp_selected(d) || d->ln_u != nullptr) return 0;
   if (const int sp = slab_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));
