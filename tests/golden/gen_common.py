@@ -244,3 +244,26 @@ def xq_params(ci):
     x = torch.randn(2, N, C, generator=g) * 1.2 + 0.3
     enc = torch.randn(2, 77 + T, ctx, generator=g) * 0.5
     return w, norm, x, enc
+
+
+def mid_image_case(case):
+    """Synthetic inputs of ``prepare_mid_image`` (reference utils/latents.py:48-135): per character a 512 x 512 segmentation mask (an ellipse with a notch,
+    so the bounding box is not the mask), a deterministic RGB image with gradients and a checker pattern (exercises the resampling filter, compresses
+    well) and a normalised layout box.  case 0: two separate characters; 1: overlapping boxes (the uint8 wrap of the summed masks); 2: a box that leaves
+    the canvas (destination clipping) + a third small character."""
+    import numpy as np
+    yy, xx = np.mgrid[0:512, 0:512]
+    specs = {
+        0: [((150, 200), (90, 140), [40 / 512, 150 / 512, 230 / 512, 450 / 512]), ((360, 260), (70, 170), [280 / 512, 150 / 512, 470 / 512, 450 / 512])],
+        1: [((200, 250), (120, 160), [0.15, 0.2, 0.6, 0.9]), ((300, 260), (110, 150), [0.4, 0.25, 0.85, 0.95])],
+        2: [((256, 256), (200, 120), [0.55, 0.5, 1.1, 0.95]), ((120, 140), (60, 90), [0.05, 0.05, 0.3, 0.45]), ((400, 100), (40, 40), [0.7, 0.05, 0.95, 0.3])],
+    }[case]
+    masks, images, boxes = [], [], []
+    for k, ((cx, cy), (rx, ry), box) in enumerate(specs):
+        m = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+        m &= ~((xx > cx + rx // 3) & (yy < cy - ry // 2))           # notch
+        masks.append(torch.from_numpy(m))
+        img = np.stack([(xx * 3 + yy * 5 + 40 * c + 17 * ((xx // 16 + yy // 16 + k) % 2) + 29 * k) % 256 for c in range(3)], axis=-1).astype(np.uint8)
+        images.append(img)
+        boxes.append(box)
+    return masks, images, boxes

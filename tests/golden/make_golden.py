@@ -336,6 +336,47 @@ def gen_geometry_latents(ref, out):
     out["lat.compose_checksum"] = np.array([float(comp.double().sum()), float(comp.double().abs().sum())])
 
 
+def gen_mid_image(ref, out):
+    """``prepare_mid_image`` and ``compose_latents_with_alignment`` of the imported reference (utils/latents.py:48-135, 242-255) on the synthetic
+    characters of ``gen_common.mid_image_case``.  The reference saves two PNGs under ./visualization: run in a scratch directory."""
+    import tempfile
+    from PIL import Image
+    L = ref.latents
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "visualization"))
+        os.chdir(tmp)
+        try:
+            for case in (0, 1, 2):
+                masks, images, boxes = gc.mid_image_case(case)
+                mask_img, canvas = L.prepare_mid_image("1.5", 0, masks, [Image.fromarray(i) for i in images], boxes)
+                out[f"mid{case}.mask"] = np.array(mask_img)
+                out[f"mid{case}.image"] = np.array(canvas)
+            # the whole hand-off: align the 51-step latents / 64 x 64 masks to the boxes, paste, compose
+            masks, images, boxes = gc.mid_image_case(0)
+            g = torch.Generator().manual_seed(910)
+            masks64 = [m.view(64, 8, 64, 8).any(3).any(1) for m in masks]
+            lat_all = [torch.randn(51, 1, 4, 64, 64, generator=g) for _ in masks]
+            bg = torch.randn(1, 4, 64, 64, generator=g)
+
+            class _Cfg: in_channels = 4
+            class _Unet: config = _Cfg(); dtype = torch.float32
+            class _Sched: init_noise_sigma = 1.0
+            class _Pipe: unet = _Unet(); scheduler = _Sched()
+            class _Adapter: pipe = _Pipe()
+            comp, fgidx, inp_mask, inp_img = L.compose_latents_with_alignment(
+                "1.5", _Adapter(), 0, masks, [Image.fromarray(i) for i in images], None, lat_all, masks64, 50, 1, 512, 512,
+                align_with_overall_bboxes=True, overall_bboxes=[[boxes[0]], [boxes[1]]], horizontal_shift_only=False, latents_bg=bg)
+            out["cwa.fgidx"] = fgidx.numpy()
+            out["cwa.step0"] = comp[0].numpy()
+            out["cwa.step23"] = comp[23].numpy()
+            out["cwa.checksum"] = np.array([float(comp.double().sum()), float(comp.double().abs().sum())])
+            out["cwa.mask"] = np.array(inp_mask)
+            out["cwa.image"] = np.array(inp_img)
+        finally:
+            os.chdir(cwd)
+
+
 def gen_block(ref, out):
     """SD-1.5 first-level geometry composed from the reference's parts.  ``BasicTransformerBlock.forward`` / ``Transformer2DModel.forward``
     cannot execute as shipped (models/attention_processor.py:161 hands ``object_positions`` to processors that do not take it: TypeError), so
@@ -417,7 +458,7 @@ def main():
     ref = load_reference()
     torch.set_num_threads(8)
     jobs = {"attn": gen_attention, "attn_branches": gen_attention_branches, "resampler": gen_resampler, "ff_geglu": gen_ff, "guidance": gen_guidance,
-            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half, "block": gen_block, "xq": gen_xq}
+            "geometry_latents": gen_geometry_latents, "imageproj": gen_imageproj, "latents_half": gen_latents_half, "block": gen_block, "xq": gen_xq, "mid_image": gen_mid_image}
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

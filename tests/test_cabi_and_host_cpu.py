@@ -103,6 +103,32 @@ def test_geometry_host_functions_vs_reference_golden():
     assert np.array_equal(get_fast_schedule(ts, 49, 2).numpy(), gold["sched.fast_49_2"])
 
 
+def test_prepare_mid_image_vs_reference_golden(tmp_path, monkeypatch):
+    """the stage-1 -> stage-2 pixel paste (reference utils/latents.py:48-135; host-side integer work, so it runs here): bit-exact mask and canvas for two
+    separate characters, overlapping boxes (the reference's uint8 mask sum wraps) and a box that leaves the canvas; the two PNGs land where the reference
+    writes them; an empty mask fails the way the reference does"""
+    from PIL import Image
+    from tests.golden import gen_common as gc
+    from theatergen_amd import latents as L
+    gold = _load("mid_image")
+    monkeypatch.chdir(tmp_path)
+    for case in (0, 1, 2):
+        masks, images, boxes = gc.mid_image_case(case)
+        mask_img, canvas = L.prepare_mid_image("1.5", 3, masks, [Image.fromarray(i) for i in images], boxes)
+        assert mask_img.mode == "L" and canvas.mode == "RGB" and canvas.size == (512, 512)
+        assert np.array_equal(np.array(mask_img), gold[f"mid{case}.mask"]), f"case {case}: mask"
+        assert np.array_equal(np.array(canvas), gold[f"mid{case}.image"]), f"case {case}: canvas"
+    assert (gold["mid1.mask"] == 1).any(), "case 1 must exercise the wrapped overlap (mask value 1)"
+    assert (tmp_path / "visualization" / "3vis_image.png").exists() and (tmp_path / "visualization" / "3vis_mask.png").exists()
+    # numpy images work like PIL images (theatergen.py:177 appends arrays of the VAE output); the side effect can be switched off
+    monkeypatch.setattr(L, "MID_IMAGE_DIR", None)
+    masks, images, boxes = gc.mid_image_case(0)
+    mask_img, canvas = L.prepare_mid_image("1.5", 9, masks, images, boxes)
+    assert np.array_equal(np.array(canvas), gold["mid0.image"]) and not (tmp_path / "visualization" / "9vis_image.png").exists()
+    with pytest.raises(TypeError):
+        L.prepare_mid_image("1.5", 0, [torch.zeros(512, 512, dtype=torch.bool)], images[:1], boxes[:1])
+
+
 def test_phrase_indices_vs_reference_golden():
     from tests.golden.gen_common import FakeTokenizer
     from theatergen_amd import guidance as G

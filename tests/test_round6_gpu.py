@@ -140,3 +140,40 @@ def test_pp_gemm_is_what_the_planner_picks_for_the_feedforward_shapes():
             assert kind == want, (M, N, K, kind)
         else:
             assert kind != 7, (M, N, K, kind)
+
+
+def test_compose_latents_with_alignment_vs_reference_golden(tmp_path, monkeypatch):
+    """the stage-1 -> stage-2 hand-off with the reference's signature (utils/latents.py:242-255 <- theatergen.py:415-423): shift (tg_shift) + pixel paste
+    (host) + masked composition (tg_masked_compose) against outputs of the imported reference (tests/golden/mid_image.npz)"""
+    import os
+    from PIL import Image
+    from tests.golden import gen_common as gc
+    from theatergen_amd import latents as L
+    dev = _dev()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "mid_image.npz"))
+    monkeypatch.chdir(tmp_path)
+    masks, images, boxes = gc.mid_image_case(0)
+    g = torch.Generator().manual_seed(910)
+    masks64 = [m.view(64, 8, 64, 8).any(3).any(1) for m in masks]
+    lat_all = [torch.randn(51, 1, 4, 64, 64, generator=g).to(dev) for _ in masks]
+    bg = torch.randn(1, 4, 64, 64, generator=g).to(dev)
+
+    class _Cfg:
+        in_channels = 4
+
+    class _Unet:
+        config = _Cfg()
+        dtype = torch.float32
+
+    ad = type("A", (), {"pipe": type("P", (), {"unet": _Unet(), "scheduler": type("Sc", (), {"init_noise_sigma": 1.0})()})()})()
+    comp, fgidx, inp_mask, inp_img = L.compose_latents_with_alignment(
+        "1.5", ad, 0, masks, [Image.fromarray(i) for i in images], None, lat_all, masks64, 50, 1, 512, 512,
+        align_with_overall_bboxes=True, overall_bboxes=[[boxes[0]], [boxes[1]]], horizontal_shift_only=False, latents_bg=bg)
+    assert np.array_equal(fgidx.cpu().numpy(), gold["cwa.fgidx"])
+    assert torch.equal(comp[0].cpu(), torch.from_numpy(gold["cwa.step0"])) and torch.equal(comp[23].cpu(), torch.from_numpy(gold["cwa.step23"]))
+    np.testing.assert_allclose([float(comp.double().sum()), float(comp.double().abs().sum())], gold["cwa.checksum"], rtol=1e-12)
+    assert np.array_equal(np.array(inp_mask), gold["cwa.mask"]) and np.array_equal(np.array(inp_img), gold["cwa.image"])
+    # the reference has no value to return when nothing is aligned (utils/latents.py:250-255): the caller's skip-the-turn policy sees a RuntimeError
+    with pytest.raises(RuntimeError):
+        L.compose_latents_with_alignment("1.5", ad, 0, masks, images, None, lat_all, masks64, 50, 1, 512, 512, align_with_overall_bboxes=False,
+                                         overall_bboxes=[[boxes[0]], [boxes[1]]], latents_bg=bg)
