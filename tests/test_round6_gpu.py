@@ -1,6 +1,7 @@
 """GPU, round 6: the ping-pong 256 x 256 GEMM (csrc/tg_gemm_pp.hip, tg_gemm force_tile 24 / planner kind 7) against a plain PyTorch fp32 reference of
 the same op, through the C ABI; the drop-in surface closed this round (compose_latents_with_alignment, the reference-signature stage loops)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -177,3 +178,200 @@ def test_compose_latents_with_alignment_vs_reference_golden(tmp_path, monkeypatc
     with pytest.raises(RuntimeError):
         L.compose_latents_with_alignment("1.5", ad, 0, masks, images, None, lat_all, masks64, 50, 1, 512, 512, align_with_overall_bboxes=False,
                                          overall_bboxes=[[boxes[0]], [boxes[1]]], latents_bg=bg)
+
+
+# ---- the reference's two stage functions with their own signatures, on the engine ------------------------------------------------
+class _FakeTextPipe:
+    """what ``generate_semantic_guidance`` / ``final_image_generation`` read from ``adapter.pipe`` besides the UNet: ``encode_prompt`` (seeded by the
+    prompt strings, records them), ``vae``, ``scheduler``, ``vae_scale_factor``"""
+
+    def __init__(self, unet, vae, ctx):
+        from theatergen_amd.scheduler import DDIMScheduler
+        self.unet, self.vae, self.ctx = unet, vae, ctx
+        self.scheduler = DDIMScheduler()
+        self.vae_scale_factor = 8
+        self.controlnet = None
+        self.prompts = []
+
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt=1, do_classifier_free_guidance=True, negative_prompt=None, **kw):
+        self.prompts.append((prompt, negative_prompt))
+
+        def emb(s):
+            g = torch.Generator().manual_seed(sum(map(ord, s)) % 100003)
+            return (torch.randn(1, 77, self.ctx, generator=g) * 0.5).to(device=self.unet.device, dtype=self.unet.dtype)
+        return emb(prompt), emb(negative_prompt)
+
+
+def _image_tokens_of(pil_image, ctx, dev, dtype):
+    """stand-in for CLIP + image projection: tokens seeded by the image's pixels (cond) / fixed (uncond)"""
+    seed = int(np.asarray(pil_image.convert("RGB").resize((8, 8))).astype(np.int64).sum() % 100003)
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(1, 4, ctx, generator=g) * 0.5).to(dev, dtype), (torch.randn(1, 4, ctx, generator=torch.Generator().manual_seed(5)) * 0.5).to(dev, dtype)
+
+
+def test_generate_semantic_guidance_reference_signature_vs_oracle_loop(tmp_path, monkeypatch):
+    """theatergen.py:108-135 calls ``pipelines.generate_semantic_guidance(task, fg_seed_now, basever, ip_prompt, database_path, idx, adapter, model_dict,
+    input_latents, input_embeddings, num_inference_steps, bboxes, phrases, object_positions, guidance_scale=..., return_saved_cross_attn=True,
+    return_box_vis=True, save_all_latents=True, ...)`` and unpacks five values: the same call on the engine, against the free-running oracle loop —
+    first appearance of a character (placeholder image, IP scale 0, PNG written), its reuse (PNG read, scale 0.4), the fast schedule."""
+    from PIL import Image
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from oracle import vae as ov
+    from tests.test_hotpath_gpu import DEV, _build, _build_vae, close, net_tol
+    from theatergen_amd import config, pipelines
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.schedule import get_fast_schedule
+    from theatergen_amd.vae import tiny_vae_config
+    dtype = torch.bfloat16
+    cfg = config.tiny()
+    unet, sd_r = _build(cfg, dtype)
+    vcfg = tiny_vae_config()
+    vae, vsd = _build_vae(vcfg, dtype)
+    pipe = _FakeTextPipe(unet, vae, cfg.cross_attention_dim)
+    ad = IPAdapter(pipe, None, None, DEV, num_tokens=4)
+    monkeypatch.setattr(ad, "get_image_embeds", lambda pil_image=None, clip_image_embeds=None: _image_tokens_of(pil_image, cfg.cross_attention_dim, DEV, dtype))
+    monkeypatch.chdir(tmp_path)
+    Image.fromarray(np.full((32, 32, 3), 90, np.uint8)).save("model.png")
+    db = str(tmp_path) + "/db_"
+    g = torch.Generator().manual_seed(31)
+    steps = 4
+    lat = torch.randn(1, 4, 16, 16, generator=g).to(dtype)
+
+    def oracle(enc, scale, timesteps=None, n=steps):
+        osch = oddim.DDIMSchedule()
+        osch.set_timesteps(n)
+        ref, rows = lat.float().clone(), [lat.float().clone()]
+        for t in (osch.timesteps if timesteps is None else timesteps).tolist():
+            npred = ou.unet_forward(cfg, sd_r, torch.cat([ref] * 2).to(dtype).float(), t, enc.float().cpu(), ip_scale=scale)
+            ref = oddim.step_epilogue(osch, npred, t, ref, 7.5)
+            rows.append(ref.clone())
+        return ref, torch.stack(rows)
+
+    def enc_of(prompt, pil):
+        pos, neg = pipe.encode_prompt(prompt, negative_prompt=pipelines.SINGLE_OBJECT_NEGATIVE_PROMPT)
+        img, unc = _image_tokens_of(pil, cfg.cross_attention_dim, DEV, dtype)
+        return torch.cat([torch.cat([neg, unc], 1), torch.cat([pos, img], 1)], 0)
+
+    kw = dict(guidance_scale=7.5, return_cross_attn=False, return_saved_cross_attn=True, semantic_guidance_kwargs=None, saved_cross_attn_keys=[("down", 2, 1, 0)],
+              return_cond_ca_only=True, return_token_ca_only=3, offload_cross_attn_to_cpu=False, return_box_vis=True, save_all_latents=True,
+              dynamic_num_inference_steps=True, use_adapter=True, obj_id=7)
+    # (1) first appearance: no db_7.png -> placeholder, scale 0, the decoded image becomes the character's reference
+    out = pipelines.generate_semantic_guidance("story", 123, "1.5", "a red fox", db, 0, ad, None, lat.to(DEV), None, steps, None, None, None, **kw)
+    assert len(out) == 5
+    latents, image, saved, image2, latents_all = out
+    assert pipe.prompts[-1] == ("full-body picture of a red fox", pipelines.SINGLE_OBJECT_NEGATIVE_PROMPT)
+    assert saved == [{}] * steps and image2 is image and image.size == (128, 128)
+    assert latents_all.shape == (steps + 1, 1, 4, 16, 16) and latents_all.device.type == "cpu" and latents_all.dtype == dtype and latents.dtype == dtype
+    assert os.path.exists(db + "7.png"), "the first image of a character is written to the database (models/pipelines.py:476-477)"
+    ref, rows = oracle(enc_of("full-body picture of a red fox", Image.open("model.png")), 0.0)
+    close(latents, ref, net_tol(dtype), "generate_semantic_guidance: first appearance (scale 0)")
+    close(latents_all, rows, net_tol(dtype), "generate_semantic_guidance: latents_all")
+    dec = ov.decode(vcfg, vsd, latents.float().cpu())
+    got_img = torch.from_numpy(np.asarray(image).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    close(got_img, (dec / 2 + 0.5).clamp(0, 1), 8e-2, "generate_semantic_guidance: decoded image")
+    # (2) reuse: db_7.png exists -> its tokens at scale 0.4; editing prompt; latents stay on the device when asked
+    out2 = pipelines.generate_semantic_guidance("editing", 123, "1.5", "a red fox", db, 0, ad, None, lat.to(DEV), None, steps, None, None, None,
+                                                **{**kw, "return_saved_cross_attn": False, "return_box_vis": False, "offload_latents_to_cpu": False})
+    assert len(out2) == 3 and out2[2].device.type == "cuda"
+    assert pipe.prompts[-1][0] == "single object, a red fox"
+    ref2, _ = oracle(enc_of("single object, a red fox", Image.open(db + "7.png")), 0.4)
+    close(out2[0], ref2, net_tol(dtype), "generate_semantic_guidance: reuse (scale 0.4)")
+    differs = not torch.equal(out2[0], latents)
+    assert differs
+    # (3) the fast schedule (utils/schedule.py:4-8 at models/pipelines.py:383-384)
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(6)
+    fast = get_fast_schedule(osch.timesteps, 2, 2)
+    out3 = pipelines.generate_semantic_guidance("story", 123, "1.5", "a red fox", db, 0, ad, None, lat.to(DEV), None, 6, None, None, None,
+                                                **{**kw, "fast_after_steps": 2, "fast_rate": 2})
+    assert out3[4].shape[0] == len(fast) + 1
+    ref3, _ = oracle(enc_of("full-body picture of a red fox", Image.open(db + "7.png")), 0.4, timesteps=fast, n=6)
+    close(out3[0], ref3, net_tol(dtype), "generate_semantic_guidance: fast schedule")
+    # refusals
+    with pytest.raises(NotImplementedError):
+        pipelines.generate_semantic_guidance("story", 1, "xl", "x", db, 0, ad, None, lat.to(DEV), None, steps, None, None, None, obj_id=7)
+    with pytest.raises(RuntimeError):
+        pipelines.generate_semantic_guidance("story", 1, "1.5", "x", db, 0, ad, None, lat.to(DEV), None, steps, None, None, None)
+
+
+def test_final_image_generation_reference_signature_vs_oracle_loop(tmp_path, monkeypatch):
+    """theatergen.py:448-484 calls ``pipelines.final_image_generation(basever, processor, controlnetpipe, tpipe, overall_prompt, overall_negative_prompt,
+    bg_prompt, single_obj_img_list, objects, repeat_ind, height, width, bg_seed, inp_mask, inp_img, adapter, model_dict, composed_latents, frozen_mask,
+    bg_input_embeddings, overall_input_embeddings, num_inference_steps, frozen_steps, ...)``: same call on the engine — the frozen latents it writes into
+    ``latents_all`` (VAE encoder + re-noising from the device generator), the mask from ``inp_mask``, then ControlNet + UNet + frozen-mask loop vs the oracle."""
+    from PIL import Image
+    from oracle import controlnet as oc
+    from oracle import ddim as oddim
+    from oracle import unet as ou
+    from oracle import vae as ov
+    from tests.test_hotpath_gpu import DEV, _build, _build_controlnet, _build_vae_full, close, net_tol
+    from theatergen_amd import config, pipelines
+    from theatergen_amd.ip_adapter import IPAdapter
+    from theatergen_amd.vae import tiny_vae_config
+    dtype = torch.bfloat16
+    cfg = config.tiny()
+    unet, sd_u = _build(cfg, dtype)
+    net, sd_c = _build_controlnet(cfg, dtype)
+    vcfg = tiny_vae_config()
+    vae, vsd = _build_vae_full(vcfg, dtype)
+    pipe = _FakeTextPipe(unet, vae, cfg.cross_attention_dim)
+    ad = IPAdapter(pipe, None, None, DEV, num_tokens=4)
+    monkeypatch.setattr(ad, "get_image_embeds", lambda pil_image=None, clip_image_embeds=None: _image_tokens_of(pil_image, cfg.cross_attention_dim, DEV, dtype))
+    cnpipe = type("CNPipe", (), {"controlnet": net})()
+    H = W = 128
+    steps, frozen_steps, bg_seed = 4, 3, 11
+    g = torch.Generator().manual_seed(41)
+    pasted = Image.fromarray((torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy())
+    m512 = np.full((H, W), 255, np.uint8)
+    m512[40:100, 24:80] = 0                                   # a character was pasted here
+    inp_mask = Image.fromarray(m512, mode="L")
+    char_img = Image.fromarray(np.full((32, 32, 3), 140, np.uint8))
+    text = (torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.5).to(DEV, dtype)
+    latents_all = torch.zeros(steps + 1, 1, 4, H // 8, W // 8, device=DEV)
+    calls = []
+
+    def processor(arr):                                       # the lineart detector's place: ndarray in, PIL out
+        calls.append(arr.shape)
+        return Image.fromarray(255 - arr)
+    latents, images = pipelines.final_image_generation("1.5", processor, cnpipe, 1, "two foxes in a park", "lowres", "a park", [char_img], None, 0, H, W,
+                                                       bg_seed, inp_mask, pasted, ad, None, latents_all, torch.ones(16, 16), None, (text, text[:1], text[1:]),
+                                                       steps, frozen_steps, guidance_scale=7.5)
+    assert calls == [(H, W, 3)] and images.shape == (1, H, W, 3) and images.dtype == np.uint8 and latents.shape == (1, 4, 16, 16)
+    assert pipe.prompts[-1] == ("two foxes in a park", "lowres")
+    assert float(ad.pipe.unet.attn_processors[[k for k in ad.pipe.unet.attn_processors if "attn2" in k][0]].scale) == pytest.approx(0.1)
+    # the device generator's draws, in the reference's order (:625-632): posterior noise, re-noising noise, background latents
+    g2 = torch.Generator(DEV).manual_seed(bg_seed)
+    n1 = torch.randn((1, 4, 16, 16), generator=g2, device=DEV, dtype=dtype)
+    n2 = torch.randn((1, 4, 16, 16), generator=g2, device=DEV, dtype=dtype)
+    bg = torch.randn((1, 4, 16, 16), generator=g2, device=DEV, dtype=dtype)
+    same = torch.equal(latents_all[0], bg.float())
+    assert same, "latents_all[0] = fresh background noise, third draw of the bg_seed generator"
+    img = (2.0 * torch.from_numpy(np.asarray(pasted).astype(np.float32) / 255.0)[None].permute(0, 3, 1, 2) - 1.0).to(dtype).float()
+    mom = ov.encode_moments(vcfg, vsd, img)
+    mean, logvar = mom[:, :4], mom[:, 4:].clamp(-30, 20)
+    init = vcfg.scaling_factor * (mean + torch.exp(0.5 * logvar) * n1.float().cpu())
+    osch = oddim.DDIMSchedule()
+    osch.set_timesteps(steps)
+    want_rows = torch.stack([osch.add_noise(init, n2.float().cpu(), t) for t in osch.timesteps.tolist()])
+    close(latents_all[1:].cpu(), want_rows.reshape(steps, 1, 4, 16, 16), net_tol(dtype), "final_image_generation: frozen latents = VAE-encoded pasted image re-noised at every timestep")
+    # the loop: the oracle starts from what the function wrote (its own frozen rows) so that only the loop is compared
+    mask = torch.from_numpy(1 - (np.array(inp_mask.resize((16, 16)).convert("L")).astype(np.float32) / 255.0 > 0).astype(np.float32))
+    ip_rows = torch.cat([torch.cat([pipe.encode_prompt("two foxes in a park", negative_prompt="lowres")[1], _image_tokens_of(char_img, cfg.cross_attention_dim, DEV, dtype)[1]], 1),
+                         torch.cat([pipe.encode_prompt("two foxes in a park", negative_prompt="lowres")[0], _image_tokens_of(char_img, cfg.cross_attention_dim, DEV, dtype)[0]], 1)], 0)
+    cond = torch.from_numpy(np.asarray(Image.fromarray(255 - np.asarray(pasted)).resize((W, H), resample=Image.LANCZOS)).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    cond = torch.cat([cond] * 2).to(dtype).float()
+    frozen = latents_all.cpu()
+    ref = frozen[0].clone()
+    for i, t in enumerate(osch.timesteps.tolist()):
+        mi = torch.cat([ref] * 2).to(dtype).float()
+        rd, rm = oc.controlnet_forward(cfg, sd_c, mi, t, text.float().cpu(), cond, 1.0, cross_mode="cn")
+        rd = [d.to(dtype).float() for d in rd]
+        npred = ou.unet_forward(cfg, sd_u, mi, t, ip_rows.float().cpu(), ip_scale=0.1, down_block_additional_residuals=rd, mid_block_additional_residual=rm.to(dtype).float())
+        ref = oddim.step_epilogue(osch, npred, t, ref, 7.5, frozen[i + 1] if i < frozen_steps else None, mask)
+    close(latents, ref, net_tol(dtype), "final_image_generation: ControlNet + UNet + frozen-mask loop")
+    dec = ov.decode(vcfg, vsd, latents.float().cpu(), scaling_factor=0.18215)
+    close(torch.from_numpy(images.astype(np.float32) / 255.0).permute(0, 3, 1, 2), (dec / 2 + 0.5).clamp(0, 1), 8e-2, "final_image_generation: decoded image")
+    with pytest.raises(TypeError):
+        pipelines.final_image_generation("1.5", processor, type("P", (), {"controlnet": object()})(), 1, "p", "n", "b", [char_img], None, 0, H, W, bg_seed, inp_mask,
+                                         pasted, ad, None, latents_all, None, None, (text, text[:1], text[1:]), steps, frozen_steps)

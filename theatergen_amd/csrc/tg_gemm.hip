@@ -374,7 +374,7 @@ inline int pp_mode() {
 inline bool pp_eligible(const tg_gemm_desc* d) {
   if (d->mode != 0 || d->a1 != nullptr || d->force_split_k > 1 || d->a_coef != nullptr) return false;
   if (d->M % 256 != 0 || d->N % 256 != 0 || d->K % 64 != 0 || d->K < 128) return false;
-  if (d->n_split > 0 && d->n_split % 64 != 0) return false;
+  if (d->n_split > 0 && (d->n_split % 64 != 0 || d->rows_per_batch <= 0 || (d->M / d->rows_per_batch) * (d->N - d->n_split) * d->ldt >= (1LL << 31))) return false;
   if (d->ln_u != nullptr && d->ln_rows == nullptr) return false;
   if (d->geglu && d->n_split > 0) return false;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -392,8 +392,9 @@ inline bool pp_selected(const tg_gemm_desc* d) {
   const long tiles = (d->M / 256) * (d->N / 256);
   const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
   // measured (scripts/dev_gemm8.py, profiles/r6_pp_gemm.txt): the ping-pong loop wins where a workgroup's K loop is long enough to pay for its
-  // prologue and the grid fills its rounds; short-K / ragged-N projections stay on the 128 x 160 / 128 x 128 tiles
-  return tiles >= 192 && eff >= 0.74 && d->K >= 640;
+  // prologue and the grid fills its rounds (2048 x 10240 x 1280 GEGLU, 320 tiles = 1.25 rounds: 81.8 -> 64.6 us; 8192 x 5120 x 640, 640 tiles: 89.6 -> 67.8);
+  // short-K / ragged-N projections stay on the 128 x 160 / 128 x 128 tiles
+  return tiles >= 192 && eff >= 0.6 && d->K >= 640;
 }
 
 // LayerNorm-folded projections on 128 x 160 tiles: 0 = no, 160 = three stages / one workgroup per CU, 161 = two stages / two per CU (tg_gemm_ln.hip)

@@ -112,7 +112,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 #undef PP_READ
   f32x4 acc[2][2][4][2];                          // [qa][qb][i][j]: tokens qa * 64 + i * 16 + frow, channels qb * 32 + j * 16 + 4 fq + e
+  const bool prio = (p.flags & 2) != 0;           // dev A/B (TG_GEMM_FLAGS bit 1): s_setprio 1 around a phase's MFMA block
   auto mfma_quad = [&](int qa, int qb) {
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[qa][qb][i][j] = mfma16(__builtin_bit_cast(V8, bf[j][ks]), __builtin_bit_cast(V8, af[i][ks]), acc[qa][qb][i][j]);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
   // end of a phase's load section: my fragment reads have RETURNED (so a slot may be refilled one phase after its last read, and the MFMAs below
   // may use them), then the workgroup barrier; the scheduling fences keep hipcc from moving MFMAs / reads across (guide 5.4 rule 18)
@@ -209,27 +212,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // LayerNorm fold with precomputed row statistics, in the accumulator layout: LN(x) W^T = rstd (x W'^T) + (-rstd mean) u + v
       // (W' = W gamma, u = row sums of W', v = W beta; tg_gemm_glds.h).  Per lane: the (rstd, -rstd mean) pairs of its 8 token rows, then one
       // 16-column group of u / v at a time; v rides with the bias below.
-      float rs[2][4], rm[2][4];
 #pragma unroll
-      for (int qa = 0; qa < 2; ++qa)
+      for (int qa = 0; qa < 2; ++qa) {
+        float rs[4], rm[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_rows + 2 * (m_w + qa * 64 + i * 16 + frow));
-          rs[qa][i] = st[0]; rm[qa][i] = st[1];
+          rs[i] = st[0]; rm[i] = st[1];
         }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const long col = n_w + qb * 32 + j * 16 + 4 * fq;
-          const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.ln_u + col), v4 = *reinterpret_cast<const f32x4*>(p.ln_v + col);
-#pragma unroll
-          for (int qa = 0; qa < 2; ++qa)
+          for (int j = 0; j < 2; ++j) {
+            const long col = n_w + qb * 32 + j * 16 + 4 * fq;
+            const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.ln_u + col), v4 = *reinterpret_cast<const f32x4*>(p.ln_v + col);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[qa][qb][i][j][e] = rs[qa][i] * acc[qa][qb][i][j][e] + (rm[qa][i] * u4[e] + v4[e]);
-        }
+              for (int e = 0; e < 4; ++e) acc[qa][qb][i][j][e] = rs[i] * acc[qa][qb][i][j][e] + (rm[i] * u4[e] + v4[e]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);          // the epilogue's own loads are not hoisted over the fold (they would sit next to all 128 accumulators)
     }
     if constexpr (EPI == 2) {
       // GEGLU in the accumulator layout: a = quadrant (q, 0), gate = quadrant (q, 1), same lane / register -> 32 output channels per wave
@@ -298,24 +301,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const long mb = m_w + 32 * b;
         if (to_t) {
           // lane = token is already the contiguous direction of out_t[(batch, column), token]: direct 2-byte stores, 16 tokens per run
+          // (32-bit element offsets from out_t: one VGPR add per store instead of a 64-bit address each — the planner checks the extent)
           T* ot = reinterpret_cast<T*>(p.out_t);
-          const long nt = p.N - p.n_split;
+          const unsigned nt = (unsigned)(p.N - p.n_split), ldt = (unsigned)p.ldt;
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * (b & 1) + ii;
             const long m = mb + 16 * ii + frow;
-            const long bb = m / p.rows_per_batch, tok = m - bb * p.rows_per_batch;
+            const unsigned bb = (unsigned)(m / p.rows_per_batch), tok = (unsigned)(m - (long)bb * p.rows_per_batch);
+            const unsigned col0 = (unsigned)(n_w - p.n_split) + 4u * (unsigned)fq;
+            const unsigned o0 = (bb * nt + col0) * ldt + tok;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-              for (int j = 0; j < 2; ++j)
+              for (int j = 0; j < 2; ++j) {
+                float bq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (biasp != nullptr) {
+                  const typename Vec<T>::v4 b4 = *reinterpret_cast<const typename Vec<T>::v4*>(biasp + n_w + qb * 32 + j * 16 + 4 * fq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const long col = n_w + qb * 32 + j * 16 + 4 * fq + e;
-                  float x = acc[qa][qb][i][j][e];
-                  if (biasp != nullptr) x += to_f32<T>(biasp[col]);
-                  ot[(bb * nt + (col - p.n_split)) * p.ldt + tok] = from_f32<T>(x * scale);
+                  for (int e = 0; e < 4; ++e) bq[e] = to_f32<T>(b4[e]);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  ot[o0 + (unsigned)(qb * 32 + j * 16 + e) * ldt] = from_f32<T>((acc[qa][qb][i][j][e] + bq[e]) * scale);
+              }
           }
           continue;
         }

@@ -57,7 +57,10 @@ class DenoiseEngine:
     ``torch.stack(latents_all)`` of reference pipelines.py:488 for every image of the batch."""
 
     def __init__(self, unet, scheduler=None, n_img=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
-                 enc_len=81, use_graph=True, controlnet=None, controlnet_enc_len=77):
+                 enc_len=81, use_graph=True, controlnet=None, controlnet_enc_len=77, timesteps=None):
+        """``timesteps`` (optional): a SUBSET of ``scheduler.set_timesteps(num_inference_steps)`` to walk instead of all of them — the reference's fast
+        schedule (``utils/schedule.py:4-8`` applied at ``models/pipelines.py:383-384``); as in the reference the DDIM update of a kept step still jumps by
+        the full schedule's stride (``prev_t = t - 1000 // num_inference_steps``)."""
         self.unet = unet
         self.ws_slot = next(_engine_ids)      # private kernel scratch: engines may replay concurrently on different streams
         # stage 2 (reference pipelines.py:759-818): every step the ControlNet runs on the same model input with the TEXT
@@ -73,9 +76,10 @@ class DenoiseEngine:
         self.dev, self.dt = dev, dt
         C = cfg.in_channels
         self.scheduler.set_timesteps(num_inference_steps)
-        self.timesteps = self.scheduler.timesteps.clone()
+        self.timesteps = self.scheduler.timesteps.clone() if timesteps is None else torch.as_tensor(timesteps, dtype=torch.int64).clone()
+        num_inference_steps = self.steps = int(self.timesteps.numel())
         self.t_table = self.timesteps.to(device=dev, dtype=torch.float32)
-        self.coef = self.scheduler.coef_table().to(dev)
+        self.coef = self.scheduler.coef_table(self.timesteps).to(dev)
         self.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sched = DeviceSchedule(self.t_table, self.step_idx)
         self.latents = torch.zeros((n_img, C, self.h, self.w), dtype=torch.float32, device=dev)
@@ -303,6 +307,186 @@ def denoise_single_object(adapter, prompt_embeds, negative_prompt_embeds, input_
     engine.set_conditioning(enc)
     latents_all = engine.run(input_latents)
     return latents_all[-1], latents_all
+
+
+# ---- the reference's two stage functions, same signatures and return tuples, on the engine ------------------------------------------------------
+SINGLE_OBJECT_NEGATIVE_PROMPT = "background, multiple objects, incomplete, lowres, bad anatomy, low quality, obscured"      # models/pipelines.py:225
+PLACEHOLDER_IMAGE = "model.png"                                                                                            # models/pipelines.py:195
+
+
+def _own_unet(adapter, what):
+    from .unet import UNet2DConditionModel
+    unet = adapter.pipe.unet
+    if not isinstance(unet, UNet2DConditionModel):
+        raise TypeError(f"theatergen_amd.pipelines.{what}: adapter.pipe.unet must be a theatergen_amd.unet.UNet2DConditionModel (INTEGRATION.md level 1: "
+                        f"UNet2DConditionModel.from_state_dict(config.sd15(), diffusers_unet.state_dict(), ...)), got {type(unet).__name__}")
+    return unet
+
+
+def _engine_of(adapter, **kw):
+    """one engine (static buffers + captured step graph) per loop geometry, kept on the adapter: the characters of a run replay the same graph"""
+    cache = adapter.__dict__.setdefault("_tg_engines", {})
+    ts = kw.get("timesteps")
+    key = tuple(sorted((k, (tuple(v.tolist()) if k == "timesteps" and v is not None else (id(v) if k == "controlnet" else v))) for k, v in kw.items()))
+    eng = cache.get(key)
+    if eng is None or eng.unet is not adapter.pipe.unet:
+        eng = cache[key] = DenoiseEngine(adapter.pipe.unet, adapter.pipe.scheduler, **kw)
+    return eng
+
+
+def _to_pil(image):
+    """``image_processor.postprocess(image, output_type='pil', do_denormalize=[True])[0]`` (models/pipelines.py:475): NCHW in [-1, 1] -> PIL RGB"""
+    from PIL import Image
+    import numpy as np
+    arr = (image[0].float() / 2 + 0.5).clamp(0, 1).permute(1, 2, 0).cpu().numpy()
+    return Image.fromarray((arr * 255).round().astype(np.uint8))
+
+
+def _text_and_image_rows(adapter, prompt, negative_prompt, pil_image):
+    """[negative rows ; positive rows] = text tokens followed by the IP-Adapter image tokens (models/pipelines.py:204-233, 369-370, 864-948)"""
+    img, unc = adapter.get_image_embeds(pil_image=pil_image, clip_image_embeds=None)
+    pos, neg = adapter.pipe.encode_prompt(prompt, device=adapter.device, num_images_per_prompt=1, do_classifier_free_guidance=True,
+                                          negative_prompt=negative_prompt)[:2]
+    return prepare_ip_embeds(pos, neg, img.to(pos.device), unc.to(pos.device))
+
+
+def generate_semantic_guidance(task, fg_seed_now, basever, ip_prompt, database_path, id, adapter, model_dict, latents, input_embeddings,
+                               num_inference_steps, bboxes, phrases, object_positions, guidance_scale=7.5, semantic_guidance_kwargs=None,
+                               return_cross_attn=False, return_saved_cross_attn=False, saved_cross_attn_keys=None, return_cond_ca_only=False,
+                               return_token_ca_only=None, offload_guidance_cross_attn_to_cpu=False, offload_cross_attn_to_cpu=False,
+                               offload_latents_to_cpu=True, return_box_vis=False, show_progress=True, save_all_latents=False,
+                               dynamic_num_inference_steps=False, fast_after_steps=None, fast_rate=2, use_boxdiff=False, use_adapter=False,
+                               obj_id=False, have_reffer=0):
+    """Stage 1, one character (reference ``models/pipelines.py:175-490``; caller ``theatergen.py:108-135``): same arguments, same side effects (the
+    character's first image becomes its reference PNG, :476-477), same return tuple ``(latents, image[, saved_attns][, image][, latents_all])``.
+
+    What runs where.  Host, as in the reference: the reference image / placeholder and its IP scale (:183-199), the prompt strings (:216-225),
+    ``adapter.get_image_embeds`` and ``adapter.pipe.encode_prompt``.  Device: the whole loop :406-453 is ``num_inference_steps`` replays of ONE captured
+    step (UNet CFG call + fused CFG / DDIM epilogue + history row) — no ``.cpu()`` per step; the 51 latents come back in one copy when
+    ``offload_latents_to_cpu`` asks for them on the host.  ``cross_attention_kwargs`` is ``None`` in the reference's UNet call (:428), so no map is
+    ever saved: ``saved_attns`` is the reference's list of empty dicts.  Unsupported here, loudly: the ``'xl'`` branch (multi-device ``.to('cuda:1')``
+    placement; the SDXL loop lives in ``theatergen_amd.custom_pipelines``) and ``return_cross_attn`` (an attribute no diffusers output has)."""
+    from PIL import Image
+    from . import schedule as tg_schedule
+    if basever == "xl":
+        raise NotImplementedError("theatergen_amd.pipelines.generate_semantic_guidance: the 'xl' branch (models/pipelines.py:261-366, 466-470) is not on "
+                                  "this path; SDXL runs through theatergen_amd.custom_pipelines.StableDiffusionXLCustomPipeline")
+    if return_cross_attn:
+        raise NotImplementedError("return_cross_attn reads unet_output.cross_attention_probs_* (models/pipelines.py:431-434), which the UNet call of "
+                                  "the reference never fills; the saved-map side channel is save_attn_to_dict")
+    if not obj_id:
+        raise RuntimeError("generate_semantic_guidance: obj_id is required (without it the reference has no prompt embeddings to run on, models/pipelines.py:183-233)")
+    unet = _own_unet(adapter, "generate_semantic_guidance")
+    # ---- image prompt of the character: its database PNG, or the placeholder with the adapter switched off (:183-199)
+    try:
+        image = Image.open(database_path + str(obj_id) + ".png")
+        scale, have_reffer = 0.4, 1
+    except (OSError, ValueError):
+        image = Image.open(PLACEHOLDER_IMAGE)
+        scale, have_reffer = 0, 0
+    adapter.set_scale(scale)
+    prompt = ("single object, " if task == "editing" else "full-body picture of ") + str(ip_prompt)
+    enc = _text_and_image_rows(adapter, prompt, SINGLE_OBJECT_NEGATIVE_PROMPT, image)
+    # ---- the loop
+    scheduler = adapter.pipe.scheduler
+    timesteps = None
+    if fast_after_steps is not None:
+        scheduler.set_timesteps(num_inference_steps)
+        timesteps = tg_schedule.get_fast_schedule(scheduler.timesteps, fast_after_steps, fast_rate)
+    h8, w8 = latents.shape[-2], latents.shape[-1]
+    eng = _engine_of(adapter, n_img=latents.shape[0], height=8 * h8, width=8 * w8, num_inference_steps=num_inference_steps,
+                     guidance_scale=guidance_scale, enc_len=enc.shape[1], timesteps=timesteps)
+    eng.set_conditioning(enc.to(eng.dev, eng.dt))
+    hist = eng.run(latents)
+    out = hist[-1].to(unet.dtype)                                # the reference's `latents.half()` (:461), in the UNet's storage dtype
+    vae = adapter.pipe.vae
+    decoded = vae.decode(out / vae.config.scaling_factor, return_dict=False)[0].detach()
+    post = getattr(getattr(adapter.pipe, "image_processor", None), "postprocess", None)
+    images = post(decoded, output_type="pil", do_denormalize=[True])[0] if post is not None else _to_pil(decoded)
+    if have_reffer == 0:
+        images.save(database_path + str(obj_id) + ".png")       # the character's first appearance becomes its reference (:476-477)
+    ret = [out, images]
+    if return_saved_cross_attn:
+        ret.append([{} for _ in range(eng.steps)])
+    if return_box_vis:
+        ret.append(images)
+    if save_all_latents:
+        allv = hist.to(latents.dtype).clone()
+        ret.append(allv.cpu() if offload_latents_to_cpu else allv)
+    return tuple(ret)
+
+
+def _control_image(controlnetpipe, control_image, width, height, device, dtype):
+    """``controlnetpipe.prepare_image(...)`` of :712-722 (CFG: the image twice) or, for a pipeline object without it, the same preparation:
+    resize to (width, height) with LANCZOS, [0, 1], NCHW"""
+    if hasattr(controlnetpipe, "prepare_image"):
+        return controlnetpipe.prepare_image(image=control_image, width=width, height=height, batch_size=1, num_images_per_prompt=1, device=device,
+                                            dtype=dtype, do_classifier_free_guidance=True, guess_mode=False)
+    import numpy as np
+    from PIL import Image
+    if torch.is_tensor(control_image):
+        t = control_image.to(device=device, dtype=dtype)
+        t = t if t.dim() == 4 else t[None]
+    else:
+        pil = control_image if isinstance(control_image, Image.Image) else Image.fromarray(np.asarray(control_image))
+        arr = np.asarray(pil.convert("RGB").resize((width, height), resample=Image.LANCZOS)).astype(np.float32) / 255.0
+        t = torch.from_numpy(arr).permute(2, 0, 1)[None].to(device=device, dtype=dtype)
+    return torch.cat([t] * 2)
+
+
+@torch.no_grad()
+def final_image_generation(basever, processor, controlnetpipe, tpipe, overall_prompt, overall_negative_prompt, bg_prompt, single_obj_img_list, objects,
+                           repeat_ind, height, width, bg_seed, inp_mask, input_img, adapter, model_dict, latents_all, frozen_mask, bg_input_embeddings,
+                           input_embeddings, num_inference_steps, frozen_steps, guidance_scale=7.5, bboxes=None, phrases=None, object_positions=None,
+                           semantic_guidance_kwargs=None, offload_guidance_cross_attn_to_cpu=False, use_boxdiff=False):
+    """Stage 2, the final image (reference ``models/pipelines.py:592-857``, SD-1.5 branch; caller ``theatergen.py:448-484``): same arguments, returns
+    ``(latents, images uint8 [1, H, W, 3])``.  As in the reference: the frozen latents are the pasted image VAE-encoded and re-noised at ALL timesteps
+    (:617-631) and OVERWRITE the caller's ``latents_all`` (:737-738); the frozen mask is the inverted, re-binarised 64 x 64 resize of ``inp_mask``
+    (:605-614), not the ``frozen_mask`` argument; the start latents are fresh background noise (:632); IP scale 0.1 on the first character's image
+    (:700-701); ControlNet at scale 1 on ``processor(input_img)`` every step (:705-731, 762-778).  All random draws come from the DEVICE generator
+    seeded with ``bg_seed`` (:594, 625-632), in the reference's order.  Device: one captured step (ControlNet + UNet + CFG / DDIM / frozen-mask
+    replace) replayed ``num_inference_steps`` times; no per-step ``.cpu()`` (:835)."""
+    import numpy as np
+    if basever == "xl":
+        raise NotImplementedError("theatergen_amd.pipelines.final_image_generation: the 'xl' branch (T2I-Adapter on 'cuda:2', models/pipelines.py:634-697) "
+                                  "is not on this path")
+    unet = _own_unet(adapter, "final_image_generation")
+    from .controlnet import ControlNetModel
+    controlnet = controlnetpipe.controlnet
+    if not isinstance(controlnet, ControlNetModel):
+        raise TypeError("theatergen_amd.pipelines.final_image_generation: controlnetpipe.controlnet must be a theatergen_amd.controlnet.ControlNetModel "
+                        f"(INTEGRATION.md, stage 2), got {type(controlnet).__name__}")
+    vae, scheduler, dtype, dev = adapter.pipe.vae, adapter.pipe.scheduler, unet.dtype, unet.device
+    generator = torch.Generator(dev).manual_seed(bg_seed)
+    text_embeddings, uncond_embeddings, cond_embeddings = input_embeddings
+    scheduler.set_timesteps(num_inference_steps)
+    h8, w8 = int(height / 8), int(width / 8)
+    # frozen mask: 1 where a character was pasted (inp_mask is 0 there)
+    m = np.array(inp_mask.resize((h8, w8)).convert("L")).astype(np.float32) / 255.0
+    m[m > 0] = 1
+    my_mask = torch.from_numpy(1 - m).to(device=dev, dtype=torch.float32)
+    # frozen latents: the pasted image through the VAE encoder, re-noised at every timestep
+    img = torch.from_numpy(np.array(input_img).astype(np.float32) / 255.0)[None].permute(0, 3, 1, 2)
+    myimage = (2.0 * img - 1.0).to(device=dev, dtype=dtype)
+    init_latents = vae.config.scaling_factor * vae.encode(myimage).latent_dist.sample(generator=generator)
+    noise = torch.randn(init_latents.shape, generator=generator, device=dev, dtype=dtype)
+    my_latents = scheduler.add_noise(init_latents, noise, scheduler.timesteps).unsqueeze(1)                    # [steps, 1, C, h, w]
+    my_bg = torch.randn((1, unet.config.in_channels, h8, w8), generator=generator, device=dev, dtype=dtype) * float(scheduler.init_noise_sigma)
+    # conditioning: overall prompt + the first character's image tokens at scale 0.1; ControlNet sees the text rows only
+    ip_embeds = _text_and_image_rows(adapter, overall_prompt, overall_negative_prompt, single_obj_img_list[0])
+    adapter.set_scale(0.1)
+    imagetight = _control_image(controlnetpipe, processor(np.array(input_img)), width, height, dev, dtype)
+    latents_all[0] = my_bg.to(latents_all.device, latents_all.dtype)
+    latents_all[1:] = my_latents.to(latents_all.device, latents_all.dtype)
+    eng = _engine_of(adapter, n_img=1, height=int(imagetight.shape[-2]), width=int(imagetight.shape[-1]), num_inference_steps=num_inference_steps,
+                     guidance_scale=guidance_scale, enc_len=ip_embeds.shape[1], controlnet=controlnet, controlnet_enc_len=text_embeddings.shape[1])
+    eng.set_conditioning(ip_embeds.to(dev, dtype))
+    eng.set_control(text_embeddings.to(dev, dtype), imagetight.to(dev, dtype), 1.0)
+    eng.set_frozen(latents_all.to(dev, torch.float32), my_mask, frozen_steps)
+    latents = eng.run(my_bg)[-1].to(dtype)
+    image = vae.decode(1 / 0.18215 * latents).sample
+    image = (image.float() / 2 + 0.5).clamp(0, 1).detach().cpu().permute(0, 2, 3, 1).numpy()
+    return latents, (image * 255).round().astype("uint8")
 
 
 def latent_backward_guidance(*args, **kwargs):

@@ -84,6 +84,17 @@ _LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_M
 _LN_FF_MAX_ROWS = int(os.environ.get("TG_LN_FF_MAX_ROWS", "0"))
 _CONV_OUT_GN = os.environ.get("TG_CONV_OUT_GN", "1") != "0"      # dev A/B knob: 0 = GroupNorm apply launch + conv_out
 _FF_PAD = os.environ.get("TG_FF_PAD", "1") != "0"      # round 5: pad the FeedForward hidden tensor's / net.2 weight's row pitch (see FeedForward._hidden)
+_PP_MODE = int(os.environ.get("TG_PP", "7"))           # csrc/tg_gemm.hip pp_mode(): bit 2 = LayerNorm-folded projections on the ping-pong tiles
+
+
+def _pp_takes_ln(M, N, K):
+    """mirror of csrc/tg_gemm.hip ``pp_selected`` for a LayerNorm-folded projection (the kernel needs the row statistics as an input)"""
+    if not (_PP_MODE & 4) or M % 256 or N % 256 or K % 64 or K < 640:
+        return False
+    tiles = (M // 256) * (N // 256)
+    return tiles >= 192 and tiles / (((tiles + 255) // 256) * 256) >= 0.6
+
+
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
 
 
@@ -288,13 +299,15 @@ class BasicTransformerBlock(nn.Module):
         if _LN_MODE and M >= _FUSE_LN_MIN_ROWS and C % 64 == 0 and x2d.stride(0) == C:
             # LayerNorm rides in the projection that consumes it (tg_gemm ln_u / ln_v): no normalised tensor.  Row statistics: a
             # statistics-only pass (half the layernorm kernel's traffic) or taken inside the GEMM from its own A tiles
-            def folded(norm, t):
-                return (norm, ops.layernorm_stats(t, norm.eps) if _LN_MODE & 4 else None)
+            def folded(norm, t, n_out=0):
+                # round 6: where the ping-pong 256 x 256 GEMM takes the projection (tg_gemm_pp.hip: it folds the LayerNorm from PRECOMPUTED row statistics)
+                # the statistics-only pass runs first: 16 x 16 level q | k | v, 4096 x 3840 x 1280: 75 -> 54 + 6 us
+                return (norm, ops.layernorm_stats(t, norm.eps) if (_LN_MODE & 4 or _pp_takes_ln(t.shape[0], n_out, t.shape[1])) else None)
             if _LN_MODE & 1:
                 if pre_qkv is not None:
                     x2d = self_attention_from_qkv(self.attn1, pre_qkv[0], pre_qkv[1], pre_qkv[2], b, n, x2d)
                 else:
-                    x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d))
+                    x2d = self._call(self.attn1, x2d, b, n, None, x2d, ca_kwargs, ln=folded(self.norm1, x2d, 3 * self.attn1.to_q.weight.shape[0]))
                 # first level of SD-1.5: norm2 + attn2 + residual as ONE row-chain launch (q, scores and O stay in registers)
                 h2 = fused_cross_block(self.attn2, self.norm2, x2d, b, n, enc, ca_kwargs)
                 x2d = h2 if h2 is not None else self._call(self.attn2, x2d, b, n, enc, x2d, ca_kwargs, ln=folded(self.norm2, x2d))

@@ -181,8 +181,12 @@ class DiagonalGaussianDistribution:
 
     def sample(self, generator=None, scale=1.0):
         B, C2, h, w = self.parameters.shape
-        noise = torch.randn((B, C2 // 2, h, w), generator=generator, dtype=self.dtype).to(device=self.parameters.device,
-                                                                                           dtype=torch.float32)
+        if generator is not None and generator.device.type != "cpu":
+            # a DEVICE generator (models/pipelines.py:594 `torch.Generator("cuda")`, stage 2): randn_tensor draws on the device in the model dtype
+            noise = torch.randn((B, C2 // 2, h, w), generator=generator, device=self.parameters.device, dtype=self.dtype).to(torch.float32)
+        else:
+            noise = torch.randn((B, C2 // 2, h, w), generator=generator, dtype=self.dtype).to(device=self.parameters.device,
+                                                                                               dtype=torch.float32)
         return ops.gaussian_sample(self.parameters, noise, scale).to(self.dtype)
 
     def mode(self, scale=1.0):
