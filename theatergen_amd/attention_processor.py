@@ -215,7 +215,8 @@ def xq_weight(attn, norm):
     import math
     from .weights_pack import pack_ln_linear
     ts = [attn.to_q.weight, norm.weight, norm.bias] + ([attn.to_q.bias] if attn.to_q.bias is not None else [])
-    return _cached(attn, "xq_q", ts, lambda: pack_ln_linear(attn.to_q.weight.detach(), attn.to_q.bias, norm.weight, norm.bias,
+    # the folded scale is part of the key: a caller that changes attn.scale (scale_qk toggles on a foreign Attention) gets a new pack
+    return _cached(attn, f"xq_q_{float(attn.scale)!r}", ts, lambda: pack_ln_linear(attn.to_q.weight.detach(), attn.to_q.bias, norm.weight, norm.bias,
                                                             scale=float(attn.scale) * math.log2(math.e)))
 
 
@@ -458,7 +459,7 @@ def fused_cross_block(attn, norm, x2d, B, N, enc, kwargs):
         kvpk = ops.rc_kv_pack(k, vt, ldt, L, None, None, 0, 0, B)
         scale_dev = None
     tq = [attn.to_q.weight, norm.weight, norm.bias] + ([attn.to_q.bias] if attn.to_q.bias is not None else [])
-    wq = _cached(attn, "rc_xq", tq, lambda: rowchain.pack_xattn_q(attn.to_q.weight, attn.to_q.bias, norm.weight, norm.bias, attn.scale))
+    wq = _cached(attn, f"rc_xq_{float(attn.scale)!r}", tq, lambda: rowchain.pack_xattn_q(attn.to_q.weight, attn.to_q.bias, norm.weight, norm.bias, attn.scale))
     to = [attn.to_out[0].weight] + ([attn.to_out[0].bias] if attn.to_out[0].bias is not None else [])
     wo = _cached(attn, "rc_xo", to, lambda: rowchain.pack_xattn_out(attn.to_out[0].weight, attn.to_out[0].bias))
     return ops.rc_xattn(x2d, wq, kvpk, wo, N, norm.eps, T, ip_scale=scale_dev, text_len=L)
@@ -642,10 +643,12 @@ class IPAttnProcessor(nn.Module):
         inner, _, d = attn_dims(attn)
         return ops.xq_kv_pack(k, vt, ldt, L, kip, vtip, ldi, T, B, inner, d, out=out)
 
-    def project_kv_xq(self, attn, enc):
+    def project_kv_xq(self, attn, enc, kv=None):
         """K / V^T of ``enc`` as the MFMA fragments of the fused inner-level launch (``tg_xq_attn``): for a REGISTERED tensor they live in the
-        tensor's slot and are re-packed in place whenever the projections are; any other tensor is packed per call."""
-        kv = self.project_kv(attn, enc)
+        tensor's slot and are re-packed in place whenever the projections are; any other tensor is packed per call.  ``kv``: the tuple a caller
+        already got from ``project_kv`` for this very call (an unregistered tensor would otherwise be projected twice)."""
+        if kv is None:
+            kv = self.project_kv(attn, enc)
         slot = self._kv.get(enc)
         if slot is not None and slot["attn"]() is attn and slot.get("kv") is kv:
             if slot.get("xqpk") is None:
@@ -653,10 +656,11 @@ class IPAttnProcessor(nn.Module):
             return slot["xqpk"]
         return self._pack_xq(attn, kv, enc.shape[0])
 
-    def project_kv_frags(self, attn, enc):
+    def project_kv_frags(self, attn, enc, kv=None):
         """K / V^T of ``enc`` as the fragment blocks of the fused first-level cross-attention (``tg_rc_xattn``): for a REGISTERED
         tensor they live in the tensor's slot and are re-packed whenever the projections are; any other tensor is packed per call."""
-        kv = self.project_kv(attn, enc)
+        if kv is None:
+            kv = self.project_kv(attn, enc)
         slot = self._kv.get(enc)
         if slot is not None and slot["attn"]() is attn and slot.get("kv") is kv:
             if slot.get("kvpk") is None:
@@ -698,14 +702,15 @@ class IPAttnProcessor(nn.Module):
             # so the registered-tensor K / V^T cache does not apply to it
             encoder_hidden_states = _norm_encoder(attn, encoder_hidden_states)
         enc = encoder_hidden_states.contiguous()
-        k, vt, ldt, kip, vtip, ldi, L, T = self.project_kv(attn, enc)
+        kv_now = self.project_kv(attn, enc)
+        k, vt, ldt, kip, vtip, ldi, L, T = kv_now
         if _fused_ln is not None and _fused_ln[1] is None and xq_eligible(attn, x, B, N, L, T, dict(
                 save_attn_to_dict=save_attn_to_dict, attn_process_fn=attn_process_fn, return_attntion_probs=return_attntion_probs)):
             # inner levels (round 5): norm2 + to_q + the two softmaxes + PV in ONE launch; the K / V^T fragments live with the conditioning's slot
             norm = _fused_ln[0]
             wx, ux, vx = xq_weight(attn, norm)
             o = torch.empty((B * N, inner), dtype=x.dtype, device=x.device)
-            ops.xq_attn(x, wx, ux, vx, norm.eps, self.project_kv_xq(attn, enc), d, N, L, T, ip_scale=self.scale_device(x.device), out=o)
+            ops.xq_attn(x, wx, ux, vx, norm.eps, self.project_kv_xq(attn, enc, kv=kv_now), d, N, L, T, ip_scale=self.scale_device(x.device), out=o)
             return _finish(attn, o, B, N, C, shape4, xin, _fused_residual)
         if _fused_ln is not None:
             norm, rows = _fused_ln

@@ -120,7 +120,7 @@ def build(force=False, verbose=True, check_gate=False):
 # (device pass only, no objects kept), writes profiles/r5_kernel_resources.json (VGPR / AGPR / scratch / spills / occupancy per
 # kernel symbol) and, with --check, fails when a kernel matching HOT_GATES exceeds its allowance.  A hot kernel that gains
 # scratch must be a decision, not an accident (round 3 shipped 6 spills inside the d = 40 attention tile loop).
-RESOURCES_JSON = os.path.join(os.path.dirname(HERE), "profiles", "r5_kernel_resources.json")
+RESOURCES_JSON = os.path.join(os.path.dirname(HERE), "profiles", "r6_kernel_resources.json")
 # (substring of the DEMANGLED name, max scratch bytes / lane, max VGPRs)
 HOT_GATES = [
     # SD-1.5 level 0 (d = 40): four waves per SIMD, nothing spilled.  Template arguments: <T, DPAD, DV, ONES, FOLD, PIPE, MASK> (round 4 added the last
@@ -141,6 +141,13 @@ HOT_GATES = [
     ("rc_linear_kernel<", 0, 256),                                 # every instance (the UNet launches <T,20,8,2,false,0>, plain / + residual)
     ("skinny_gemm_kernel<", 0, 256),                               # round 5: the CK = 16 / 20 instances spilled 44 .. 164 bytes
     ("attn_bwd_kernel<", 0, 224),                                  # round 5: reverse pass of attention (statistics / dQ / dK + dV instances: 156 / 198 / 216 VGPRs)
+    # round 6: ping-pong 256 x 256 GEMM.  Template arguments <T, EPI, LN>: nothing spilled in the GEGLU / linear / activation instances; the
+    # LayerNorm-folded linear instance (q | k | v^T) spills in its EPILOGUE only (scripts/asm_loop_report.py: 0 scratch accesses inside the MFMA loop)
+    ("pp_gemm_kernel<bf16,2,", 0, 256),
+    ("pp_gemm_kernel<f16,2,", 0, 256),
+    ("pp_gemm_kernel<bf16,0,0>", 0, 256),
+    ("pp_gemm_kernel<f16,0,0>", 0, 256),
+    ("pp_gemm_kernel<", 256, 256),
     ("conv_in_mfma_kernel<", 0, 256),                              # round 5: boundary convs on the matrix cores
     ("conv_out_mfma_kernel<", 0, 128),
 ]

@@ -109,10 +109,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     const T* wlane = nullptr;                      // this lane's 16 bytes of (row wave * 8 + lane / 8, tap 0, chunk 0) of the tile's rows
     int cfirst = 0, nchunks = 0, nkt = 0;               // this work item's first chunk, chunk count, K-steps
-    // (a per-work-item rotation of the chunk walk — L2 channel spread of lockstep workgroups — was measured in round 5: 1.5 % SLOWER end to end)
-    auto pchunk = [&](int cc) { return cc; };
-    auto issue_w = [&](int ccl, int tap, int stage) {
-      const int cc = pchunk(ccl);
+    // (a per-work-item rotation of the chunk walk — L2 channel spread of lockstep workgroups — was measured in round 5: 1.5 % SLOWER end to end, profiles/r5_t160_findings.md)
+    auto issue_w = [&](int cc, int tap, int stage) {
       const T* src = wlane + ((long)tap * ctot + cc * BK);
       const unsigned dst = lds0 + W_BASE + (unsigned)stage * WST_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
@@ -127,8 +125,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 ca0, ca1, cd0, cd1;                       // its GroupNorm coefficients a[8], d[8] (of the image of patch 0)
     f32x4 cb0, cb1, ce0, ce1;                       // NP = 2: the same for the image of patch 1 (slab rows >= WIN)
     int img = 0, img1 = 0;
-    auto load_slab = [&](int ccl) {                 // request chunk cc of the window (asm: the compiler's waitcnt pass must not see these)
-      const int cc = pchunk(ccl);
+    auto load_slab = [&](int cc) {                  // request chunk cc of the window (asm: the compiler's waitcnt pass must not see these)
       int c = cc * BK;
       const T* base = A0;
       int pitch = p.c0;

@@ -32,7 +32,8 @@ constexpr int kNumTiles = 10;
 // exactly two / one per CU.  7: BK = 64, three stages (108 KB, one workgroup per CU, two K-tiles in flight); 9 (= 8): BK = 64, two stages (72 KB, two per
 // CU).  (A BK = 32 / four-stage variant does not exist: 160 weight rows are not a whole number of 16-row DMA instructions per wave.)  Isolated, rotating
 // operands, us (profiles/r5_t160_sweep.txt; 128 x 128 -> 128 x 160): 16384 x 640 x 640 + res 30.6 -> 27.5, x 2560 86.4 -> 70.2, x 1280 44.0 -> 35.2;
-// 4096 x 1280 x 1280 + res 27.3 -> 24.9, x 5120 87.5 -> 79.2; 65536 x 320 x 1280 97.0 -> 84.0 (N = 320 is 2.5 tiles of 128: a sixth of those MFMAs is padding).  // id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
+// 4096 x 1280 x 1280 + res 27.3 -> 24.9, x 5120 87.5 -> 79.2; 65536 x 320 x 1280 97.0 -> 84.0 (N = 320 is 2.5 tiles of 128: a sixth of those MFMAs is padding).
+// id 4 = 128x128 with 3 stages (forced only); id 6 = 128x128 with three 32-wide K stages (48 KB: three
 // workgroups per CU instead of two; forced / dev switch: see make_plan)
 // id 5 = 256x256, 8 waves of 128x64, fragments read per k-step (230 VGPRs): +11..22 % over 128x128 on large plain GEMMs
 // (8192x4096x4096 929 vs 839 TF, 16384x5120x2560 1001 vs 818) but no gain at the SD-1.5 UNet's K = 320..1280 with the GEGLU

@@ -102,7 +102,6 @@ void gemm_glds_kernel(GemmParams p) {
   // (K ROTATION — every work item starting its K walk at another tile so that the lockstep workgroups of a single-round launch do not ask the same few L2
   // channels for the same K offset — was built and measured in round 5: the operand-pitch effect is real (profiles/r5_operand_pitch.txt: 4096 x 1280 x 5120
   // 594 TF, 718-751 TF with the row pitch padded by 64 / 192 elements) but the rotation loses more L2 locality than it wins: 16384 x 640 x 2560 70.2 -> 80.1 us.)
-  auto ktile = [&](int i) { return kt_begin + i; };
 
   // DMA lane geometry: instruction q covers tile rows [RPI*q, RPI*q + RPI); lane -> (row RPI*q + lane/CH, slot lane%CH)
   const int lrow = lane / CH;
@@ -228,14 +227,14 @@ void gemm_glds_kernel(GemmParams p) {
     // counted waits: a wave only waits until the NEXT tile's DMA has landed (vmcnt(NDMA) = one younger tile may stay in
     // flight; LDS-DMA completes in issue order); raw s_barrier, because __syncthreads() would drain vmcnt to 0.
     if constexpr (ER) {
-      issue_tile(ktile(0), 0);
-      if (nkt > 1) issue_tile(ktile(1), 1);
+      issue_tile(kt_begin + (0), 0);
+      if (nkt > 1) issue_tile(kt_begin + (1), 1);
       if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
 #pragma unroll
       for (int s = 0; s < PF; ++s)
-        if (s < nkt) issue_tile(ktile(s), s);
+        if (s < nkt) issue_tile(kt_begin + (s), s);
       if (PF >= 2 && nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -278,7 +277,7 @@ void gemm_glds_kernel(GemmParams p) {
         if (it + PF < nkt) {
           int nb = buf + PF;
           if (nb >= STAGES) nb -= STAGES;
-          issue_tile(ktile(it + PF), nb);
+          issue_tile(kt_begin + (it + PF), nb);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -298,7 +297,7 @@ void gemm_glds_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (it + 2 < nkt) issue_tile(ktile(it + 2), buf);
+            if (it + 2 < nkt) issue_tile(kt_begin + (it + 2), buf);
             __builtin_amdgcn_sched_barrier(0);
           }
         }

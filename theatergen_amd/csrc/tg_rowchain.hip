@@ -26,6 +26,19 @@
 #include <type_traits>
 #include <utility>
 
+// Dev timing switches (skip stores / barriers / MFMAs: WRONG results by design) exist only in a build with -DTG_RC_DEV_BUILD; the library's own build
+// (theatergen_amd/build.py) compiles them OUT of the stage loops: RC_DBG(bit) is the constant 0 there and the C entries refuse every dev bit.
+#ifdef TG_RC_DEV_BUILD
+#define RC_DBG(bit) ((p.dbg & (bit)) != 0)
+#define RC_DBG_ARG() (p.dbg >> 8)
+#else
+#define RC_DBG(bit) (false)
+#define RC_DBG_ARG() (0)
+#endif
+// rc_xattn_kernel keeps its switches as RUN-TIME branches on the (always zero, C entry checked) dbg word: with them compiled out hipcc's allocator spills
+// 99-111 VGPRs in the image-token instances (448 B scratch; profiles/r6_kernel_resources.json gate) — the branches are scheduling fences it relies on.
+#define RC_DBG_RT(bit) ((p.dbg & (bit)) != 0)
+
 namespace {
 
 struct RcLinearParams {
@@ -201,9 +214,9 @@ __global__ __launch_bounds__(NW * 64) void rc_linear_kernel(RcLinearParams p) {
     const int buf = c % NBUF;
     // chunk c has landed (this wave's pieces; the barrier covers the other waves') and every wave is done with chunk c - 1's buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
-    if (c + NBUF - 1 < NC && !(p.dbg & 2)) issue_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
-    if (pend_ch >= 0 && !(p.dbg & 1)) {
+    if (!RC_DBG(4)) __builtin_amdgcn_s_barrier();
+    if (c + NBUF - 1 < NC && !RC_DBG(2)) issue_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
+    if (pend_ch >= 0 && !RC_DBG(1)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (mok[i]) *reinterpret_cast<V8*>(outp + mrow[i] * p.ldc + pend_ch + 8 * qb) = pend[i];
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void rc_linear_kernel(RcLinearParams p) {
         }
     }
     const char* cb = cbase + lane * 16;
-    if (p.dbg & 8) {
+    if RC_DBG(8) {
     } else if constexpr (PD == 0) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     else if (st < 28) issue(reinterpret_cast<const char*>(p.wo) + (long)(st - 18) * TBW, st % 3);
   };
   // dev: phase stagger of the two co-resident workgroups of a CU (dbg 32: odd blocks, 64: second half of the grid; delay = dbg >> 8 x ~3.5 us)
-  if (((p.dbg & 32) && (blockIdx.x & 1)) || ((p.dbg & 64) && blockIdx.x >= gridDim.x / 2)) {
+  if ((RC_DBG_RT(32) && (blockIdx.x & 1)) || (RC_DBG_RT(64) && blockIdx.x >= gridDim.x / 2)) {
     for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
   }
   issue_stage(0);
@@ -432,8 +445,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     else if (younger >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (younger >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
-    if (!(p.dbg & 8)) issue_stage(st + 2);
+    if (!RC_DBG_RT(16)) __builtin_amdgcn_s_barrier();
+    if (!RC_DBG_RT(8)) issue_stage(st + 2);
   };
   // One 32-row weight tile = a stream of 20 fragments consumed by 20 MFMAs on one accumulator, read PD steps ahead of their MFMA with the
   // order PINNED (hipcc otherwise sinks every ds_read next to its MFMA: ~150 exposed cycles per MFMA).  The accumulator is seeded from
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int t = 0; t < 10; ++t) {
     stage_begin(t, 6);
-    if (p.dbg & 1) continue;
+    if RC_DBG_RT(1) continue;
     f32x16 acc = tile_stream(smem + (t % 3) * SLOT, H, true, std::integral_constant<int, 4>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= ln_rstd;
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       stage_begin(10 + 2 * m + hh, 6);
-      if (p.dbg & 2) continue;
+      if RC_DBG_RT(2) continue;
       const char* kb = smem + ((10 + 2 * m + hh) % 3) * SLOT + lane * 16;
       const char* vb = kb + 12 * 1024;
       const int s0 = 5 * m + 2 * hh;          // the head's three q k-steps: s0, s0 + 1, s0 + 2
@@ -642,7 +655,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = 0; i < 4; ++i) r8[i] = gld<V8>(hp + mrow[i] * p.ldh + ch0 + 8 * qb);
       }
       f32x16 acc;
-      if (!(p.dbg & 4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false, std::integral_constant<int, 8>{});
+      if (!RC_DBG_RT(4)) acc = tile_stream(smem + (st % 3) * SLOT, Q, false, std::integral_constant<int, 8>{});
       if (uu == 0) quad_transpose(r8[0], r8[1], r8[2], r8[3]);
       float o[16];
 #pragma unroll
@@ -862,7 +875,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   V8 pend[4];
   auto flush = [&](int k) __attribute__((always_inline)) {      // the stores of stage k
     if (k < 0 || n_stores(k) == 0) return;
-    if ((k >= 30 && (p.dbg & 1)) || (k < 30 && (p.dbg & 2))) return;
+    if ((k >= 30 && RC_DBG(1)) || (k < 30 && RC_DBG(2))) return;
     if (k < 30) {
       T* base = reinterpret_cast<T*>(p.qk);
       asm volatile("" : "+s"(base));
@@ -972,7 +985,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   };
   auto y_chunk_store = [&](int c) __attribute__((always_inline)) {
-    if (p.dbg & 4) return;
+    if RC_DBG(4) return;
     V8 t0 = Y[4 * c], t1 = Y[4 * c + 1], t2 = Y[4 * c + 2], t3 = Y[4 * c + 3];
     quad_transpose(t0, t1, t2, t3);
     T* base = reinterpret_cast<T*>(p.y);
@@ -1182,9 +1195,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool F1 = decltype(f1_c)::value, GG = decltype(gg_c)::value, F2 = decltype(f2_c)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
-    if (j + 1 < NS && !(p.dbg & 8)) issue_w1(j + 1);
-    if (j >= 1 && j - 1 < NS && !(p.dbg & 8)) issue_w2(j - 1);
+    if (!RC_DBG(16)) __builtin_amdgcn_s_barrier();
+    if (j + 1 < NS && !RC_DBG(8)) issue_w1(j + 1);
+    if (j >= 1 && j - 1 < NS && !RC_DBG(8)) issue_w2(j - 1);
     const char* w1b = smem + PAR * W1SLOT + lane * 16;
     const char* w2b = smem + W2OFF + PAR * W2B + lane * 16;
     if constexpr (F1) {
@@ -1468,8 +1481,12 @@ int dispatch_rc_linear(const tg_rc_linear_desc* d, const RcLinearParams& p, hipS
 // The dbg switches of the kernels above (timing experiments: skip stores / barriers / MFMAs — WRONG results by design) ride in descriptor bits the
 // release path never sets; a descriptor that carries them is rejected unless the process opted in with TG_RC_DEV=1 (scripts/dev_rc_*.py) — ADVICE r4
 inline bool rc_dev_enabled() {
-  static const bool on = [] { const char* e = getenv("TG_RC_DEV"); return e != nullptr && e[0] == '1'; }();
+#ifdef TG_RC_DEV_BUILD
+  static const bool on = []() { const char* e = getenv("TG_RC_DEV"); return e != nullptr && e[0] == '1'; }();
   return on;
+#else
+  return false;          // release build: the switches are not compiled into the kernels (RC_DBG above)
+#endif
 }
 
 }  // namespace

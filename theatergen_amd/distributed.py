@@ -42,7 +42,14 @@ def init(backend=None, device=None):
 def pin_host_threads(local, world):
     """One process per GPU on ONE node: N Python launch threads (+ torch's intra-op pools, used by the CPU-side latent recipe) must not fight over
     the same cores.  Rank ``local`` of ``world`` takes a contiguous slice of the CPUs this process may run on (``sched_setaffinity``) and sizes
-    torch's pool to it.  Returns (first cpu, count).  A single-rank run keeps the whole machine."""
+    torch's pool to it.  Returns (first cpu, count).  A single-rank run keeps the whole machine.  The slice count is the number of ranks ON THIS NODE
+    (``LOCAL_WORLD_SIZE`` of the launcher; the global ``world`` only when that is not set), so a multi-node launch still splits a node's CPUs among its
+    own ranks.  The pinning is for the life of the process (every later CPU leg and subprocess inherits it): bench.py and the launcher tests are the
+    only callers, one call per process."""
+    try:
+        world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    except ValueError:
+        pass
     if world <= 1:
         return None
     try:
