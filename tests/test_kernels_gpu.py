@@ -738,6 +738,25 @@ def test_conv_slab_kernel(dtype, case):
     out = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
     got = out.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2)
     check(got, ref, dtype, f"slab conv {case}")
+    # round 6: whole-row tiles of the 64 / 32 / 16-wide maps run on the ping-pong compute waves (tg_conv_slab_pp.hip, 16 x 16 x 32 MFMAs: another summation
+    # order inside a K-step); TG_SLAB_PP=0 keeps conv_slab_kernel, whose outputs are bit-identical to the LDS-halo kernel's
+    old_pp = os.environ.get("TG_SLAB_PP")
+    os.environ["TG_SLAB_PP"] = "0"
+    try:
+        out1 = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
+    finally:
+        if old_pp is None:
+            del os.environ["TG_SLAB_PP"]
+        else:
+            os.environ["TG_SLAB_PP"] = old_pp
+    check(out1.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2), ref, dtype, f"slab conv (one compute wave per SIMD) {case}")
+    pp_took_it = w in (16, 32, 64) and h % (128 // w) == 0
+    if not pp_took_it:
+        assert torch.equal(out, out1), "patch tiles do not run on the ping-pong kernel"
+    else:
+        check(out.float(), out1.float(), dtype, f"ping-pong slab vs one-wave slab {case}", scale=1.0)
+        again = ops.conv3x3(x0, wp, B, h, w, cin, **fkw, **kw)
+        assert torch.equal(out, again), "the ping-pong slab kernel is deterministic"
     old = os.environ.get("TG_GEMM_FLAGS")
     os.environ["TG_GEMM_FLAGS"] = "128"                     # dev flag: the planner skips the slab kernel
     try:
@@ -745,7 +764,7 @@ def test_conv_slab_kernel(dtype, case):
         assert kk != 4
         if kk == 2 and sp == 1 and plan[2] == 1:
             halo = ops.conv3x3(x0, wp, B, h, w, cin, **kw)
-            assert torch.equal(out, halo), "slab and halo kernels accumulate in the same order: outputs must be bit-identical"
+            assert torch.equal(out1, halo), "conv_slab_kernel and the halo kernel accumulate in the same order: outputs must be bit-identical"
     finally:
         if old is None:
             del os.environ["TG_GEMM_FLAGS"]

@@ -477,10 +477,20 @@ int launch_slab_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hi
 
 }  // namespace
 
+// ping-pong compute waves (tg_conv_slab_pp.hip, round 6): whole-row tiles of the 64 / 32 / 16-wide maps
+int tg_conv_slab_pp_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
+
 // Called by tg_gemm.hip's planner (not part of the C ABI); GemmParams arrives filled except for the tile bookkeeping.  With
 // splits > 1 the caller runs the reduce kernel over the tiles_m * tiles_n tail tiles of `splits` partials each.
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+  {
+    // dev A/B knob TG_SLAB_PP (default 1): 0 keeps every layer on conv_slab_kernel (one compute wave per SIMD)
+    const char* e = getenv("TG_SLAB_PP");
+    const bool on = e == nullptr || e[0] != '0';
+    if (on && p.patch_pwl == 0 && p.patch_np == 1 && p.epi_lds && (d->out_w == 64 || d->out_w == 32 || d->out_w == 16) && d->in_w == d->out_w)
+      return tg_conv_slab_pp_launch(d, params, splits, stream);
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == TG_BF16) return launch_slab_dtype<bf16_t>(d, p, splits, st);
   return launch_slab_dtype<f16_t>(d, p, splits, st);

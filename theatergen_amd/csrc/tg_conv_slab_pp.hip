@@ -1,0 +1,445 @@
+// Slab 3x3 convolution with PING-PONG compute waves (round 6; called from tg_conv_slab.hip for the whole-row tiles of the 64 / 32 / 16-wide maps).
+//
+// conv_slab_kernel (tg_conv_slab.hip) keeps ONE compute wave per SIMD: every fragment-read wait, barrier and weight-tile wait of that wave is matrix-pipe
+// idle time (duty 0.39 - 0.47, profiles/r5_pmc_sq.json; 1.0 PFLOP/s where the pipe alone sustains 1.88 on random operands, profiles/r6_mfma_sustained.json).
+// This kernel keeps that kernel's data path — 128-pixel x 320-channel tiles, the input window staged ONCE per 64-channel chunk through registers with GroupNorm
+// (+ SiLU) applied on the way, weight tiles by LDS-DMA into a ring of three 40 KB stages, four LOADER waves that never issue an MFMA, persistent XCD-chunked
+// tile walk, K splits as fp32 partial tiles — and replaces the compute side by the structure that took the plain GEMM from 0.85 to 1.3 PFLOP/s
+// (tg_gemm_pp.hip): EIGHT compute waves in two groups (pixels 0-63 / 64-127 of the tile; one wave of each group per SIMD) that run the same phase program
+// ONE BARRIER APART, so that while a wave issues its 20 MFMAs its SIMD partner reads fragments and waits for them.
+//   * wave tile 64 pixels x 80 channels = 4 x 5 MFMA tiles of 16 x 16 x 32 (80 accumulator registers; 12 waves per workgroup = three per SIMD, 168 registers);
+//   * a K-step (one tap of one 64-channel chunk) is two phases = the two 32-deep k-steps: a phase reads 4 pixel + 5 weight fragments (ds_read_b128), waits
+//     for them, crosses a barrier, issues 20 MFMAs, crosses a barrier;
+//   * loaders follow the first group's barrier count: the weight stage of K-step kt - 1 is refilled (tile kt + 2) right after its last read retired, the
+//     tile of K-step kt + 1 is waited for before the barrier that ends K-step kt; at a chunk boundary the window is rewritten between two extra barriers;
+//   * epilogue: fp32 bounce through the (dead) slab region, 16 pixels x 64 channels per wave and pass (+ one 32 x 16 pass for the last 16 channels):
+//     bias / time-embedding vector / residual loads and the stores are 16 bytes per lane on whole 128-byte rows; split work items store fp32 partial tiles
+//     in tile-local order for tg_gemm.hip's fixed-order reduce.
+// K order (chunk, tap, k) and the fp32 epilogue arithmetic are conv_slab_kernel's; the 16 x 16 x 32 MFMA sums a K-step's 64 products in another order than the
+// 32 x 32 x 16 one, so results agree with it to accumulation-order rounding, not bit for bit (tests/test_round6_gpu.py states the tolerance).
+#include "tg_gemm_common.h"
+
+namespace {
+
+template <typename T, int WI, bool PRO>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_slab_pp_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 320;
+  constexpr int TH = BM / WI, SW = WI + 2, SROWS = TH + 2, SLAB = SROWS * SW, SJ = (SLAB + 31) / 32;
+  constexpr unsigned SLAB_BYTES = SJ * 32 * 128, WST_BYTES = BN * 128, SCRATCH_BYTES = 8 * 16 * 68 * 4;
+  constexpr unsigned SLAB_PAD = SLAB_BYTES > SCRATCH_BYTES ? SLAB_BYTES : SCRATCH_BYTES, W_BASE = SLAB_PAD;
+  constexpr int WJ = BN / 32;                      // LDS-DMA instructions per loader wave per weight tile (8 rows x 128 B each)
+  static_assert(SJ <= 9, "two slab rows per thread in taps 3..5, one in taps 6..8");
+  typedef typename Vec<T>::v8 V8;
+
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int lane = threadIdx.x & 63;
+  const int wave12 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool loader = wave12 >= 8;
+
+  const int ctot = p.c0 + p.c1;
+  const int nchunks_all = ctot / BK;
+  const int S = p.tail_s, cps = p.kt_per_split;
+  const int H = p.in_h;
+  const int tiles_m = (int)(p.M / BM);
+  const int ntiles = tiles_m * p.tiles_n * S;
+
+  auto work_item = [&](int v, int& t, int& sp) {   // tg_conv_slab.hip: tile-major, or (column tile, split)-major for weight-heavy layers
+    const int lbid = xcd_chunked_block_id(v, ntiles);
+    if (p.slab_order == 1) {
+      const int combo = lbid / tiles_m, tm_ = lbid - combo * tiles_m;
+      const int tn_ = combo / S;
+      sp = combo - tn_ * S;
+      t = tm_ * p.tiles_n + tn_;
+    } else {
+      t = lbid / S;
+      sp = lbid - t * S;
+    }
+  };
+#define SLAB_BAR()                                         \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+
+  // dev timing switches (TG_GEMM_FLAGS, WRONG results by design, scripts/dev_slab_pp.py): 1 << 16 no weight DMA after the prologue, 1 << 17 no window
+  // staging after the prologue, 1 << 18 no MFMAs, 1 << 19 no fragment reads
+  const bool ab_now = (p.flags & (1 << 16)) != 0, ab_nos = (p.flags & (1 << 17)) != 0, ab_nom = (p.flags & (1 << 18)) != 0, ab_nor = (p.flags & (1 << 19)) != 0;
+  if (loader) {
+    // =========================================================== loader waves ===========================================
+    const int wave = wave12 - 8;
+    const int tid = (int)threadIdx.x - 512;
+    const T* A0 = reinterpret_cast<const T*>(p.a0);
+    const T* A1 = reinterpret_cast<const T*>(p.a1);
+    const T* Wp = reinterpret_cast<const T*>(p.w);
+    const T* zero = reinterpret_cast<const T*>(tg_zero_page);
+    const float* coef = reinterpret_cast<const float*>(p.a_coef);
+    const int wchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    auto dma = [&](const T* src, unsigned lds_byte_addr) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(lds_byte_addr) : "memory");
+    };
+    const T* wlane = nullptr;
+    int cfirst = 0, nchunks = 0, nkt = 0;
+    auto issue_w = [&](int cc, int tap, int stage) {
+      const T* src = wlane + ((long)tap * ctot + cc * BK);
+      const unsigned dst = lds0 + W_BASE + (unsigned)stage * WST_BYTES + (unsigned)wave * 1024u;
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) dma(src + (long)j * 32 * p.K, dst + (unsigned)j * 4096u);
+    };
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const unsigned sdst = (unsigned)tid * 16u;
+    int spix[SJ];
+    u32x4 sreg[SJ];
+    f32x4 ca0, ca1, cd0, cd1;
+    int img = 0;
+    auto load_slab = [&](int cc) {
+      int c = cc * BK;
+      const T* base = A0;
+      int pitch = p.c0;
+      if (c >= p.c0) { base = A1; pitch = p.c1; c -= p.c0; }
+      c += schunk * 8;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const T* src = spix[j] >= 0 ? base + (long)spix[j] * pitch + c : zero;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(sreg[j]) : "v"(src) : "memory");
+      }
+      if constexpr (PRO) {
+        const float* ca = coef + (long)img * 2 * ctot + cc * BK + schunk * 8;
+        const float* cd = ca + ctot;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ca0) : "v"(ca) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(ca1) : "v"(ca) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cd0) : "v"(cd) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(cd1) : "v"(cd) : "memory");
+      }
+    };
+    constexpr int NCOEF = PRO ? 4 : 0;
+    auto slab_landed = [&]() {
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) asm volatile("" : "+v"(sreg[j]));
+      if constexpr (PRO) asm volatile("" : "+v"(ca0), "+v"(ca1), "+v"(cd0), "+v"(cd1));
+    };
+    const bool silu = p.a_silu != 0;
+    auto xform_piece = [&](int j) {                 // normalise (+ SiLU) slab row j in its registers: tg_norm.hip's expression and rounding point
+      if constexpr (PRO) {
+        V8 v = __builtin_bit_cast(V8, sreg[j]);
+        const float a[8] = {ca0[0], ca0[1], ca0[2], ca0[3], ca1[0], ca1[1], ca1[2], ca1[3]};
+        const float d[8] = {cd0[0], cd0[1], cd0[2], cd0[3], cd1[0], cd1[1], cd1[2], cd1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = to_f32<T>(v[e]) * a[e] + d[e];
+          v[e] = from_f32<T>(silu ? silu_f(f) : f);
+        }
+        u32x4 r = __builtin_bit_cast(u32x4, v);
+        const bool ok = spix[j] >= 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ok ? r[e] : 0u;
+        sreg[j] = r;
+      }
+    };
+    auto write_slab = [&]() {
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) *reinterpret_cast<u32x4*>(smem + sdst + (unsigned)j * 4096u) = sreg[j];
+    };
+    auto setup_tile = [&](int v) {
+      int t, sp;
+      work_item(v, t, sp);
+      const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+      const long n0 = (long)tile_n * BN;
+      cfirst = sp * cps;
+      nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
+      nkt = nchunks * 9;
+      const int tpi = H / TH;                       // whole-row tiles: TH image rows per tile
+      img = tile_m / tpi;
+      const int y0 = (tile_m - img * tpi) * TH;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const int sr = (tid >> 3) + 32 * j;
+        const int sy = sr / SW, sx = sr - sy * SW;
+        const int iy = y0 - 1 + sy, ix = sx - 1;
+        const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI;
+        spix[j] = ok ? (img * H + iy) * WI + ix : -1;
+      }
+      wlane = Wp + (n0 + wave * 8 + (lane >> 3)) * p.K + wchunk * 8;
+    };
+    auto prologue = [&](int v) {
+      setup_tile(v);
+      issue_w(cfirst, 0, 0);
+      load_slab(cfirst);
+      issue_w(cfirst, 1, 1);
+      issue_w(cfirst, 2, 2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WJ) : "memory");
+      slab_landed();
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) xform_piece(j);
+    };
+
+    int v = blockIdx.x;
+    if (v < ntiles) prologue(v);
+    for (; v < ntiles; v += gridDim.x) {
+      SLAB_BAR();                                   // S1: the compute waves are out of their epilogue, the slab region is free
+      write_slab();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SLAB_BAR();                                   // S2: window chunk 0 and weight tile 0 are in place
+      int kt = 0;
+      for (int cc = 0; cc < nchunks; ++cc) {
+        const bool more = cc + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++kt) {
+          // Every read of the previous K-step's weight stage retired before the barrier that ended it: it is refilled with tile kt + 2 — the ten
+          // requests and the window arithmetic SPREAD over the four barrier intervals of the K-step (first build: all of it in front of barrier #0,
+          // where every compute wave waited for the loaders: 354 us on 64 x 64 960 -> 320 against 278 with the requests switched off)
+          const bool refill = kt >= 1 && kt + 2 < nkt && !ab_now;
+          const int t2 = tap + 2;
+          const int rcc = cfirst + (t2 >= 9 ? cc + 1 : cc), rtap = t2 >= 9 ? t2 - 9 : t2;
+          auto issue_part = [&](int j0, int j1) {
+            if (!refill) return;
+            const T* src = wlane + ((long)rtap * ctot + rcc * BK);
+            const unsigned dst = lds0 + W_BASE + (unsigned)(t2 % 3) * WST_BYTES + (unsigned)wave * 1024u;
+#pragma unroll
+            for (int j = j0; j < j1; ++j) dma(src + (long)j * 32 * p.K, dst + (unsigned)j * 4096u);
+          };
+          const bool stage_now = more && !ab_nos;
+          issue_part(0, 3);
+          if (stage_now) {
+            if (tap >= 3 && tap <= 5) xform_piece(2 * (tap - 3));
+            if (tap >= 6 && tap < SJ) xform_piece(tap);
+          }
+          SLAB_BAR();                               // #0
+          issue_part(3, 6);
+          if (stage_now && tap >= 3 && tap <= 5 && 2 * (tap - 3) + 1 < SJ) xform_piece(2 * (tap - 3) + 1);
+          SLAB_BAR();                               // #1
+          issue_part(6, 8);
+          SLAB_BAR();                               // #2
+          issue_part(8, WJ);
+          // the next chunk's window is requested BEHIND tile kt + 2 (vmcnt retires in order: the counted waits below rely on this queue order)
+          if (tap == 0 && stage_now) load_slab(cfirst + cc + 1);
+          // weight tile kt + 1 has landed before the barrier that ends K-step kt; tile kt + 2 and (taps 0, 1) the window loads may stay in flight
+          if (ab_now || ab_nos) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (kt + 2 < nkt) {
+            if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + SJ + NCOEF) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
+          } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tap == 2 && more) slab_landed();
+          SLAB_BAR();                               // #3
+          if (tap == 8 && more) {                   // chunk boundary: both groups' last window reads retired before #3
+            if (!ab_nos) write_slab();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SLAB_BAR();                             // Xa
+            SLAB_BAR();                             // Xb
+          }
+        }
+      }
+      SLAB_BAR();                                   // E: the second group's last MFMA phase
+      const int vn = v + (int)gridDim.x;
+      if (vn < ntiles) prologue(vn);                // under the compute waves' epilogue
+    }
+    return;
+  }
+
+  // ============================================================= compute waves =============================================
+  const int group = wave12 >> 2;                   // 0: pixels 0-63 of the tile, 1: pixels 64-127; waves w and w + 4 share a SIMD
+  const int wave_n = wave12 & 3;                    // 80-channel column of the tile
+  const int frow = lane & 15, fq = lane >> 4;
+  const unsigned fkey = (unsigned)((frow >> 1) & 7);
+  const unsigned aw0 = lds0 + W_BASE + (unsigned)((wave_n * 80 + frow) * 128) + ((((unsigned)fq) ^ fkey) << 4);
+  int srow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pm = group * 64 + i * 16 + frow;
+    srow[i] = (pm / WI) * SW + pm % WI;
+  }
+  u32x4 xf[4] = {}, wf[5] = {};
+  f32x4 acc[4][5];
+#define SPP_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  auto phase = [&](int tap, int ks) {
+    // fragments of k-step ks of this tap: pixel rows srow[i] + tap offset of the window, weight rows of stage tap % 3
+    const int off = (tap / 3) * SW + tap % 3;
+    const unsigned kx = (unsigned)ks << 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned sr = (unsigned)(srow[i] + off);
+      const unsigned a = (lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4)) ^ kx;
+      if (!ab_nor) SPP_READ(xf[i], a, 0);
+    }
+    const unsigned aw = (aw0 + (unsigned)(tap % 3) * WST_BYTES) ^ kx;
+    if (!ab_nor) {
+      SPP_READ(wf[0], aw, 0);
+      SPP_READ(wf[1], aw, 2048);
+      SPP_READ(wf[2], aw, 4096);
+      SPP_READ(wf[3], aw, 6144);
+      SPP_READ(wf[4], aw, 8192);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SLAB_BAR();
+    if (!ab_nom) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xf[i]), acc[i][j]);
+    }
+    SLAB_BAR();
+  };
+#undef SPP_READ
+
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    int t, sp;
+    work_item(v, t, sp);
+    const int lbid = t * S + sp;
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+    const int nchunks = nchunks_all - sp * cps < cps ? nchunks_all - sp * cps : cps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    SLAB_BAR();                                     // S1
+    SLAB_BAR();                                     // S2
+    if (group == 1) SLAB_BAR();                     // the second group runs one barrier behind the first
+    for (int cc = 0; cc < nchunks; ++cc) {
+      const bool more = cc + 1 < nchunks;
+      asm volatile("" : "+v"(srow[0]), "+v"(srow[1]), "+v"(srow[2]), "+v"(srow[3]));   // per-tap addresses are recomputed, not hoisted over the chunk loop
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        phase(tap, 0);
+        phase(tap, 1);
+        if (tap == 8 && more) { SLAB_BAR(); SLAB_BAR(); }      // Xa, Xb: the loaders rewrite the window
+      }
+    }
+    if (group == 0) SLAB_BAR();                     // E
+
+    // ---- epilogue: fp32 bounce through this wave's 4352 bytes of the slab region
+    float* scr = reinterpret_cast<float*>(smem) + wave12 * (16 * 68);
+    const long mw = m0 + group * 64, nw = n0 + wave_n * 80;
+    T* outp = reinterpret_cast<T*>(p.out);
+    const T* biasp = reinterpret_cast<const T*>(p.bias);
+    const T* bvecp = reinterpret_cast<const T*>(p.bvec);
+    const T* resp = reinterpret_cast<const T*>(p.res);
+    const float scale = p.out_scale;
+    const bool part = S > 1;
+    float* wsp = part ? p.ws + (long)lbid * BM * BN : nullptr;
+    auto finish8 = [&](const f32x4& lo, const f32x4& hi, long m, long n, const float (&bias_f)[8]) {
+      if (part) {                                   // fp32 partial in tile-local order: the reduce kernel sums the splits and applies the epilogue
+        float* q = wsp + (m - m0) * BN + (n - n0);
+        *reinterpret_cast<f32x4*>(q) = lo;
+        *reinterpret_cast<f32x4*>(q + 4) = hi;
+        return;
+      }
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] = lo[e] + bias_f[e]; x[4 + e] = hi[e] + bias_f[4 + e]; }
+      if (bvecp != nullptr) {
+        const V8 a8 = *reinterpret_cast<const V8*>(bvecp + (m / p.rows_per_batch) * p.ldbvec + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(a8[e]);
+      }
+      if (resp != nullptr) {
+        const V8 r8 = *reinterpret_cast<const V8*>(resp + m * p.ldres + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(r8[e]);
+      }
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e] * scale);
+      *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
+    };
+    {
+      // channels 0-63 of the wave's 80: 16 pixels x 64 channels per pass, lane -> (row lane / 8 + 8 it, 8-channel piece lane % 8)
+      const int c = lane & 7, r0 = lane >> 3;
+      const long n = nw + c * 8;
+      float bias_f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
+      if (biasp != nullptr && !part) {
+        const V8 b8 = *reinterpret_cast<const V8*>(biasp + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(scr + frow * 68 + 16 * j + 4 * fq) = acc[i][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + (it * 8 + r0) * 68 + c * 8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + (it * 8 + r0) * 68 + c * 8 + 4);
+          finish8(lo, hi, mw + i * 16 + it * 8 + r0, n, bias_f);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    {
+      // channels 64-79: two pixel tiles per pass = 32 pixels x 16 channels, lane -> (row lane / 2, 8-channel piece lane % 2)
+      const int c = lane & 1, r = lane >> 1;
+      const long n = nw + 64 + c * 8;
+      float bias_f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
+      if (biasp != nullptr && !part) {
+        const V8 b8 = *reinterpret_cast<const V8*>(biasp + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_f[e] = to_f32<T>(b8[e]);
+      }
+#pragma unroll
+      for (int ip = 0; ip < 2; ++ip) {
+        *reinterpret_cast<f32x4*>(scr + frow * 20 + 4 * fq) = acc[2 * ip][4];
+        *reinterpret_cast<f32x4*>(scr + (16 + frow) * 20 + 4 * fq) = acc[2 * ip + 1][4];
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8 + 4);
+        finish8(lo, hi, mw + ip * 32 + r, n, bias_f);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+#undef SLAB_BAR
+}
+
+template <typename T, int WI, bool PRO>
+int launch_slab_pp(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st) {
+  constexpr int BM = 128, TH = BM / WI, SLAB = (TH + 2) * (WI + 2), SJ = (SLAB + 31) / 32;
+  constexpr size_t slab = (size_t)SJ * 32 * 128, scratch = 8 * 16 * 68 * 4;
+  const size_t lds = (slab > scratch ? slab : scratch) + 3 * (size_t)320 * 128;
+  const long tiles_m = d->M / BM, tiles_n = d->N / 320;
+  const int nchunks = (d->c0 + (d->a1 ? d->c1 : 0)) / BK;
+  p.tiles_n = (int)tiles_n;
+  p.full_tiles = 0;
+  p.tail_s = splits;
+  p.kt_per_split = (nchunks + splits - 1) / splits;
+  p.tile_bm = BM; p.tile_bn = 320;
+  p.slab_order = ((long)d->N * d->K > (long)d->M * (d->K / 9) && !(p.flags & 8192)) ? 1 : 0;
+  long grid = tiles_m * tiles_n * splits;
+  if (grid > 256) grid = 256;
+  auto k = conv_slab_pp_kernel<T, WI, PRO>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(768), lds, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
+}
+
+template <typename T>
+int launch_slab_pp_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hipStream_t st) {
+  const bool pro = d->a_coef != nullptr;
+#define TG_SPP_CASE(W) \
+  if (d->out_w == W) return pro ? launch_slab_pp<T, W, true>(d, p, splits, st) : launch_slab_pp<T, W, false>(d, p, splits, st);
+  TG_SPP_CASE(64)
+  TG_SPP_CASE(32)
+  TG_SPP_CASE(16)
+#undef TG_SPP_CASE
+  tg_set_error("tg_gemm conv: no ping-pong slab kernel for width %d", d->out_w);
+  return TG_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// Called by tg_conv_slab.hip (not part of the C ABI) for whole-row tiles (patch_pwl == 0, one patch per tile) with 16-byte aligned epilogue operands.
+int tg_conv_slab_pp_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {
+  const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == TG_BF16) return launch_slab_pp_dtype<bf16_t>(d, p, splits, st);
+  return launch_slab_pp_dtype<f16_t>(d, p, splits, st);
+}
