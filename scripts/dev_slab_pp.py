@@ -67,8 +67,9 @@ for (h, cin, c1, cout, n) in [(64, 320, 0, 320, 7), (64, 320, 320, 320, 2), (64,
     print(f"{h:3d}x{h:<3d} {ctot:5d} -> {cout:5d}    {t_new:7.1f} {fl / t_new / 1e6:5.0f}      {t_old:7.1f} {fl / t_old / 1e6:5.0f}      x{n}   rel diff {err:.1e}", flush=True)
 print(f"per step (launch-weighted): ping-pong {tot_new:.0f} us, one wave / SIMD {tot_old:.0f} us")
 
-# ---- where does a K-step go?  dev switches of the ping-pong kernel (wrong results by design)
-print("ablations of the ping-pong kernel, 64x64 960 -> 320 and 32x32 640 -> 640 (us):")
+
+# ---- where does a K-step go?  dev switches of the two-waves-per-SIMD kernel (wrong results by design)
+print("dev switches (us):")
 for (h, cin, c1, cout) in [(64, 640, 320, 320), (32, 640, 0, 640), (16, 1280, 0, 1280)]:
     g = torch.Generator().manual_seed(1)
     ctot, M = cin + c1, B * h * h
@@ -79,8 +80,8 @@ for (h, cin, c1, cout) in [(64, 640, 320, 320), (32, 640, 0, 640), (16, 1280, 0,
     coef = ops.groupnorm_coef(x0, B, h * h, 32, 1e-5, torch.ones(ctot, device=dev, dtype=dt), torch.zeros(ctot, device=dev, dtype=dt), x1=x1)
     fns = [(lambda wp=wp: ops.conv3x3(x0, wp, B, h, h, cin, x1=x1, c1=c1, bias=bias, a_coef=coef, a_silu=True)) for wp in wps]
     row = f"{h}x{h} {ctot}->{cout}: "
-    for name, fl in (("full", 0), ("no weight DMA", 1 << 16), ("no window staging", 1 << 17), ("no DMA, no window", 3 << 16), ("no MFMA", 1 << 18), ("no fragment reads", 1 << 19),
-                     ("MFMA + barriers only", (1 << 16) | (1 << 17) | (1 << 19)), ("old kernel", -1)):
+    for name, fl in (("full", 0), ("no weight DMA", 1 << 16), ("no window staging", 1 << 17), ("no DMA, no window", 3 << 16), ("no MFMA", 1 << 18),
+                     ("loaders only (no MFMA)", 1 << 18), ("no DMA, no window, no MFMA", 7 << 16), ("old kernel", -1)):
         if fl < 0:
             t = with_env("TG_SLAB_PP", "0", lambda: timeit(fns))
         else:

@@ -750,7 +750,7 @@ def test_conv_slab_kernel(dtype, case):
         else:
             os.environ["TG_SLAB_PP"] = old_pp
     check(out1.float().cpu().reshape(B, h, w, cout).permute(0, 3, 1, 2), ref, dtype, f"slab conv (one compute wave per SIMD) {case}")
-    pp_took_it = w in (16, 32, 64) and h % (128 // w) == 0
+    pp_took_it = w in (16, 32, 64) and h % (128 // w) == 0  # default TG_SLAB_PP = 2: whole-row tiles of the 64 / 32 / 16-wide maps
     if not pp_took_it:
         assert torch.equal(out, out1), "patch tiles do not run on the ping-pong kernel"
     else:

@@ -485,10 +485,14 @@ int tg_conv_slab_pp_launch(const tg_gemm_desc* d, const void* params, int splits
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   {
-    // dev A/B knob TG_SLAB_PP (default 1): 0 keeps every layer on conv_slab_kernel (one compute wave per SIMD)
+    // TG_SLAB_PP (dev A/B knob): 0 keeps every layer on conv_slab_kernel (one compute wave per SIMD), 1 = the two-waves-per-SIMD kernel on the 64-wide
+    // maps only, 2 (default) = on the 32- and 16-wide maps as well.  Isolated launches (scripts/dev_slab_pp.py): 64 x 64 layers 4-6 % faster, 32 x 32 equal,
+    // 16 x 16 (split tiles) 5-10 % slower; under graph replay, same box, interleaved (profiles/r6_ab_slab2w.json): 864.3 -> 859.3 (mode 1) -> 855.3 ms per
+    // story (mode 2, +1.05 %): the whole-step evidence decides.
     const char* e = getenv("TG_SLAB_PP");
-    const bool on = e == nullptr || e[0] != '0';
-    if (on && p.patch_pwl == 0 && p.patch_np == 1 && p.epi_lds && (d->out_w == 64 || d->out_w == 32 || d->out_w == 16) && d->in_w == d->out_w)
+    const int mode = e == nullptr ? 2 : (int)strtol(e, nullptr, 0);
+    const bool w_ok = d->out_w == 64 || (mode >= 2 && (d->out_w == 32 || d->out_w == 16));
+    if (mode >= 1 && w_ok && p.patch_pwl == 0 && p.patch_np == 1 && p.epi_lds && d->in_w == d->out_w)
       return tg_conv_slab_pp_launch(d, params, splits, stream);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

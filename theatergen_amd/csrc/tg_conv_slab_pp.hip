@@ -1,22 +1,24 @@
-// Slab 3x3 convolution with PING-PONG compute waves (round 6; called from tg_conv_slab.hip for the whole-row tiles of the 64 / 32 / 16-wide maps).
+// Slab 3x3 convolution with TWO compute waves per SIMD (round 6; called from tg_conv_slab.hip for the whole-row tiles of the 64 / 32 / 16-wide maps).
 //
-// conv_slab_kernel (tg_conv_slab.hip) keeps ONE compute wave per SIMD: every fragment-read wait, barrier and weight-tile wait of that wave is matrix-pipe
-// idle time (duty 0.39 - 0.47, profiles/r5_pmc_sq.json; 1.0 PFLOP/s where the pipe alone sustains 1.88 on random operands, profiles/r6_mfma_sustained.json).
-// This kernel keeps that kernel's data path — 128-pixel x 320-channel tiles, the input window staged ONCE per 64-channel chunk through registers with GroupNorm
-// (+ SiLU) applied on the way, weight tiles by LDS-DMA into a ring of three 40 KB stages, four LOADER waves that never issue an MFMA, persistent XCD-chunked
-// tile walk, K splits as fp32 partial tiles — and replaces the compute side by the structure that took the plain GEMM from 0.85 to 1.3 PFLOP/s
-// (tg_gemm_pp.hip): EIGHT compute waves in two groups (pixels 0-63 / 64-127 of the tile; one wave of each group per SIMD) that run the same phase program
-// ONE BARRIER APART, so that while a wave issues its 20 MFMAs its SIMD partner reads fragments and waits for them.
-//   * wave tile 64 pixels x 80 channels = 4 x 5 MFMA tiles of 16 x 16 x 32 (80 accumulator registers; 12 waves per workgroup = three per SIMD, 168 registers);
-//   * a K-step (one tap of one 64-channel chunk) is two phases = the two 32-deep k-steps: a phase reads 4 pixel + 5 weight fragments (ds_read_b128), waits
-//     for them, crosses a barrier, issues 20 MFMAs, crosses a barrier;
-//   * loaders follow the first group's barrier count: the weight stage of K-step kt - 1 is refilled (tile kt + 2) right after its last read retired, the
-//     tile of K-step kt + 1 is waited for before the barrier that ends K-step kt; at a chunk boundary the window is rewritten between two extra barriers;
+// conv_slab_kernel (tg_conv_slab.hip) keeps ONE compute wave per SIMD (wave tile 64 x 160, 160 accumulator registers, 256-register budget, 47-195 spilled
+// VGPRs): every fragment-read wait, barrier and weight-tile wait of that wave is matrix-pipe idle time (duty 0.39 - 0.47, profiles/r5_pmc_sq.json; ~1.0 PFLOP/s
+// where the pipe alone sustains 1.88 on random operands, profiles/r6_mfma_sustained.json).  This kernel keeps that kernel's data path and barrier protocol —
+// 128-pixel x 320-channel tiles, the input window staged ONCE per 64-channel chunk through registers with GroupNorm (+ SiLU) applied on the way, weight tiles
+// by LDS-DMA into a ring of three 40 KB stages, four LOADER waves that never issue an MFMA, ONE workgroup barrier per K-step, persistent XCD-chunked tile walk,
+// K splits as fp32 partial tiles — and gives every SIMD TWO compute waves on 16 x 16 x 32 MFMAs:
+//   * wave tile 64 pixels x 80 channels = 4 x 5 MFMA tiles (80 accumulator registers; 12 waves per workgroup = three per SIMD, 168-register budget, no spills);
+//   * a K-step (one tap of one 64-channel chunk) is two phases = its two 32-deep k-steps of 20 MFMAs; fragments are software-pipelined ONE PHASE ahead
+//     (inline-asm ds_read_b128, hand-counted lgkmcnt): the four pixel fragments of the next phase are requested at the top of a phase (two register sets),
+//     weight fragment j right behind the four MFMAs of column j; the K-step's barrier sits between its two phases (every read of the stage has returned, the
+//     next tile has landed), so the second phase already reads the next K-step's first fragments;
+//   * the two waves of a SIMD are synchronised by that barrier only: one fills the other's waits;
 //   * epilogue: fp32 bounce through the (dead) slab region, 16 pixels x 64 channels per wave and pass (+ one 32 x 16 pass for the last 16 channels):
 //     bias / time-embedding vector / residual loads and the stores are 16 bytes per lane on whole 128-byte rows; split work items store fp32 partial tiles
 //     in tile-local order for tg_gemm.hip's fixed-order reduce.
-// K order (chunk, tap, k) and the fp32 epilogue arithmetic are conv_slab_kernel's; the 16 x 16 x 32 MFMA sums a K-step's 64 products in another order than the
-// 32 x 32 x 16 one, so results agree with it to accumulation-order rounding, not bit for bit (tests/test_round6_gpu.py states the tolerance).
+// (First build of the round: the two compute groups one barrier apart, tg_gemm_pp.hip's schedule — four barriers per K-step, a phase's nine reads took ~480
+// cycles against 320 of MFMA: no faster than conv_slab_kernel, scripts/dev_slab_pp.py ablations in profiles/r6_slab_findings.md.)
+// K order (chunk, tap, k) and the fp32 epilogue arithmetic are conv_slab_kernel's; measured outputs are bit-identical to it (the 16 x 16 x 32 MFMA evidently
+// folds a K-step's products in the same order as two 32 x 32 x 16 ones); the tests do not rely on that: they state a tolerance.
 #include "tg_gemm_common.h"
 
 namespace {
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_sched_barrier(0);                     \
   } while (0)
 
-  // dev timing switches (TG_GEMM_FLAGS, WRONG results by design, scripts/dev_slab_pp.py): 1 << 16 no weight DMA after the prologue, 1 << 17 no window
-  // staging after the prologue, 1 << 18 no MFMAs, 1 << 19 no fragment reads
-  const bool ab_now = (p.flags & (1 << 16)) != 0, ab_nos = (p.flags & (1 << 17)) != 0, ab_nom = (p.flags & (1 << 18)) != 0, ab_nor = (p.flags & (1 << 19)) != 0;
+  // dev timing switches (TG_GEMM_FLAGS, WRONG results by design; scripts/dev_slab_pp.py -> profiles/r6_slab_findings.md): 1 << 16 no weight DMA after the
+  // prologue, 1 << 17 no window staging after the prologue, 1 << 18 no MFMAs
+  const bool ab_now = (p.flags & (1 << 16)) != 0, ab_nos = (p.flags & (1 << 17)) != 0, ab_nom = (p.flags & (1 << 18)) != 0;
   if (loader) {
     // =========================================================== loader waves ===========================================
     const int wave = wave12 - 8;
@@ -188,51 +190,32 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bool more = cc + 1 < nchunks;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++kt) {
-          // Every read of the previous K-step's weight stage retired before the barrier that ended it: it is refilled with tile kt + 2 — the ten
-          // requests and the window arithmetic SPREAD over the four barrier intervals of the K-step (first build: all of it in front of barrier #0,
-          // where every compute wave waited for the loaders: 354 us on 64 x 64 960 -> 320 against 278 with the requests switched off)
-          const bool refill = kt >= 1 && kt + 2 < nkt && !ab_now;
-          const int t2 = tap + 2;
-          const int rcc = cfirst + (t2 >= 9 ? cc + 1 : cc), rtap = t2 >= 9 ? t2 - 9 : t2;
-          auto issue_part = [&](int j0, int j1) {
-            if (!refill) return;
-            const T* src = wlane + ((long)rtap * ctot + rcc * BK);
-            const unsigned dst = lds0 + W_BASE + (unsigned)(t2 % 3) * WST_BYTES + (unsigned)wave * 1024u;
+          // the next chunk's window: requested at tap 0, landed by the seam of tap 2, normalised in registers in taps 3..8
+          if (tap == 0 && more && !ab_nos) load_slab(cfirst + cc + 1);
+          if (more && !ab_nos) {
 #pragma unroll
-            for (int j = j0; j < j1; ++j) dma(src + (long)j * 32 * p.K, dst + (unsigned)j * 4096u);
-          };
-          const bool stage_now = more && !ab_nos;
-          issue_part(0, 3);
-          if (stage_now) {
-            if (tap >= 3 && tap <= 5) xform_piece(2 * (tap - 3));
-            if (tap >= 6 && tap < SJ) xform_piece(tap);
+            for (int j = 0; j < SJ; ++j)
+              if ((tap >= 3 && tap <= 5 && j / 2 == tap - 3) || (tap >= 6 && j == tap)) xform_piece(j);
           }
-          SLAB_BAR();                               // #0
-          issue_part(3, 6);
-          if (stage_now && tap >= 3 && tap <= 5 && 2 * (tap - 3) + 1 < SJ) xform_piece(2 * (tap - 3) + 1);
-          SLAB_BAR();                               // #1
-          issue_part(6, 8);
-          SLAB_BAR();                               // #2
-          issue_part(8, WJ);
-          // the next chunk's window is requested BEHIND tile kt + 2 (vmcnt retires in order: the counted waits below rely on this queue order)
-          if (tap == 0 && stage_now) load_slab(cfirst + cc + 1);
-          // weight tile kt + 1 has landed before the barrier that ends K-step kt; tile kt + 2 and (taps 0, 1) the window loads may stay in flight
+          // seam of K-step kt: weight tile kt + 1 (requested TWO K-steps ago) has landed; tile kt + 2 and, in taps 0 and 1, the window loads may stay in flight
           if (ab_now || ab_nos) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else if (kt + 2 < nkt) {
             if (tap <= 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + SJ + NCOEF) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");
           } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (tap == 2 && more) slab_landed();
-          SLAB_BAR();                               // #3
-          if (tap == 8 && more) {                   // chunk boundary: both groups' last window reads retired before #3
+          SLAB_BAR();
+          if (kt + 3 < nkt && !ab_now) {            // every compute wave's reads of stage tap % 3 have returned: refill it
+            const int t3 = tap + 3;
+            issue_w(cfirst + (t3 >= 9 ? cc + 1 : cc), t3 >= 9 ? t3 - 9 : t3, tap % 3);
+          }
+          if (tap == 8 && more) {                   // chunk boundary: the window has been read for the last time
             if (!ab_nos) write_slab();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            SLAB_BAR();                             // Xa
-            SLAB_BAR();                             // Xb
+            SLAB_BAR();                             // X: the next chunk's window is in place
           }
         }
       }
-      SLAB_BAR();                                   // E: the second group's last MFMA phase
       const int vn = v + (int)gridDim.x;
       if (vn < ntiles) prologue(vn);                // under the compute waves' epilogue
     }
@@ -251,38 +234,51 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int pm = group * 64 + i * 16 + frow;
     srow[i] = (pm / WI) * SW + pm % WI;
   }
-  u32x4 xf[4] = {}, wf[5] = {};
-  f32x4 acc[4][5];
-#define SPP_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-  auto phase = [&](int tap, int ks) {
-    // fragments of k-step ks of this tap: pixel rows srow[i] + tap offset of the window, weight rows of stage tap % 3
+  // Fragment pipeline (inline asm reads stay where they are written; LDS returns in order).  Issue order of a phase: 4 pixel fragments of the NEXT phase,
+  // then per column j: wait, 4 MFMAs, weight fragment j of the next phase.  Reads issued after w[j] of the current phase and before its use:
+  // w[j+1..4] (previous phase), 4 pixel fragments, w[0..j-1] (this phase) = 8 for every j -> lgkmcnt(8); without the pixel reads (chunk boundary) 4.
+  unsigned ax[4], aw;
+  auto set_x = [&](int tap) {
     const int off = (tap / 3) * SW + tap % 3;
-    const unsigned kx = (unsigned)ks << 6;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned sr = (unsigned)(srow[i] + off);
-      const unsigned a = (lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4)) ^ kx;
-      if (!ab_nor) SPP_READ(xf[i], a, 0);
+      ax[i] = lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4);
     }
-    const unsigned aw = (aw0 + (unsigned)(tap % 3) * WST_BYTES) ^ kx;
-    if (!ab_nor) {
-      SPP_READ(wf[0], aw, 0);
-      SPP_READ(wf[1], aw, 2048);
-      SPP_READ(wf[2], aw, 4096);
-      SPP_READ(wf[3], aw, 6144);
-      SPP_READ(wf[4], aw, 8192);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SLAB_BAR();
-    if (!ab_nom) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xf[i]), acc[i][j]);
-    }
-    SLAB_BAR();
   };
-#undef SPP_READ
+  auto set_w = [&](int tap) { aw = aw0 + (unsigned)(tap % 3) * WST_BYTES; };
+  auto read_x = [&](u32x4 (&xf)[4], int ks) {
+    const unsigned kx = (unsigned)ks << 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[i]) : "v"(ax[i] ^ kx));
+  };
+  auto read_w = [&](u32x4& wf, int j, int ks) {
+    const unsigned a = aw ^ ((unsigned)ks << 6);
+    if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(wf) : "v"(a));
+    if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf) : "v"(a));
+    if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf) : "v"(a));
+    if (j == 3) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(wf) : "v"(a));
+    if (j == 4) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf) : "v"(a));
+  };
+  f32x4 acc[4][5];
+  // one phase: MFMAs on (xc, wf); next_x: request the next phase's pixel fragments (k-step nks of the addresses in ax) into xn first; next_w: re-read
+  // wf[j] for the next phase (k-step nks of stage aw) behind column j
+  auto phase = [&](const u32x4 (&xc)[4], u32x4 (&xn)[4], u32x4 (&wf)[5], int nks, bool next_x, bool next_w) {
+    if (next_x) read_x(xn, nks);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (next_x) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!ab_nom) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xc[i]), acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (next_w) read_w(wf[j], j, nks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
     int t, sp;
@@ -297,18 +293,40 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     SLAB_BAR();                                     // S1
     SLAB_BAR();                                     // S2
-    if (group == 1) SLAB_BAR();                     // the second group runs one barrier behind the first
+    u32x4 xa[4], xb[4], wf[5];
+    set_x(0);
+    set_w(0);
+    read_x(xa, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) read_w(wf[j], j, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
       const bool more = cc + 1 < nchunks;
       asm volatile("" : "+v"(srow[0]), "+v"(srow[1]), "+v"(srow[2]), "+v"(srow[3]));   // per-tap addresses are recomputed, not hoisted over the chunk loop
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        phase(tap, 0);
-        phase(tap, 1);
-        if (tap == 8 && more) { SLAB_BAR(); SLAB_BAR(); }      // Xa, Xb: the loaders rewrite the window
+        // first phase (k-step 0); the second k-step's fragments come from the same window rows / weight stage
+        phase(xa, xb, wf, 1, true, true);
+        // seam: every read of this K-step's weight stage (and, at tap 8, of the window) has been issued: wait for them, then the workgroup barrier —
+        // behind it the loaders refill the stage, and the second phase reads the NEXT K-step's first fragments (its tile has landed)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SLAB_BAR();
+        const bool last = !more && tap == 8;
+        if (!last) { set_w(tap == 8 ? 0 : tap + 1); if (tap != 8) set_x(tap + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8) {
+          // chunk boundary: the loaders are rewriting the window — weight fragments now, pixel fragments behind barrier X
+          phase(xb, xa, wf, 0, false, !last);
+          if (more) {
+            SLAB_BAR();                             // X
+            set_x(0);
+            read_x(xa, 0);
+          }
+        } else {
+          phase(xb, xa, wf, 0, true, true);
+        }
       }
     }
-    if (group == 0) SLAB_BAR();                     // E
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // ---- epilogue: fp32 bounce through this wave's 4352 bytes of the slab region
     float* scr = reinterpret_cast<float*>(smem) + wave12 * (16 * 68);
