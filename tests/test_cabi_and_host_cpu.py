@@ -405,14 +405,19 @@ def test_gemm_planner_kernel_choice(monkeypatch):
         return d
     assert plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(65536, 320, 320))[3] == 0
     assert plan(gemm(65536, 2560, 320, geglu=1)) == (256, 256, 1, 3)          # fused GEGLU FF1 on the big tile
-    # round 5: tile-count-aware 128 x 160 tiles where they fill whole rounds (512 / 256 tiles) and 128 x 128 does not (640 / 320)
-    assert plan(gemm(16384, 640, 2560))[:2] == (128, 160) and plan(gemm(16384, 640, 640))[:2] == (128, 160) and plan(gemm(4096, 1280, 1280))[:2] == (128, 160)
+    # round 5: tile-count-aware 128 x 160 tiles where they fill whole rounds (512 / 256 tiles) and 128 x 128 does not (640 / 320); round 6 moves the
+    # M = 16384 / 65536 ones of them to the ping-pong 256 x 160 tiles (kind 7; TG_PP bit 3)
+    assert plan(gemm(4096, 1280, 1280))[:2] == (128, 160)
+    assert plan(gemm(16384, 640, 2560)) == (256, 160, 1, 7) and plan(gemm(16384, 640, 640)) == (256, 160, 1, 7) and plan(gemm(16384, 1920, 640)) == (256, 160, 1, 7)
+    assert plan(gemm(512, 320, 640, force_tile=25)) == (256, 160, 1, 7)
+    monkeypatch.setenv("TG_PP", "7")
+    assert plan(gemm(16384, 640, 2560))[:2] == (128, 160) and plan(gemm(16384, 640, 640))[:2] == (128, 160)
     assert plan(gemm(65536, 320, 320))[:2] == (128, 128) and plan(gemm(1024, 1280, 1280))[:2] == (64, 64)
     # round 6: the ping-pong 256 x 256 tiles (kernel_kind 7) where M, N are multiples of 256, K >= 640 and the tiles fill the persistent grid's rounds:
     # the FeedForward GEGLU GEMMs of the 32 x 32 / 16 x 16 levels, SDXL's batch-2 shapes; short K, ragged N and small grids keep their kernels
     assert plan(gemm(4096, 10240, 1280)) == (256, 256, 1, 7) and plan(gemm(4096, 10240, 1280, geglu=1)) == (256, 256, 1, 7)
     assert plan(gemm(16384, 5120, 640, geglu=1)) == (256, 256, 1, 7) and plan(gemm(2048, 10240, 1280, geglu=1)) == (256, 256, 1, 7)
-    assert plan(gemm(4096, 1280, 5120))[3] != 7 and plan(gemm(16384, 1920, 640))[3] != 7 and plan(gemm(65536, 2560, 320, geglu=1))[3] == 3
+    assert plan(gemm(4096, 1280, 5120))[3] != 7 and plan(gemm(65536, 2560, 320, geglu=1))[3] == 3
     assert plan(gemm(512, 512, 640, force_tile=24)) == (256, 256, 1, 7)
     bad = gemm(300, 512, 640, force_tile=24)
     assert h.tg_gemm(C.byref(bad), None) != 0 and b"force_tile 24" in h.tg_last_error()
@@ -421,12 +426,15 @@ def test_gemm_planner_kernel_choice(monkeypatch):
     monkeypatch.setenv("TG_PP", "1")
     assert plan(gemm(4096, 10240, 1280))[3] != 7 and plan(gemm(4096, 10240, 1280, geglu=1))[3] == 7
     monkeypatch.delenv("TG_PP")
+    assert plan(gemm(65536, 320, 1280)) == (256, 160, 1, 7)
+    monkeypatch.setenv("TG_PP", "7")
     assert plan(gemm(65536, 320, 1280))[:2] == (128, 160)                     # N = 320 = 2.5 tiles of 128: a sixth of the MFMA work would be padding
     monkeypatch.setenv("TG_T160", "3")
     assert plan(gemm(65536, 320, 1280))[:2] == (128, 128) and plan(gemm(16384, 640, 640))[:2] == (128, 160)
     monkeypatch.setenv("TG_T160", "0")
     assert plan(gemm(16384, 640, 2560))[:2] == (128, 128)
     monkeypatch.delenv("TG_T160")
+    monkeypatch.delenv("TG_PP")
 
 
 def test_shift_tensor_ignore_last_dim_matches_reference_formula():

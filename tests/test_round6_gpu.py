@@ -108,6 +108,67 @@ def test_pp_gemm_qkv_split_geglu_and_layernorm_fold(dtype):
     check(gl, yn[:, :N2 // 2] * F.gelu(yn[:, N2 // 2:]), dtype, "pp ln-folded geglu", scale=1.5)
 
 
+P160_SHAPES = [(256, 160, 128), (512, 480, 192), (1024, 320, 64 * 7), (16384, 640, 640), (4096, 1920, 320), (8192, 640, 2560)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", P160_SHAPES)
+def test_pp160_gemm_linear_epilogues(dtype, shape):
+    """the ping-pong structure on 256 x 160 tiles (csrc/tg_gemm_pp160.hip, force_tile 25): plain / bias + residual + per-batch vector / activation;
+    K of two tiles up to forty (the three-stage ring wraps), one to 768 tiles"""
+    from theatergen_amd import ops
+    dev = _dev()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    rows = 128
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    bias, res, bvec = rnd((N,), dtype, g), rnd((M, N), dtype, g), rnd((M // rows, N), dtype, g)
+    ad, wd, bd, rd, vd = a.to(dev), w.to(dev), bias.to(dev), res.to(dev), bvec.to(dev)
+    assert ops.gemm(ad, wd, M, N, K, force_tile=25, plan_only=True) == (256, 160, 1, 7)
+    ref0 = ad.float() @ wd.float().t()
+    check(ops.linear(ad, wd, force_tile=25), ref0.cpu(), dtype, f"pp160 plain {shape}")
+    out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=25)
+    check(out, (ref0 + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu(), dtype, f"pp160 bias + res + bvec {shape}")
+    again = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=25)
+    same = torch.equal(out, again)
+    assert same
+    out = ops.linear(ad, wd, bd, act=ops.ACT_SILU, out_scale=0.5, force_tile=25)
+    check(out, (F.silu(ref0 + bd.float()) * 0.5).cpu(), dtype, f"pp160 silu {shape}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pp160_gemm_qkv_split_and_layernorm_fold(dtype):
+    """Q | K token-major + V^T per batch item (n_split on an 80-column boundary) and the LayerNorm fold with precomputed row statistics on the 256 x 160
+    tiles: the 32 x 32 level's q | k | v projection (C = 640)"""
+    from theatergen_amd import ops
+    from theatergen_amd.weights_pack import pack_ln_linear
+    dev = _dev()
+    g = torch.Generator().manual_seed(2607)
+    B, rows, C = 2, 512, 320
+    M, N, K = B * rows, 3 * C, C
+    x = ((torch.randn(M, C, generator=g) + 0.5 * torch.randn(M, 1, generator=g)) * 2.0).to(dtype)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.3 * torch.randn(C, generator=g)).to(dtype)
+    eps = 1e-5
+    xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps)
+    xd = x.to(dev)
+    w3 = rnd((N, K), dtype, g, 1 / math.sqrt(K))
+    ref = x.float() @ w3.float().t()
+    out = torch.zeros((M, 2 * C), dtype=dtype, device=dev)
+    out_t = torch.zeros((B, C, rows), dtype=dtype, device=dev)
+    ops.gemm(xd, w3.to(dev), M, N, K, rows_per_batch=rows, out=out, n_split=2 * C, out_t=out_t, ldt=rows, force_tile=25)
+    check(out, ref[:, :2 * C], dtype, "pp160 qkv main")
+    check(out_t, ref[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, "pp160 qkv V^T")
+    st = ops.layernorm_stats(xd, eps)
+    wl3, u3, v3 = pack_ln_linear(w3.to(dev), None, gamma.to(dev), beta.to(dev))
+    out.zero_(); out_t.zero_()
+    ops.gemm(xd, wl3, M, N, K, rows_per_batch=rows, out=out, n_split=2 * C, out_t=out_t, ldt=rows, ln=(u3, v3, eps, st), force_tile=25)
+    ref3 = xn @ w3.float().t()
+    check(out, ref3[:, :2 * C], dtype, "pp160 ln-folded q|k", scale=1.5)
+    check(out_t, ref3[:, 2 * C:].reshape(B, rows, C).permute(0, 2, 1), dtype, "pp160 ln-folded v^T", scale=1.5)
+    with pytest.raises(RuntimeError):
+        ops.linear(rnd((300, K), dtype, g).to(dev), w3.to(dev), force_tile=25)
+
+
 def test_pp_gemm_batched_a_padded_pitches_and_refusals():
     from theatergen_amd import ops
     dev = _dev()
@@ -133,7 +194,7 @@ def test_pp_gemm_is_what_the_planner_picks_for_the_feedforward_shapes():
     from theatergen_amd import ops
     dev = _dev()
     dtype = torch.bfloat16
-    for (M, N, K, geglu, want) in [(16384, 5120, 640, True, 7), (4096, 10240, 1280, True, 7), (4096, 1280, 1280, False, None), (16384, 640, 640, False, None)]:
+    for (M, N, K, geglu, want) in [(16384, 5120, 640, True, 7), (4096, 10240, 1280, True, 7), (4096, 1280, 1280, False, None), (16384, 640, 640, False, 7)]:
         a = torch.zeros((M, K), dtype=dtype, device=dev)
         w = torch.zeros((N, K), dtype=dtype, device=dev)
         kind = ops.gemm(a, w, M, N, K, geglu=geglu, plan_only=True)[3]

@@ -250,6 +250,8 @@ int tg_gemm_t160_launch(const tg_gemm_desc* d, const void* params, int variant, 
 int tg_conv_halo_launch(const tg_gemm_desc* d, const void* params, int grid, void* stream);
 // ping-pong 256 x 256 tiles (tg_gemm_pp.hip, round 6): 8 waves in two groups one barrier apart, persistent
 int tg_gemm_pp_launch(const tg_gemm_desc* d, const void* params, void* stream);
+// the same structure on 256 x 160 tiles (tg_gemm_pp160.hip): the N = 640 / 1920 / 320 projections
+int tg_gemm_pp160_launch(const tg_gemm_desc* d, const void* params, void* stream);
 namespace {
 
 // Tile geometry of the slab kernel for an out_h x out_w map: patch width *pw and patches per 128-pixel tile *np (tg_conv_slab.hip).
@@ -367,10 +369,10 @@ inline int bt_tile_of(const tg_gemm_desc* d) {
 
 // Ping-pong 256 x 256 tiles (tg_gemm_pp.hip; force_tile 24): plain single-source GEMMs with M, N multiples of 256 and K of 64 whose tile count fills
 // the persistent grid's rounds; linear / activation / GEGLU epilogues, V^T columns on a 64-column boundary, the LayerNorm fold only with precomputed
-// row statistics (ln_rows).  Dev A/B knob TG_PP (bit mask, default 7): 1 = GEGLU launches, 2 = linear / activation launches, 4 = LayerNorm-folded ones.
+// row statistics (ln_rows).  Dev A/B knob TG_PP (bit mask, default 15): 1 = GEGLU launches, 2 = linear / activation launches, 4 = LayerNorm-folded ones, 8 = the 256 x 160 tiles (force_tile 25).
 inline int pp_mode() {
   const char* e = getenv("TG_PP");
-  return e ? (int)strtol(e, nullptr, 0) : 7;
+  return e ? (int)strtol(e, nullptr, 0) : 15;
 }
 inline bool pp_eligible(const tg_gemm_desc* d) {
   if (d->mode != 0 || d->a1 != nullptr || d->force_split_k > 1 || d->a_coef != nullptr) return false;
@@ -396,6 +398,29 @@ inline bool pp_selected(const tg_gemm_desc* d) {
   // prologue and the grid fills its rounds (2048 x 10240 x 1280 GEGLU, 320 tiles = 1.25 rounds: 81.8 -> 64.6 us; 8192 x 5120 x 640, 640 tiles: 89.6 -> 67.8);
   // short-K / ragged-N projections stay on the 128 x 160 / 128 x 128 tiles
   return tiles >= 192 && eff >= 0.6 && d->K >= 640;
+}
+
+// Ping-pong 256 x 160 tiles (tg_gemm_pp160.hip; force_tile 25): the same problems with N a multiple of 160 instead of 256 (no GEGLU; V^T columns on an
+// 80-column boundary) whose 256 x 160 tiles fill whole rounds of the chip: 16384 x 640 (256 tiles), 16384 x 1920 (768), 65536 x 320 (512).
+inline bool pp160_eligible(const tg_gemm_desc* d) {
+  if (d->mode != 0 || d->a1 != nullptr || d->force_split_k > 1 || d->a_coef != nullptr || d->geglu) return false;
+  if (d->M % 256 != 0 || d->N % 160 != 0 || d->K % 64 != 0 || d->K < 128) return false;
+  if (d->n_split > 0 && (d->n_split % 80 != 0 || d->rows_per_batch <= 0 || (d->M / d->rows_per_batch) * (d->N - d->n_split) * d->ldt >= (1LL << 31))) return false;
+  if (d->ln_u != nullptr && d->ln_rows == nullptr) return false;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const long lda = d->lda > 0 ? d->lda : d->c0, ldw = d->ldw > 0 ? d->ldw : d->K;
+  if (!(al16(d->a0) && al16(d->w) && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res)) || lda % 8 != 0 || ldw % 8 != 0 || d->ldc % 8 != 0) return false;
+  if ((d->bvec != nullptr && d->ldbvec % 8 != 0) || (d->res != nullptr && d->ldres % 8 != 0)) return false;
+  if (d->a_rows_per_batch > 0 && d->a_batch_stride % 8 != 0) return false;
+  return true;
+}
+inline bool pp160_selected(const tg_gemm_desc* d) {
+  if (d->force_tile == 25) return pp160_eligible(d);
+  if (d->force_tile != 0 || !pp160_eligible(d) || !(pp_mode() & 8)) return false;
+  if (d->ln_u != nullptr && !(pp_mode() & 4)) return false;
+  const long tiles = (d->M / 256) * (d->N / 160);
+  const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+  return tiles >= 192 && eff >= 0.74 && d->K >= 640;          // (K = 320: five K-tiles, not measured: stays on the 128 x 160 / 128 x 128 tiles)
 }
 
 // LayerNorm-folded projections on 128 x 160 tiles: 0 = no, 160 = three stages / one workgroup per CU, 161 = two stages / two per CU (tg_gemm_ln.hip)
@@ -444,6 +469,8 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
                 (d->n_split == 0 || d->n_split % 64 == 0);
   }
   if (pp_selected(d)) return tg_gemm_pp_launch(d, &p, st);
+  if (pp160_selected(d)) return tg_gemm_pp160_launch(d, &p, st);
+  TG_CHECK(d->force_tile != 25, TG_ERR_UNSUPPORTED, "tg_gemm: force_tile 25 (ping-pong 256 x 160 tiles) needs a plain single-source GEMM with M %% 256 == 0, N %% 160 == 0, K %% 64 == 0, 16-byte aligned operands and no GEGLU");
   TG_CHECK(d->force_tile != 24, TG_ERR_UNSUPPORTED, "tg_gemm: force_tile 24 (ping-pong 256 x 256 tiles) needs a plain single-source GEMM with M %% 256 == 0, N %% 256 == 0, K %% 64 == 0 and 16-byte aligned operands");
   if (d->ln_u != nullptr) {
     // LayerNorm-fused projection: whole rows per workgroup (no K split), 128 x 128 tiles — or 128 x 160 where those fill whole rounds — in XCD-chunked order
@@ -558,7 +585,7 @@ int validate(const tg_gemm_desc* d) {
   if (d->bvec) TG_CHECK(d->rows_per_batch > 0, TG_ERR_ARG, "tg_gemm: bvec needs rows_per_batch");
   if (d->ln_u != nullptr || d->ln_v != nullptr || d->ln_rows != nullptr) {
     TG_CHECK(d->ln_u && d->ln_v, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs both ln_u and ln_v");
-    TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && (d->force_tile == 0 || d->force_tile == 24),
+    TG_CHECK(d->mode == 0 && d->a1 == nullptr && !d->bvec && !d->res && d->act == TG_ACT_NONE && d->force_split_k <= 1 && (d->force_tile == 0 || d->force_tile == 24 || d->force_tile == 25),
              TG_ERR_ARG, "tg_gemm: the LayerNorm fold takes a plain single-source GEMM with a linear or GEGLU epilogue (no residual / per-batch vector / split)");
     TG_CHECK(d->K % 32 == 0 && d->N % 8 == 0 && d->ln_eps > 0.f, TG_ERR_ARG, "tg_gemm: the LayerNorm fold needs K %% 32 == 0, N %% 8 == 0, eps > 0");
     TG_CHECK((reinterpret_cast<uintptr_t>(d->ln_u) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->ln_v) & 15) == 0 &&
@@ -572,9 +599,9 @@ int validate(const tg_gemm_desc* d) {
 extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind) {
   int rc = validate(d);
   if (rc != TG_OK) return rc;
-  if (pp_selected(d)) {
+  if (pp_selected(d) || pp160_selected(d)) {
     if (tile_m) *tile_m = 256;
-    if (tile_n) *tile_n = 256;
+    if (tile_n) *tile_n = pp_selected(d) ? 256 : 160;
     if (splits) *splits = 1;
     if (kernel_kind) *kernel_kind = 7;
     return TG_OK;
@@ -610,7 +637,7 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {
   if (validate(d) != TG_OK) return -1;
-  if (pp_selected(d) || d->ln_u != nullptr) return 0;
+  if (pp_selected(d) || pp160_selected(d) || d->ln_u != nullptr) return 0;
   if (const int sp = slab_splits_of(d); sp > 0) return sp > 1 ? (d->M / 128) * (d->N / 320) * sp * 128 * 320 * 4 : 0;
   if (bt_tile_of(d) >= 0) return 0;
   return plan_workspace_bytes(make_plan(d));

@@ -84,15 +84,21 @@ _LN_MODE = 0 if os.environ.get("TG_NO_LN_FUSE") else int(os.environ.get("TG_LN_M
 _LN_FF_MAX_ROWS = int(os.environ.get("TG_LN_FF_MAX_ROWS", "0"))
 _CONV_OUT_GN = os.environ.get("TG_CONV_OUT_GN", "1") != "0"      # dev A/B knob: 0 = GroupNorm apply launch + conv_out
 _FF_PAD = os.environ.get("TG_FF_PAD", "1") != "0"      # round 5: pad the FeedForward hidden tensor's / net.2 weight's row pitch (see FeedForward._hidden)
-_PP_MODE = int(os.environ.get("TG_PP", "7"))           # csrc/tg_gemm.hip pp_mode(): bit 2 = LayerNorm-folded projections on the ping-pong tiles
+_PP_MODE = int(os.environ.get("TG_PP", "15"))           # csrc/tg_gemm.hip pp_mode(): bit 2 = LayerNorm-folded projections on the ping-pong tiles
 
 
 def _pp_takes_ln(M, N, K):
     """mirror of csrc/tg_gemm.hip ``pp_selected`` for a LayerNorm-folded projection (the kernel needs the row statistics as an input)"""
-    if not (_PP_MODE & 4) or M % 256 or N % 256 or K % 64 or K < 640:
+    if not (_PP_MODE & 4) or M % 256 or K % 64:
         return False
-    tiles = (M // 256) * (N // 256)
-    return tiles >= 192 and tiles / (((tiles + 255) // 256) * 256) >= 0.6
+    if N % 256 == 0 and K >= 640:                                      # 256 x 256 tiles (pp_selected)
+        tiles = (M // 256) * (N // 256)
+        if tiles >= 192 and tiles / (((tiles + 255) // 256) * 256) >= 0.6:
+            return True
+    if N % 160 == 0 and K >= 640 and (_PP_MODE & 8):                   # 256 x 160 tiles (pp160_selected); q | k | v^T: n_split = 2 N / 3 on an 80-column boundary
+        tiles = (M // 256) * (N // 160)
+        return tiles >= 192 and tiles / (((tiles + 255) // 256) * 256) >= 0.74 and (2 * N // 3) % 80 == 0
+    return False
 
 
 _FUSE_LN_MIN_ROWS = int(os.environ.get("TG_LN_FUSE_MIN_ROWS", "2048"))     # below: few 128-row tiles, the 64 x 64-tile path wins
