@@ -137,7 +137,11 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     if kk.value == 2:
         kname = "conv_halo_kernel<128x128>"
     elif kk.value == 4:
-        kname = f"conv_slab_kernel<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
+        # round 6: whole-row tiles of the 64 / 32 / 16-wide maps run on conv_slab_pp_kernel (csrc/tg_conv_slab.hip: TG_SLAB_PP, default 2)
+        spp = os.environ.get("TG_SLAB_PP", "2")
+        ow = int(conv[4]) if conv is not None else 0
+        two_wave = (ow == 64 and spp != "0") or (ow in (16, 32) and spp not in ("0", "1"))
+        kname = ("conv_slab_pp_kernel" if two_wave and int(conv[2]) == ow else "conv_slab_kernel") + f"<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
     elif kk.value == 6:
