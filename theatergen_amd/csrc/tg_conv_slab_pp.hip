@@ -67,7 +67,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // dev timing switches (TG_GEMM_FLAGS, WRONG results by design; scripts/dev_slab_pp.py -> profiles/r6_slab_findings.md): 1 << 16 no weight DMA after the
   // prologue, 1 << 17 no window staging after the prologue, 1 << 18 no MFMAs
+  // — compiled in only with -DTG_SLAB_DEV_BUILD (the tables of profiles/r6_slab_findings.md came from such a build); constants in the library's build
+#ifdef TG_SLAB_DEV_BUILD
   const bool ab_now = (p.flags & (1 << 16)) != 0, ab_nos = (p.flags & (1 << 17)) != 0, ab_nom = (p.flags & (1 << 18)) != 0;
+#else
+  constexpr bool ab_now = false, ab_nos = false, ab_nom = false;
+#endif
   if (loader) {
     // =========================================================== loader waves ===========================================
     const int wave = wave12 - 8;

@@ -112,7 +112,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 #undef PP_READ
   f32x4 acc[2][2][4][2];                          // [qa][qb][i][j]: tokens qa * 64 + i * 16 + frow, channels qb * 32 + j * 16 + 4 fq + e
-  const bool prio = (p.flags & 2) != 0;           // dev A/B (TG_GEMM_FLAGS bit 1): s_setprio 1 around a phase's MFMA block
+  // s_setprio 1 around a phase's MFMA block (guide T5: the phase split gives the arbiter something to prefer): same-box A/B 842.8 -> 839.9 ms per story
+  // (profiles/r6_ab_prio.json); TG_GEMM_FLAGS bit 15 (dev) switches it off
+  const bool prio = (p.flags & 32768) == 0;
   auto mfma_quad = [&](int qa, int qb) {
     if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll

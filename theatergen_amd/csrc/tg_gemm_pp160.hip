@@ -94,11 +94,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P160_READ(xf[0], a, 0); P160_READ(xf[1], a, 2048); P160_READ(xf[2], a, 4096); P160_READ(xf[3], a, 6144);
   };
 #undef P160_READ
+  const bool prio = (p.flags & 32768) == 0;       // s_setprio 1 around a phase's MFMA block (tg_gemm_pp.hip); TG_GEMM_FLAGS bit 15 (dev) switches it off
   auto mfmas = [&]() {
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xf[i]), acc[i][j]);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 #define P160_LOAD_END()                                    \
   do {                                                     \
