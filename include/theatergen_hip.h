@@ -43,7 +43,7 @@ extern "C" {
 
 /* ABI version: changes whenever a signature or descriptor layout in this header changes.  Callers compare it with the
  * TG_ABI_VERSION they were built against (the ctypes binding does at load time) and refuse a mismatching library. */
-#define TG_ABI_VERSION 306
+#define TG_ABI_VERSION 307
 int tg_version(void);
 const char* tg_last_error(void);
 
@@ -138,6 +138,14 @@ typedef struct {
    * (unet.FeedForward) pads the hidden tensor it owns and its packed copy of net.2's weight. */
   int64_t lda;
   int64_t ldw;
+  /* round 6, mode 1 on the two-wave slab kernel without a K split only (tg_gemm_gn_partial_blocks(d) > 0): the GroupNorm(out_gn_groups) partial sums of the
+   * OUTPUT leave the epilogue, so the consumer's statistics pass (gn_partial_kernel: one more HBM read of the tensor) disappears: every compute wave sums the
+   * stored (rounded) values of its 64 pixels x 80 channels per group — fp32 [batch][hw / 64][out_gn_groups][2] = (sum, sum of squares), each entry written by
+   * exactly one wave in a fixed order (deterministic) — the layout tg_groupnorm_from_partials folds (fp64) into the statistics.  ResnetBlock2D: conv1 -> norm2,
+   * conv2 (+ shortcut) -> Transformer2DModel.norm (models/unet_2d_blocks.py:184-195, models/transformer_2d.py:303-316 of diffusers).  NULL = off;
+   * TG_ERR_UNSUPPORTED when the planner's kernel for the descriptor does not write them. */
+  float* out_gn_partials;
+  int32_t out_gn_groups;
 } tg_gemm_desc;
 
 int tg_gemm(const tg_gemm_desc* d, void* stream);
@@ -147,6 +155,9 @@ int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d);
  * GroupNorm prologue), 5 = loader / compute GEMM (128 x 320 tiles, long K), 6 = LayerNorm-fused projection (ln_u)) the heuristic
  * picks for a descriptor */
 int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits, int32_t* kernel_kind);
+/* > 0: the kernel tg_gemm runs for `d` can write GroupNorm(d->out_gn_groups) partial sums of its output (tg_gemm_desc.out_gn_partials); the value is the number
+ * of 64-pixel blocks per batch item (the `nblk` of tg_groupnorm_from_partials).  0: it cannot (ask before setting out_gn_partials). */
+int tg_gemm_gn_partial_blocks(const tg_gemm_desc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused flash-style attention with up to two independently-normalised K/V segments:
@@ -253,6 +264,13 @@ int tg_layernorm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, in
  * (normalise + SiLU, one HBM write + read of the activation per conv) moves into the consumer conv's window staging. */
 int tg_groupnorm_coef(int32_t dtype, const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t batch, int64_t hw,
                       int32_t groups, float eps, const void* gamma, const void* beta, float* coef, void* partials, void* stream);
+
+/* tg_groupnorm / tg_groupnorm_coef from partial sums a producer already wrote (tg_gemm_desc.out_gn_partials: fp32 [batch][nblk][groups][2], one entry per
+ * 64-pixel block): the statistics launch is skipped.  `coef` != NULL: the coefficients (x is not read); else `out` = the normalised (+ SiLU) tensor of the
+ * single-source x [batch, hw, C].  The fold of the partials (fp64, fixed order) and the apply expressions are tg_groupnorm's; the sums were accumulated in a
+ * different order than gn_partial_kernel's, so results agree with tg_groupnorm to rounding of the statistics, not bit for bit. */
+int tg_groupnorm_from_partials(int32_t dtype, const void* x, int32_t C, int32_t batch, int64_t hw, int32_t groups, float eps, const void* gamma,
+                               const void* beta, int32_t silu, void* out, float* coef, const float* partials, int32_t nblk, void* stream);
 
 /* out[m, j] = x[m, j] * gelu(x[m, inner + j])  (GEGLU.forward, models/attention.py:337-338) */
 int tg_geglu(int32_t dtype, const void* x, int64_t rows, int64_t inner, void* out, void* stream);

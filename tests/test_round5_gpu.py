@@ -275,13 +275,17 @@ def test_gemm_128x160_tiles(dtype, shape):
     ad, wd, bd, rd, vd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), bvec.to(DEV)
     ref = (ad.float() @ wd.float().t() + bd.float() + rd.float() + vd.float().repeat_interleave(rows, 0)).cpu()
     base = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=1)
+    # round 6: the planner hands long-K whole-round problems (here 16384 x 640 x 640) to the ping-pong 256 x 160 kernel (kernel_kind 7: 16 x 16 x 32 MFMAs,
+    # another K order) — its own tests are in test_round6_gpu.py; bit-identity with the 128 x 128 kernel is a property of the round-5 tiles only
+    kind0 = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, bvec=vd, rows_per_batch=rows, plan_only=True)[3]
     for tile in (21, 23, 0):
         out = ops.linear(ad, wd, bd, res=rd, bvec=vd, rows_per_batch=rows, force_tile=tile)
         check(out, ref, dtype, f"128x160 tile {tile} {shape}")
-        assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
+        if tile != 0 or kind0 != 7:
+            assert torch.equal(out, base), f"tile {tile} {shape}: not bit-identical to the 128 x 128 kernel"
     if (M, N) in ((16384, 640), (4096, 1280)):
         pl = ops.gemm(ad, wd, M, N, K, bias=bd, res=rd, plan_only=True)
-        assert (pl[0], pl[1]) == (128, 160), pl
+        assert (pl[0], pl[1]) == ((256, 160) if pl[3] == 7 else (128, 160)), pl
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

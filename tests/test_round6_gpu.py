@@ -436,3 +436,86 @@ def test_final_image_generation_reference_signature_vs_oracle_loop(tmp_path, mon
     with pytest.raises(TypeError):
         pipelines.final_image_generation("1.5", processor, type("P", (), {"controlnet": object()})(), 1, "p", "n", "b", [char_img], None, 0, H, W, bg_seed, inp_mask,
                                          pasted, ad, None, latents_all, None, None, (text, text[:1], text[1:]), steps, frozen_steps)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("geom", [(8, 64, 64, 320, 320), (16, 32, 32, 640, 640), (16, 32, 32, 320, 640), (2, 64, 64, 640, 1280)])
+def test_groupnorm_partials_from_the_slab_conv_epilogue(dtype, geom):
+    """round 6: the two-wave slab conv writes the GroupNorm(32) partial sums of its OUTPUT (tg_gemm_desc.out_gn_partials) and tg_groupnorm_from_partials folds
+    them: coefficients and the normalised tensor against tg_groupnorm_coef / tg_groupnorm of the same stored output (statistics agree to fp32 rounding) and
+    against F.group_norm in fp32; the conv output itself is unchanged bit for bit; a kernel that cannot write them leaves gn_out alone / refuses the pointer."""
+    from theatergen_amd import ops
+    from theatergen_amd._lib import GemmDesc
+    from theatergen_amd.weights_pack import pack_conv3x3
+    dev = _dev()
+    B, h, w, cin, cout = geom
+    g = torch.Generator().manual_seed(B * h + cin + cout)
+    x = rnd((B * h * w, cin), dtype, g).to(dev)
+    wt = rnd((cout, cin, 3, 3), dtype, g, 1 / math.sqrt(9 * cin))
+    bias = rnd((cout,), dtype, g).to(dev)
+    res = (rnd((B * h * w, cout), dtype, g) + 0.5).to(dev)                 # a mean the E[x^2] - mean^2 form has to cancel
+    bvec = rnd((B, cout), dtype, g).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(cout, generator=g)).to(dtype).to(dev), (0.2 * torch.randn(cout, generator=g)).to(dtype).to(dev)
+    wp = pack_conv3x3(wt).to(dev)
+    kw = dict(bias=bias, res=res, bvec=bvec, rows_per_batch=h * w)
+    plain = ops.conv3x3(x, wp, B, h, w, cin, **kw)
+    gn = {"groups": 32}
+    out = ops.conv3x3(x, wp, B, h, w, cin, gn_out=gn, **kw)
+    assert "partials" in gn and gn["nblk"] == h * w // 64, gn.keys()
+    assert torch.equal(out, plain)
+    # the sums themselves: fp64 sums of the stored values per (image, 64-pixel block, group)
+    o64 = out.double().reshape(B, h * w // 64, 64, 32, cout // 32)
+    want = torch.stack([o64.sum(dim=(2, 4)), (o64 * o64).sum(dim=(2, 4))], dim=-1)
+    got = gn["partials"].double()
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-3), (got - want).abs().max().item()
+    for eps in (1e-5, 1e-6):
+        c_ref = ops.groupnorm_coef(out, B, h * w, 32, eps, gamma, beta)
+        c_got = ops.groupnorm_from_partials(gn, B, h * w, cout, eps, gamma, beta)
+        assert torch.allclose(c_got, c_ref, rtol=2e-5, atol=2e-6), (c_got - c_ref).abs().max().item()
+    for silu in (False, True):
+        y_ref = ops.groupnorm(out, B, h * w, 32, 1e-6, gamma, beta, silu=silu)
+        y_got = ops.groupnorm_from_partials(gn, B, h * w, cout, 1e-6, gamma, beta, x=out, silu=silu)
+        t = F.group_norm(out.float().reshape(B, h * w, cout).transpose(1, 2), 32, gamma.float(), beta.float(), 1e-6)
+        t = (F.silu(t) if silu else t).transpose(1, 2).reshape(B * h * w, cout)
+        check(y_got, t.cpu(), dtype, f"groupnorm_from_partials {geom} silu={silu}")
+        ulp = (y_got.float() - y_ref.float()).abs().max().item()
+        assert ulp <= (0.04 if dtype == torch.bfloat16 else 0.006), ulp     # the same apply pass on statistics that agree to ~1e-6: rare 1-ulp flips
+    # the one-wave slab kernel and a K-split launch do not write them: gn_out is left alone, the raw pointer is refused
+    for extra in (dict(force_tile=12), ):
+        gn2 = {"groups": 32}
+        ops.conv3x3(x, wp, B, h, w, cin, gn_out=gn2, **extra, **kw)
+        assert "partials" not in gn2
+    gn3 = {"groups": 24}                                                   # 80 % (cout / 24) != 0 for these widths, or cout % 24 != 0
+    ops.conv3x3(x, wp, B, h, w, cin, gn_out=gn3, **kw)
+    assert "partials" not in gn3
+
+
+def test_groupnorm_partials_env_switch_and_unet_block_parity(monkeypatch):
+    """ResnetBlock2D -> Transformer2DModel.norm with the statistics from the conv epilogues (default) against the statistics launches (TG_GN_EPI=0)."""
+    import importlib
+    from theatergen_amd import ops, unet as unet_mod
+    dev = _dev()
+    dtype = torch.bfloat16
+    torch.manual_seed(3)
+    blk = unet_mod.ResnetBlock2D(320, 320, 1280).to(dev).to(dtype)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * (0.05 if p.ndim > 1 else 0.3) + (1.0 if p.ndim == 1 and p.numel() == 320 else 0.0))
+    blk.temb_slot = (0, 320)
+    B, h, w = 8, 64, 64
+    x = unet_mod._Act(torch.randn(B * h * w, 320, device=dev).to(dtype), B, h, w, 320)
+    tproj = torch.randn(B, 320, device=dev).to(dtype)
+    launches = []
+    real = ops.groupnorm_coef
+    monkeypatch.setattr(ops, "groupnorm_coef", lambda *a, **k: (launches.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(unet_mod, "_GN_EPI", True)
+    y1 = blk.run(x, None, tproj)
+    n_on = len(launches)
+    assert y1.gn is not None and "partials" in y1.gn
+    monkeypatch.setattr(unet_mod, "_GN_EPI", False)
+    y0 = blk.run(x, None, tproj)
+    assert y0.gn is None and len(launches) - n_on == 2 and n_on == 1        # norm1 keeps its statistics launch (its input is not a conv output here)
+    d = (y1.t.float() - y0.t.float()).abs().max().item()
+    assert d <= 0.07 * y0.t.float().abs().max().item(), d
+    rel = ((y1.t.float() - y0.t.float()).norm() / y0.t.float().norm()).item()
+    assert rel < 2e-3, rel

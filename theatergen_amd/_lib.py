@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THEATERGEN_HIP_LIB") or os.path.join(HERE, "lib", "libtheatergen_hip.so")
 
 TG_BF16, TG_F16 = 0, 1
-ABI_VERSION = 306          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
+ABI_VERSION = 307          # TG_ABI_VERSION of include/theatergen_hip.h this binding was written against
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("out_t", vp), ("ldt", i64), ("workspace", vp), ("workspace_bytes", i64),
         ("force_split_k", i32), ("force_tile", i32), ("a_rows_per_batch", i64), ("a_batch_stride", i64),
         ("pad_mode", i32), ("a_silu", i32), ("a_coef", vp), ("ln_u", vp), ("ln_v", vp), ("ln_eps", f32), ("ln_rows", vp),
-        ("lda", i64), ("ldw", i64),
+        ("lda", i64), ("ldw", i64), ("out_gn_partials", vp), ("out_gn_groups", i32),
     ]
 
 
@@ -144,6 +144,8 @@ SIGNATURES = {
     "tg_layernorm": (i32, [i32, vp, i64, i32, i64, f32, vp, vp, vp, i64, vp]),
     "tg_layernorm_stats": (i32, [i32, vp, i64, i32, i64, f32, vp, vp]),
     "tg_groupnorm_coef": (i32, [i32, vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, vp, vp]),
+    "tg_groupnorm_from_partials": (i32, [i32, vp, i32, i32, i64, i32, f32, vp, vp, i32, vp, vp, vp, i32, vp]),
+    "tg_gemm_gn_partial_blocks": (i32, [C.POINTER(GemmDesc)]),
     "tg_geglu": (i32, [i32, vp, i64, i64, vp, vp]),
     "tg_act": (i32, [i32, vp, i64, i32, vp, vp]),
     "tg_add": (i32, [i32, vp, vp, i64, vp, vp]),

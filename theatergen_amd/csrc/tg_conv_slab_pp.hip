@@ -343,6 +343,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float scale = p.out_scale;
     const bool part = S > 1;
     float* wsp = part ? p.ws + (long)lbid * BM * BN : nullptr;
+    // GroupNorm partial sums of the OUTPUT (tg_gemm_desc.out_gn_partials; unsplit tiles only): every lane sums the stored (rounded) values it writes, per channel
+    const bool gn = p.gn_part != nullptr && !part;
+    float gs[8], gq[8];
     auto finish8 = [&](const f32x4& lo, const f32x4& hi, long m, long n, const float (&bias_f)[8]) {
       if (part) {                                   // fp32 partial in tile-local order: the reduce kernel sums the splits and applies the epilogue
         float* q = wsp + (m - m0) * BN + (n - n0);
@@ -367,10 +370,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e] * scale);
       *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
+      if (gn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(o[e]); gs[e] += f; gq[e] += f * f; }
+      }
     };
+    float* gsum = scr + 704;                         // [2][80] channel sums of this wave's 64 pixels (behind the 32 x 20 floats the last pass bounces through)
     {
       // channels 0-63 of the wave's 80: 16 pixels x 64 channels per pass, lane -> (row lane / 8 + 8 it, 8-channel piece lane % 8)
       const int c = lane & 7, r0 = lane >> 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
       const long n = nw + c * 8;
       float bias_f[8];
 #pragma unroll
@@ -393,11 +403,23 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         __builtin_amdgcn_wave_barrier();
       }
+      if (gn) {                                     // the 8 lanes of a channel piece (rows r0 = lane / 8) fold in a fixed butterfly order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = gs[e], b = gq[e];
+          a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+          a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+          a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+          if (r0 == 0) { gsum[c * 8 + e] = a; gsum[80 + c * 8 + e] = b; }
+        }
+      }
     }
     {
       // channels 64-79: two pixel tiles per pass = 32 pixels x 16 channels, lane -> (row lane / 2, 8-channel piece lane % 2)
       const int c = lane & 1, r = lane >> 1;
       const long n = nw + 64 + c * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
       float bias_f[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
@@ -414,6 +436,29 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8 + 4);
         finish8(lo, hi, mw + ip * 32 + r, n, bias_f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (gn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = gs[e], b = gq[e];
+#pragma unroll
+          for (int x = 2; x < 64; x <<= 1) { a += __shfl_xor(a, x); b += __shfl_xor(b, x); }
+          if (r == 0) { gsum[64 + c * 8 + e] = a; gsum[80 + 64 + c * 8 + e] = b; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // channels -> groups: lane g owns group g of the wave's 80 / cpg whole groups; entry [image][64-pixel block][group] is written by this wave alone
+        const int cpg = p.gn_cpg;
+        if (lane < 80 / cpg) {
+          float a = 0.f, b = 0.f;
+          for (int j = 0; j < cpg; ++j) { a += gsum[lane * cpg + j]; b += gsum[80 + lane * cpg + j]; }
+          const long hw = (long)p.out_h * p.out_w;
+          const long img = mw / hw, blk = (mw - img * hw) >> 6;
+          const int groups = (int)(p.N / cpg);
+          float* o = p.gn_part + ((img * (hw >> 6) + blk) * groups + nw / cpg + lane) * 2;
+          o[0] = a;
+          o[1] = b;
+        }
         __builtin_amdgcn_wave_barrier();
       }
     }

@@ -242,6 +242,7 @@ int launch_cfg2(const tg_gemm_desc* d, const GemmParams& p, const Plan& pl, hipS
 int tg_gemm_bt_launch(const tg_gemm_desc* d, const void* params, int bt_tile, void* stream);
 // slab conv kernel (tg_conv_slab.hip): BM x 320 output tiles, GroupNorm(+SiLU) prologue on the staged window
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream);
+bool tg_conv_slab_is_pp(const tg_gemm_desc* d, int patch_pwl, int patch_np, int epi_lds);
 // LayerNorm-fused projections (tg_gemm_ln.hip): 128 x 128 tiles, no K split
 int tg_gemm_ln_launch(const tg_gemm_desc* d, const void* params, int short_k, int grid, void* stream);
 // 128 x 160 tiles (tg_gemm_t160.hip): variant 0 = BK 64 x 3 stages, 1 = BK 32 x 4 stages, 2 = BK 64 x 2 stages
@@ -438,6 +439,27 @@ inline int ln_t160_of(const tg_gemm_desc* d) {
   return one_per_cu ? 160 : 161;
 }
 
+// operands / strides allow the LDS-transposed, 16-byte-coalesced epilogue (GemmParams::epi_lds)
+inline bool epi_lds_of(const tg_gemm_desc* d) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
+         (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) && (d->n_split == 0 || d->n_split % 64 == 0);
+}
+
+// tg_gemm_desc.out_gn_partials: only the two-wave slab kernel's unsplit epilogue writes them (every compute wave owns 64 pixels x 80 channels: whole groups,
+// one batch item).  -> 64-pixel blocks per batch item, 0 = this descriptor's kernel cannot.
+inline int gn_partial_blocks_of(const tg_gemm_desc* d) {
+  if (d->out_gn_groups <= 0 || d->N % d->out_gn_groups != 0 || 80 % (d->N / d->out_gn_groups) != 0) return 0;
+  if (slab_splits_of(d) != 1) return 0;
+  int pw = 0, np = 1;
+  bool patch = false;
+  if (!slab_geometry(d, &pw, &np, &patch) || patch || np != 1) return 0;
+  if (!tg_conv_slab_is_pp(d, 0, 1, epi_lds_of(d))) return 0;
+  const long hw = (long)d->out_h * d->out_w;
+  if (hw % 64 != 0) return 0;
+  return (int)(hw / 64);
+}
+
 template <typename T>
 int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   Plan pl = make_plan(d);
@@ -462,12 +484,10 @@ int launch_gemm(const tg_gemm_desc* d, hipStream_t st) {
   p.a_coef = d->a_coef; p.a_silu = d->a_silu;
   p.patch_pwl = 0; p.patch_np = 1;
   p.ln_u = d->ln_u; p.ln_v = d->ln_v; p.ln_eps = d->ln_eps; p.ln_rows = d->ln_rows;
-  {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    p.epi_lds = d->N % 8 == 0 && d->ldc % 8 == 0 && al16(d->out) && al16(d->bias) && al16(d->bvec) && al16(d->res) &&
-                (d->bvec == nullptr || d->ldbvec % 8 == 0) && (d->res == nullptr || d->ldres % 8 == 0) &&
-                (d->n_split == 0 || d->n_split % 64 == 0);
-  }
+  p.epi_lds = epi_lds_of(d);
+  p.gn_part = d->out_gn_partials; p.gn_cpg = d->out_gn_partials ? (int)(d->N / d->out_gn_groups) : 0;
+  TG_CHECK(d->out_gn_partials == nullptr || gn_partial_blocks_of(d) > 0, TG_ERR_UNSUPPORTED,
+           "tg_gemm: out_gn_partials needs an unsplit stride-1 conv on the two-wave slab kernel with 80 %% (N / groups) == 0 (ask tg_gemm_gn_partial_blocks)");
   if (pp_selected(d)) return tg_gemm_pp_launch(d, &p, st);
   if (pp160_selected(d)) return tg_gemm_pp160_launch(d, &p, st);
   TG_CHECK(d->force_tile != 25, TG_ERR_UNSUPPORTED, "tg_gemm: force_tile 25 (ping-pong 256 x 160 tiles) needs a plain single-source GEMM with M %% 256 == 0, N %% 160 == 0, K %% 64 == 0, 16-byte aligned operands and no GEGLU");
@@ -633,6 +653,12 @@ extern "C" int tg_gemm_plan(const tg_gemm_desc* d, int32_t* tile_m, int32_t* til
   if (splits) *splits = pl.s;
   if (kernel_kind) *kernel_kind = pl.halo ? 2 : (d->mode == 1 ? 1 : 0);
   return TG_OK;
+}
+
+extern "C" int tg_gemm_gn_partial_blocks(const tg_gemm_desc* d) {
+  if (validate(d) != TG_OK) return 0;
+  if (pp_selected(d) || pp160_selected(d) || d->ln_u != nullptr) return 0;
+  return gn_partial_blocks_of(d);
 }
 
 extern "C" int64_t tg_gemm_workspace_bytes(const tg_gemm_desc* d) {

@@ -55,6 +55,8 @@ struct GemmParams {
   const float* xa_ip_scale;   // device scalar (IPAttnProcessor.scale) or NULL (1.0)
   int xa_rows_per_batch, xa_tiles_n, xa_L, xa_T;
   int slab_order;   // slab conv work order: 0 tile-major, 1 (column tile, split)-major / row-tile-minor (weight-heavy layers)
+  float* gn_part;   // two-wave slab conv, unsplit: GroupNorm partial sums of the output, fp32 [batch][hw / 64][N / gn_cpg][2] (tg_gemm_desc.out_gn_partials), or NULL
+  int gn_cpg;       // ... channels per group (divides 80)
 };
 
 // token (row of the token-major tensor) of local row `lr` (0..127) of patch tile `tile_m`; see GemmParams::patch_pwl

@@ -26,6 +26,7 @@ struct GnParams {
   float* partials;  // [batch][nblk][groups][2]
   float* stats;     // [batch][groups][2] (mean, rstd) — placed after the partials
   int nblk;
+  int npart;        // partial sums per batch item the statistics fold reads (= nblk unless a producer wrote them: tg_groupnorm_from_partials)
   int cx, ry;       // thread grid: cx channel-chunk columns x ry pixel rows
   float* coef;      // tg_groupnorm_coef: [batch][2][C] (a = rstd * gamma, d = beta - mean * a) instead of the normalised tensor
 };
@@ -120,8 +121,8 @@ __device__ __forceinline__ void gn_block_stats(const GnParams& p, int b, float* 
     const int g = g0 + gl;
     double s = 0.0, q = 0.0;
     if (g < p.groups)
-      for (int k = part; k < p.nblk; k += 8) {
-        const float* o = p.partials + (((long)b * p.nblk + k) * p.groups + g) * 2;
+      for (int k = part; k < p.npart; k += 8) {
+        const float* o = p.partials + (((long)b * p.npart + k) * p.groups + g) * 2;
         s += (double)o[0];
         q += (double)o[1];
       }
@@ -526,6 +527,7 @@ int groupnorm_impl(int32_t dtype, const void* x0, const void* x1, int32_t c0, in
     }
   }
   p.nblk = gn_nblk(batch, hw);
+  p.npart = p.nblk;
   p.partials = reinterpret_cast<float*>(partials);
   p.stats = p.partials + (long)batch * p.nblk * groups * 2;
   const int cpr = C / 8;
@@ -572,6 +574,35 @@ extern "C" int tg_layernorm(int32_t dtype, const void* x, int64_t rows, int32_t 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == TG_BF16) return launch_ln<bf16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
   return launch_ln<f16_t>(x, rows, C, ldx, eps, gamma, beta, out, ldo, st);
+}
+
+extern "C" int tg_groupnorm_from_partials(int32_t dtype, const void* x, int32_t C, int32_t batch, int64_t hw, int32_t groups, float eps, const void* gamma,
+                                          const void* beta, int32_t silu, void* out, float* coef, const float* partials, int32_t nblk, void* stream) {
+  TG_CHECK(dtype == TG_BF16 || dtype == TG_F16, TG_ERR_ARG, "tg_groupnorm_from_partials: bad dtype");
+  TG_CHECK(partials != nullptr && nblk > 0 && (coef != nullptr || (x != nullptr && out != nullptr)), TG_ERR_ARG, "tg_groupnorm_from_partials: null pointer");
+  TG_CHECK(batch > 0 && hw > 0 && groups > 0 && groups <= 256 && C % groups == 0 && C % 8 == 0 && C <= 8 * 256 * GN_MAX_CHUNKS, TG_ERR_ARG,
+           "tg_groupnorm_from_partials: bad shape batch=%d hw=%lld C=%d groups=%d", batch, (long long)hw, C, groups);
+  GnParams p{};
+  p.x0 = x; p.x1 = nullptr; p.c0 = C; p.c1 = 0; p.batch = batch; p.hw = hw; p.groups = groups; p.eps = eps;
+  p.gamma = gamma; p.beta = beta; p.silu = silu; p.out = out; p.coef = coef;
+  p.partials = const_cast<float*>(partials);
+  p.npart = nblk;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (coef != nullptr) {
+    if (dtype == TG_BF16) hipLaunchKernelGGL(gn_coef_kernel<bf16_t>, dim3(batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gn_coef_kernel<f16_t>, dim3(batch), dim3(256), 0, st, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+  }
+  p.nblk = gn_nblk(batch, hw);                     // pixel slabs of the apply pass (independent of the producer's block count)
+  const int cpr = C / 8;
+  p.cx = cpr < 256 ? cpr : 256;
+  p.ry = 256 / p.cx;
+  const size_t lds_stats = (size_t)groups * 2 * sizeof(float);
+  if (dtype == TG_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(p.nblk, batch), dim3(256), lds_stats, st, p);
+  else hipLaunchKernelGGL(gn_apply_kernel<f16_t>, dim3(p.nblk, batch), dim3(256), lds_stats, st, p);
+  TG_LAUNCH_CHECK();
+  return TG_OK;
 }
 
 extern "C" int tg_layernorm_stats(int32_t dtype, const void* x, int64_t rows, int32_t C, int64_t ldx, float eps, float* stats, void* stream) {

@@ -68,7 +68,8 @@ def workspace(nbytes, device):
 
 def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None, bvec=None, rows_per_batch=0,
          res=None, act=ACT_NONE, out_scale=1.0, out=None, n_split=0, out_t=None, ldt=0, force_split_k=0, force_tile=0,
-         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False, ln=None, lda=0, ldw=0):
+         a_rows_per_batch=0, a_batch_stride=0, geglu=False, pad_mode=0, a_coef=None, a_silu=False, plan_only=False, ln=None, lda=0, ldw=0,
+         gn_out=None):
     """out[M, N] = epilogue(A[M, K] @ W[N, K]^T); see tg_gemm in include/theatergen_hip.h.
     ``conv`` = (batch, in_h, in_w, out_h, out_w, stride, upsample) for mode 1."""
     _need_cuda(a0)
@@ -113,6 +114,17 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
             if ln[3].dtype != torch.float32 or ln[3].numel() != 2 * M or not ln[3].is_contiguous():
                 raise RuntimeError("gemm: ln rows must be the contiguous fp32 [M, 2] tensor of layernorm_stats")
             d.ln_rows = _ptr(ln[3])
+    if gn_out is not None and not plan_only:
+        # gn_out = {"groups": G}: GroupNorm(G) partial sums of the OUTPUT from the epilogue where the planner's kernel writes them (the two-wave slab conv,
+        # unsplit); filled in with "partials" (fp32 [batch, nblk, G, 2]) and "nblk" for ``groupnorm_from_partials``; left alone otherwise.
+        d.out_gn_groups = int(gn_out["groups"])
+        nb = L.tg_gemm_gn_partial_blocks(C.byref(d))
+        if nb > 0:
+            gn_out["partials"] = torch.empty((int(conv[0]), nb, d.out_gn_groups, 2), dtype=torch.float32, device=a0.device)
+            gn_out["nblk"] = nb
+            d.out_gn_partials = gn_out["partials"].data_ptr()
+        else:
+            d.out_gn_groups = 0
     if plan_only:
         tm, tn, sp, kk = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(L.tg_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp), C.byref(kk)))
@@ -466,6 +478,27 @@ def groupnorm_coef(x0, batch, hw, groups, eps, gamma, beta, x1=None):
     _lib.check(L.tg_groupnorm_coef(_dt(x0), _ptr(x0), _ptr(x1), c0, c1, batch, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
                                    _ptr(coef), _ptr(scratch), _stream()))
     return coef
+
+
+def groupnorm_from_partials(gn, batch, hw, C_, eps, gamma, beta, x=None, silu=False, out=None):
+    """GroupNorm whose partial sums a producer conv already wrote (``gemm(gn_out=...)``): ``x`` None -> the coefficients fp32 [batch, 2, C]
+    (``groupnorm_coef``), else the normalised (+ SiLU) tensor (``groupnorm``); no statistics pass over the activation."""
+    L = _lib.lib()
+    part, nblk, groups = gn["partials"], int(gn["nblk"]), int(gn["groups"])
+    if part.shape != (batch, nblk, groups, 2) or part.dtype != torch.float32 or not part.is_cuda:
+        raise RuntimeError("groupnorm_from_partials: partials must be the fp32 [batch, nblk, groups, 2] tensor a producer conv wrote")
+    dt = _dt(x) if x is not None else (0 if gamma.dtype == torch.bfloat16 else 1)
+    if x is None:
+        coef = torch.empty((batch, 2, C_), dtype=torch.float32, device=part.device)
+        _lib.check(L.tg_groupnorm_from_partials(dt, None, int(C_), int(batch), int(hw), groups, float(eps), _ptr(gamma), _ptr(beta), 0, None,
+                                                _ptr(coef), _ptr(part), nblk, _stream()))
+        return coef
+    _need_cuda(x)
+    if out is None:
+        out = torch.empty((batch * hw, C_), dtype=x.dtype, device=x.device)
+    _lib.check(L.tg_groupnorm_from_partials(dt, _ptr(x), int(C_), int(batch), int(hw), groups, float(eps), _ptr(gamma), _ptr(beta), 1 if silu else 0,
+                                            _ptr(out), None, _ptr(part), nblk, _stream()))
+    return out
 
 
 _slab_plans = {}

@@ -44,10 +44,11 @@ class DeviceSchedule:
 
 class _Act:
     """A token-major activation: 2-D tensor [B*h*w, C] + its geometry."""
-    __slots__ = ("t", "b", "h", "w", "c")
+    __slots__ = ("t", "b", "h", "w", "c", "gn")
 
-    def __init__(self, t, b, h, w, c):
+    def __init__(self, t, b, h, w, c, gn=None):
         self.t, self.b, self.h, self.w, self.c = t, b, h, w, c
+        self.gn = gn          # GroupNorm partial sums of ``t`` its producer conv wrote (ops.gemm gn_out), or None
 
     @property
     def hw(self):
@@ -72,6 +73,13 @@ class _Packed:
 
 # dev switch: TG_NO_GN_FUSE=1 keeps GroupNorm and conv two ops everywhere (A/B of the fused window staging)
 _FUSE_GN = not os.environ.get("TG_NO_GN_FUSE")
+# round 6: the statistics pass of a GroupNorm whose input is a slab conv's output (ResnetBlock2D.norm2 after conv1, Transformer2DModel.norm after conv2) comes
+# out of that conv's epilogue as partial sums (tg_gemm_desc.out_gn_partials) where the two-wave slab kernel runs the layer unsplit.  TG_GN_EPI=0 (dev A/B) = off.
+_GN_EPI = os.environ.get("TG_GN_EPI", "1") != "0"
+
+
+def _gn_of(gn, groups):
+    return gn if gn is not None and "partials" in gn and gn["groups"] == groups else None
 # dev switch: TG_NO_LN_FUSE=1 keeps LayerNorm a launch of its own in front of the q|k|v / to_q / GEGLU projections
 # TG_LN_MODE bits: 1 = fold norm1 / norm2 into attn1 q|k|v / attn2.to_q, 2 = fold norm3 into the GEGLU GEMM, 4 = row statistics from a
 # statistics-only pass (tg_layernorm_stats) instead of inside the GEMM.  0 = LayerNorm launches (round 2).
@@ -136,8 +144,14 @@ class ResnetBlock2D(nn.Module):
         if tproj is not None:
             off, width = self.temb_slot
             kw1.update(bvec=tproj[:, off:off + width], rows_per_batch=x.hw)
+        fuse2 = _FUSE_GN and ops.conv3x3_takes_gn(x.t.dtype, x.b, x.h, x.w, self.out_channels, 0, self.out_channels)
+        gn1 = {"groups": self.groups} if _GN_EPI and fuse2 else None      # conv1 -> norm2: the coefficients are all norm2 needs
+        if gn1 is not None:
+            kw1.update(gn_out=gn1)
         if _FUSE_GN and ops.conv3x3_takes_gn(x.t.dtype, x.b, x.h, x.w, x.c, c1, self.out_channels):
-            coef = ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, x1=x1)
+            g0 = _gn_of(x.gn, self.groups) if skip is None else None
+            coef = (ops.groupnorm_from_partials(g0, x.b, x.hw, x.c, self.eps, self.norm1.weight, self.norm1.bias) if g0 is not None else
+                    ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, x1=x1))
             h = ops.conv3x3(x.t, w1, x.b, x.h, x.w, x.c, x1=x1, c1=c1, a_coef=coef, a_silu=True, **kw1)
         else:
             h = ops.groupnorm(x.t, x.b, x.hw, self.groups, self.eps, self.norm1.weight, self.norm1.bias, silu=True, x1=x1)
@@ -149,13 +163,18 @@ class ResnetBlock2D(nn.Module):
         else:
             res = x.t
         kw2 = dict(bias=self.conv2.bias, res=res, out_scale=1.0 / self.output_scale_factor)
-        if _FUSE_GN and ops.conv3x3_takes_gn(h.dtype, x.b, x.h, x.w, self.out_channels, 0, self.out_channels):
-            coef = ops.groupnorm_coef(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias)
+        gn2 = {"groups": self.groups} if _GN_EPI else None                 # conv2 -> the next GroupNorm(groups) of the block output (Transformer2DModel.norm)
+        if gn2 is not None:
+            kw2.update(gn_out=gn2)
+        if fuse2:
+            g1 = _gn_of(gn1, self.groups)
+            coef = (ops.groupnorm_from_partials(g1, x.b, x.hw, self.out_channels, self.eps, self.norm2.weight, self.norm2.bias) if g1 is not None else
+                    ops.groupnorm_coef(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias))
             out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, a_coef=coef, a_silu=True, **kw2)
         else:
             h = ops.groupnorm(h, x.b, x.hw, self.groups, self.eps, self.norm2.weight, self.norm2.bias, silu=True)
             out = ops.conv3x3(h, w2, x.b, x.h, x.w, self.out_channels, **kw2)
-        return _Act(out, x.b, x.h, x.w, self.out_channels)
+        return _Act(out, x.b, x.h, x.w, self.out_channels, gn=_gn_of(gn2, self.groups))
 
 
 class Downsample2D(nn.Module):
@@ -370,7 +389,9 @@ class Transformer2DModel(nn.Module):
         if (not rowchain.ENABLED or not (rowchain.MODE & 8) or not _LN_MODE & 1 or C != 320 or w_in.shape != (320, 320) or M < rowchain.MIN_ROWS_CHAIN
                 or x.hw % 128 or x.t.stride(0) != C or x.c != 320 or not front_eligible(blk.attn1, ca_kwargs)):
             return None
-        coef = ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias)
+        g = _gn_of(x.gn, self.groups)
+        coef = (ops.groupnorm_from_partials(g, x.b, x.hw, x.c, 1e-6, self.norm.weight, self.norm.bias) if g is not None else
+                ops.groupnorm_coef(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias))
         bin_ = self.proj_in.bias
         win = self._p.get("rc_front_in", [w_in] + ([bin_] if bin_ is not None else []),
                           lambda: rc_pack_tiles(w_in.detach(), bin_.detach().float() if bin_ is not None else None))
@@ -384,7 +405,9 @@ class Transformer2DModel(nn.Module):
         if pre is not None:
             y, pre = pre[0], pre[1:]
         else:
-            y = ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False)
+            g = _gn_of(x.gn, self.groups)
+            y = (ops.groupnorm_from_partials(g, x.b, x.hw, x.c, 1e-6, self.norm.weight, self.norm.bias, x=x.t) if g is not None else
+                 ops.groupnorm(x.t, x.b, x.hw, self.groups, 1e-6, self.norm.weight, self.norm.bias, silu=False))
             y_in = rowchain.linear320(y, w_in, self.proj_in.bias, None, self, "proj_in", _cached)
             y = y_in if y_in is not None else ops.linear(y, w_in, self.proj_in.bias)
         base_key = list(ca_kwargs.get("attn_key", [])) if "attn_key" in ca_kwargs else None
