@@ -202,14 +202,18 @@ def lib():
         # other way round the process ends up with two runtimes and the second reports "no ROCm-capable device".
         import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
+        h.tg_version.restype = i32
+        got = h.tg_version()
+        # dev A/B of an OLDER build of the same ABI family (scripts/ab.py: old .so vs new .so on one box): descriptor fields are only ever
+        # appended, so a library one revision behind reads a prefix of what this binding writes (entry points it lacks stay unbound: the arm
+        # must not reach them, e.g. TG_GN_EPI=0).  Never the default path.
+        compat = os.environ.get("THEATERGEN_HIP_LIB") and os.environ.get("THEATERGEN_HIP_ABI_COMPAT") == str(got)
         for name, (res, args) in SIGNATURES.items():
+            if compat and not hasattr(h, name):
+                continue
             fn = getattr(h, name)      # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        got = h.tg_version()
-        # dev A/B of an OLDER build of the same ABI family (scripts/ab.py: old .so vs new .so on one box): descriptor fields are only ever
-        # appended, so a library one revision behind reads a prefix of what this binding writes.  Never the default path.
-        compat = os.environ.get("THEATERGEN_HIP_LIB") and os.environ.get("THEATERGEN_HIP_ABI_COMPAT") == str(got)
         if got != ABI_VERSION and not compat:
             raise RuntimeError(f"theatergen_amd: {LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: "
                                "rebuild with `python -m theatergen_amd.build` (a stale library would misread descriptors)")

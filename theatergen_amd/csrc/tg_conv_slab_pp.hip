@@ -20,8 +20,29 @@
 // K order (chunk, tap, k) and the fp32 epilogue arithmetic are conv_slab_kernel's; measured outputs are bit-identical to it (the 16 x 16 x 32 MFMA evidently
 // folds a K-step's products in the same order as two 32 x 32 x 16 ones); the tests do not rely on that: they state a tolerance.
 #include "tg_gemm_common.h"
+#include <type_traits>
+#ifndef TGV_ASM_MFMA
+#define TGV_ASM_MFMA 1
+#endif
+#ifndef TGV_AW0
+#define TGV_AW0 1
+#endif
+#ifndef TGV_LEPI
+#define TGV_LEPI 0
+#endif
 
 namespace {
+
+// acc + lo * lo2 + hi * hi2 of two packed storage-dtype pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16: exact products, fp32 sum)
+template <typename T> __device__ __forceinline__ float dot2acc(unsigned a, unsigned b, float acc);
+template <> __device__ __forceinline__ float dot2acc<bf16_t>(unsigned a, unsigned b, float acc) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a), __builtin_bit_cast(bf2, b), acc, false);
+}
+template <> __device__ __forceinline__ float dot2acc<f16_t>(unsigned a, unsigned b, float acc) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), acc, false);
+}
 
 template <typename T, int WI, bool PRO>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_slab_pp_kernel(GemmParams p) {
@@ -232,13 +253,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int wave_n = wave12 & 3;                    // 80-channel column of the tile
   const int frow = lane & 15, fq = lane >> 4;
   const unsigned fkey = (unsigned)((frow >> 1) & 7);
-  const unsigned aw0 = lds0 + W_BASE + (unsigned)((wave_n * 80 + frow) * 128) + ((((unsigned)fq) ^ fkey) << 4);
-  int srow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pm = group * 64 + i * 16 + frow;
-    srow[i] = (pm / WI) * SW + pm % WI;
-  }
+  unsigned aw0 = lds0 + W_BASE + (unsigned)((wave_n * 80 + frow) * 128) + ((((unsigned)fq) ^ fkey) << 4);
+  // slab row of pixel tile i's row frow: (pm / WI) * SW + pm % WI with pm = group * 64 + i * 16 + frow  =  srow0 + a compile-time constant per i
+  int srow0 = ((group * 64 + frow) / WI) * SW + (group * 64 + frow) % WI;
+  constexpr int srow_d[4] = {0, (16 / WI) * SW + 16 % WI, (32 / WI) * SW + 32 % WI, (48 / WI) * SW + 48 % WI};
   // Fragment pipeline (inline asm reads stay where they are written; LDS returns in order).  Issue order of a phase: 4 pixel fragments of the NEXT phase,
   // then per column j: wait, 4 MFMAs, weight fragment j of the next phase.  Reads issued after w[j] of the current phase and before its use:
   // w[j+1..4] (previous phase), 4 pixel fragments, w[0..j-1] (this phase) = 8 for every j -> lgkmcnt(8); without the pixel reads (chunk boundary) 4.
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int off = (tap / 3) * SW + tap % 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned sr = (unsigned)(srow[i] + off);
+      const unsigned sr = (unsigned)(srow0 + srow_d[i] + off);
       ax[i] = lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4);
     }
   };
@@ -277,7 +295,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       __builtin_amdgcn_sched_barrier(0);
       if (!ab_nom) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xc[i]), acc[i][j]);
+        for (int i = 0; i < 4; ++i) {
+#if TGV_ASM_MFMA
+          // accumulate IN PLACE (tied operand): left to the compiler the 20 accumulator tuples get renamed from MFMA to MFMA (dst != srcC) on a full register
+          // file and the allocator ends up bouncing accumulators or fragment tuples through scratch inside the K loop
+          if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xc[i]));
+          else
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xc[i]));
+#else
+          acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xc[i]), acc[i][j]);
+#endif
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (next_w) read_w(wf[j], j, nks);
@@ -306,7 +335,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 5; ++j) read_w(wf[j], j, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
       const bool more = cc + 1 < nchunks;
-      asm volatile("" : "+v"(srow[0]), "+v"(srow[1]), "+v"(srow[2]), "+v"(srow[3]));   // per-tap addresses are recomputed, not hoisted over the chunk loop
+#if TGV_AW0
+      asm volatile("" : "+v"(srow0), "+v"(aw0));     // per-tap window / weight-stage addresses are recomputed, not hoisted over the chunk loop (and spilled)
+#else
+      asm volatile("" : "+v"(srow0));
+#endif
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // first phase (k-step 0); the second k-step's fragments come from the same window rows / weight stage
@@ -332,8 +365,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if TGV_ASM_MFMA
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the inline-asm MFMAs' results are read by the epilogue's LDS writes: the wait states the compiler would insert
+#endif
 
     // ---- epilogue: fp32 bounce through this wave's 4352 bytes of the slab region
+    // (every lane-dependent address below is derived from a LAUNDERED copy of the lane id: they are invariant across the persistent tile loop, and left to the
+    // compiler they are hoisted out of it and kept in — or spilled from and reloaded into — registers across the K loop, where 168 registers are all taken)
+    int lane_e = lane;
+#if TGV_LEPI
+    asm volatile("" : "+v"(lane_e));
+#endif
+    const int frow_e = lane_e & 15, fq_e = lane_e >> 4;
     float* scr = reinterpret_cast<float*>(smem) + wave12 * (16 * 68);
     const long mw = m0 + group * 64, nw = n0 + wave_n * 80;
     T* outp = reinterpret_cast<T*>(p.out);
@@ -343,9 +386,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float scale = p.out_scale;
     const bool part = S > 1;
     float* wsp = part ? p.ws + (long)lbid * BM * BN : nullptr;
-    // GroupNorm partial sums of the OUTPUT (tg_gemm_desc.out_gn_partials; unsplit tiles only): every lane sums the stored (rounded) values it writes, per channel
+    // GroupNorm partial sums of the OUTPUT (tg_gemm_desc.out_gn_partials; unsplit tiles only): every lane_e sums the stored (rounded) values it writes, per channel
     const bool gn = p.gn_part != nullptr && !part;
-    float gs[8], gq[8];
+    // ... per channel PAIR (GroupNorm groups are even-sized and start on even channels): one v_dot2c per pair and moment, 8 accumulators
+    float gs[4], gq[4];
+    const unsigned one2 = sizeof(T) == 2 && __builtin_bit_cast(unsigned short, from_f32<T>(1.0f)) == 0x3F80 ? 0x3F803F80u : 0x3C003C00u;
     auto finish8 = [&](const f32x4& lo, const f32x4& hi, long m, long n, const float (&bias_f)[8]) {
       if (part) {                                   // fp32 partial in tile-local order: the reduce kernel sums the splits and applies the epilogue
         float* q = wsp + (m - m0) * BN + (n - n0);
@@ -372,15 +417,20 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       *reinterpret_cast<V8*>(outp + m * p.ldc + n) = o;
       if (gn) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(o[e]); gs[e] += f; gq[e] += f * f; }
+        for (int e = 0; e < 4; ++e) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const unsigned pr = __builtin_bit_cast(u32x4, o)[e];
+          gs[e] = dot2acc<T>(pr, one2, gs[e]);
+          gq[e] = dot2acc<T>(pr, pr, gq[e]);
+        }
       }
     };
-    float* gsum = scr + 704;                         // [2][80] channel sums of this wave's 64 pixels (behind the 32 x 20 floats the last pass bounces through)
+    float* gsum = scr + 1000;                        // [2][40] channel-pair sums of this wave's 64 pixels (the last floats of the wave's 1088: behind both bounce areas)
     {
-      // channels 0-63 of the wave's 80: 16 pixels x 64 channels per pass, lane -> (row lane / 8 + 8 it, 8-channel piece lane % 8)
-      const int c = lane & 7, r0 = lane >> 3;
+      // channels 0-63 of the wave's 80: 16 pixels x 64 channels per pass, lane_e -> (row lane_e / 8 + 8 it, 8-channel piece lane_e % 8)
+      const int c = lane_e & 7, r0 = lane_e >> 3;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
       const long n = nw + c * 8;
       float bias_f[8];
 #pragma unroll
@@ -393,7 +443,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(scr + frow * 68 + 16 * j + 4 * fq) = acc[i][j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(scr + frow_e * 68 + 16 * j + 4 * fq_e) = acc[i][j];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -403,23 +453,26 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         __builtin_amdgcn_wave_barrier();
       }
-      if (gn) {                                     // the 8 lanes of a channel piece (rows r0 = lane / 8) fold in a fixed butterfly order
+      if (gn) {
+        // fold the 8 row groups (r0 = lane_e / 8) through the (free) bounce area: [r0][piece c][4 pair sums | 4 pair sums of squares], row pitch 68 floats; then
+        // lane_e L sums column L over the 8 rows in a fixed order (2 ds_write_b128 + 8 ds_read_b32 per lane_e)
+        float* red = scr + r0 * 68 + c * 8;
+        *reinterpret_cast<f32x4*>(red) = f32x4{gs[0], gs[1], gs[2], gs[3]};
+        *reinterpret_cast<f32x4*>(red + 4) = f32x4{gq[0], gq[1], gq[2], gq[3]};
+        __builtin_amdgcn_wave_barrier();
+        float a = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float a = gs[e], b = gq[e];
-          a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
-          a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-          a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-          if (r0 == 0) { gsum[c * 8 + e] = a; gsum[80 + c * 8 + e] = b; }
-        }
+        for (int r = 0; r < 8; ++r) a += scr[r * 68 + lane_e];
+        __builtin_amdgcn_wave_barrier();
+        gsum[((lane_e >> 2) & 1) * 40 + (lane_e >> 3) * 4 + (lane_e & 3)] = a;     // column = piece * 8 + kind * 4 + e  ->  gsum[kind][piece * 4 + e]
       }
     }
     {
-      // channels 64-79: two pixel tiles per pass = 32 pixels x 16 channels, lane -> (row lane / 2, 8-channel piece lane % 2)
-      const int c = lane & 1, r = lane >> 1;
+      // channels 64-79: two pixel tiles per pass = 32 pixels x 16 channels, lane_e -> (row lane_e / 2, 8-channel piece lane_e % 2)
+      const int c = lane_e & 1, r = lane_e >> 1;
       const long n = nw + 64 + c * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
       float bias_f[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias_f[e] = 0.f;
@@ -430,8 +483,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
 #pragma unroll
       for (int ip = 0; ip < 2; ++ip) {
-        *reinterpret_cast<f32x4*>(scr + frow * 20 + 4 * fq) = acc[2 * ip][4];
-        *reinterpret_cast<f32x4*>(scr + (16 + frow) * 20 + 4 * fq) = acc[2 * ip + 1][4];
+        *reinterpret_cast<f32x4*>(scr + frow_e * 20 + 4 * fq_e) = acc[2 * ip][4];
+        *reinterpret_cast<f32x4*>(scr + (16 + frow_e) * 20 + 4 * fq_e) = acc[2 * ip + 1][4];
         __builtin_amdgcn_wave_barrier();
         const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * 20 + c * 8 + 4);
@@ -439,23 +492,32 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_wave_barrier();
       }
       if (gn) {
+        // 32 rows (lane_e / 2) x 2 pieces: one shuffle folds row pairs, the 16 pair rows go through the bounce area (pitch 20), lane_e L sums column L % 16 over 4 of
+        // the 16 rows, two more shuffles join the four quarters
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float a = gs[e], b = gq[e];
-#pragma unroll
-          for (int x = 2; x < 64; x <<= 1) { a += __shfl_xor(a, x); b += __shfl_xor(b, x); }
-          if (r == 0) { gsum[64 + c * 8 + e] = a; gsum[80 + 64 + c * 8 + e] = b; }
+        for (int e = 0; e < 4; ++e) { gs[e] += __shfl_xor(gs[e], 2); gq[e] += __shfl_xor(gq[e], 2); }
+        if ((lane_e & 2) == 0) {
+          float* red = scr + (lane_e >> 2) * 20 + c * 8;
+          *reinterpret_cast<f32x4*>(red) = f32x4{gs[0], gs[1], gs[2], gs[3]};
+          *reinterpret_cast<f32x4*>(red + 4) = f32x4{gq[0], gq[1], gq[2], gq[3]};
         }
         __builtin_amdgcn_wave_barrier();
-        // channels -> groups: lane g owns group g of the wave's 80 / cpg whole groups; entry [image][64-pixel block][group] is written by this wave alone
-        const int cpg = p.gn_cpg;
-        if (lane < 80 / cpg) {
+        float a = 0.f;
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) a += scr[((lane_e >> 4) * 4 + r2) * 20 + (lane_e & 15)];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (lane_e < 16) gsum[((lane_e >> 2) & 1) * 40 + 32 + (lane_e >> 3) * 4 + (lane_e & 3)] = a;
+        __builtin_amdgcn_wave_barrier();
+        // channels -> groups: lane_e g owns group g of the wave's 80 / cpg whole groups; entry [image][64-pixel block][group] is written by this wave alone
+        const int cpg = p.gn_cpg, ppg = cpg >> 1;
+        if (lane_e < 80 / cpg) {
           float a = 0.f, b = 0.f;
-          for (int j = 0; j < cpg; ++j) { a += gsum[lane * cpg + j]; b += gsum[80 + lane * cpg + j]; }
-          const long hw = (long)p.out_h * p.out_w;
-          const long img = mw / hw, blk = (mw - img * hw) >> 6;
+          for (int j = 0; j < ppg; ++j) { a += gsum[lane_e * ppg + j]; b += gsum[40 + lane_e * ppg + j]; }
+          const int hw = p.out_h * p.out_w;
+          const int img = (int)mw / hw, blk = ((int)mw - img * hw) >> 6;
           const int groups = (int)(p.N / cpg);
-          float* o = p.gn_part + ((img * (hw >> 6) + blk) * groups + nw / cpg + lane) * 2;
+          float* o = p.gn_part + ((long)(img * (hw >> 6) + blk) * groups + nw / cpg + lane_e) * 2;
           o[0] = a;
           o[1] = b;
         }
