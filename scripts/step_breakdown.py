@@ -19,7 +19,7 @@ import re
 import statistics
 import sys
 
-SHAPED = ("gemm_glds_kernel", "pp_gemm_kernel", "pp160_gemm_kernel", "conv_slab_pp_kernel", "conv_slab_kernel", "conv_halo_kernel", "bt_gemm_kernel", "lc_gemm_kernel", "ws_gemm_kernel", "attention_kernel")
+SHAPED = ("gemm_glds_kernel", "pp_gemm_kernel", "pp160_gemm_kernel", "conv_slab_pp_kernel", "conv_slab_kernel", "conv_halo_kernel", "bt_gemm_kernel", "lc_gemm_kernel", "ws_gemm_kernel", "attention_kernel", "rc_front_kernel", "rc_linear_kernel", "rc_xattn_kernel", "rc_ff_kernel")
 
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -21,15 +21,6 @@
 // folds a K-step's products in the same order as two 32 x 32 x 16 ones); the tests do not rely on that: they state a tolerance.
 #include "tg_gemm_common.h"
 #include <type_traits>
-#ifndef TGV_ASM_MFMA
-#define TGV_ASM_MFMA 1
-#endif
-#ifndef TGV_AW0
-#define TGV_AW0 1
-#endif
-#ifndef TGV_LEPI
-#define TGV_LEPI 0
-#endif
 
 namespace {
 
@@ -296,16 +287,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (!ab_nom) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#if TGV_ASM_MFMA
           // accumulate IN PLACE (tied operand): left to the compiler the 20 accumulator tuples get renamed from MFMA to MFMA (dst != srcC) on a full register
           // file and the allocator ends up bouncing accumulators or fragment tuples through scratch inside the K loop
           if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xc[i]));
           else
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[j]), "v"(xc[i]));
-#else
-          acc[i][j] = mfma16(__builtin_bit_cast(V8, wf[j]), __builtin_bit_cast(V8, xc[i]), acc[i][j]);
-#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -335,11 +322,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 5; ++j) read_w(wf[j], j, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
       const bool more = cc + 1 < nchunks;
-#if TGV_AW0
       asm volatile("" : "+v"(srow0), "+v"(aw0));     // per-tap window / weight-stage addresses are recomputed, not hoisted over the chunk loop (and spilled)
-#else
-      asm volatile("" : "+v"(srow0));
-#endif
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // first phase (k-step 0); the second k-step's fragments come from the same window rows / weight stage
@@ -365,17 +348,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if TGV_ASM_MFMA
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the inline-asm MFMAs' results are read by the epilogue's LDS writes: the wait states the compiler would insert
-#endif
 
     // ---- epilogue: fp32 bounce through this wave's 4352 bytes of the slab region
-    // (every lane-dependent address below is derived from a LAUNDERED copy of the lane id: they are invariant across the persistent tile loop, and left to the
-    // compiler they are hoisted out of it and kept in — or spilled from and reloaded into — registers across the K loop, where 168 registers are all taken)
-    int lane_e = lane;
-#if TGV_LEPI
-    asm volatile("" : "+v"(lane_e));
-#endif
+    const int lane_e = lane;
     const int frow_e = lane_e & 15, fq_e = lane_e >> 4;
     float* scr = reinterpret_cast<float*>(smem) + wave12 * (16 * 68);
     const long mw = m0 + group * 64, nw = n0 + wave_n * 80;
