@@ -146,12 +146,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         V8 v = __builtin_bit_cast(V8, sreg[j]);
         const float a[8] = {ca0[0], ca0[1], ca0[2], ca0[3], ca1[0], ca1[1], ca1[2], ca1[3]};
         const float d[8] = {cd0[0], cd0[1], cd0[2], cd0[3], cd1[0], cd1[1], cd1[2], cd1[3]};
-        if (silu) {                                 // uniform: one branch per piece instead of a select per element (the loaders' VALU work shares the SIMDs' issue with the MFMAs)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(silu_f(to_f32<T>(v[e]) * a[e] + d[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32<T>(v[e]) * a[e] + d[e]);
+        for (int e = 0; e < 8; ++e) {
+          const float f = to_f32<T>(v[e]) * a[e] + d[e];
+          v[e] = from_f32<T>(silu ? silu_f(f) : f);
         }
         u32x4 r = __builtin_bit_cast(u32x4, v);
         const bool ok = spix[j] >= 0;
