@@ -84,7 +84,9 @@ def build_model(plan, dtype, device, num_tokens=4, scale=0.4):
     from theatergen_amd.pipelines import SDPipe
     from theatergen_amd.unet import UNet2DConditionModel
     cfg = config.PLANS[plan]()
-    sd = weights.random_unet_state_dict(cfg, seed=0)
+    # weights drawn ON the device from the seed (every rank of a multi-GPU launch gets the same values from its own generator: nothing to broadcast, no host RNG);
+    # the module tree is built on the meta device (theatergen_amd.unet._load_on_meta): start-up ~45 s -> ~2 s per rank
+    sd = weights.random_unet_state_dict(cfg, seed=0, device=device)
     unet = UNet2DConditionModel.from_state_dict(cfg, sd, device=device, dtype=dtype, num_tokens=num_tokens, ip_scale=scale)
     adapter = IPAdapter(SDPipe(unet), None, None, device, num_tokens=num_tokens)
     adapter.set_scale(scale)
@@ -357,7 +359,7 @@ def cpu_baseline_leg(cfg, sd, dtype, n_calls, ddim_steps, loop_steps=0):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, cfg.in_channels, 64, 64, generator=g)
     enc = torch.randn(2, 81, cfg.cross_attention_dim, generator=g) * 0.5
-    sd32 = {k: v.float() for k, v in sd.items()}
+    sd32 = {k: v.float().cpu() for k, v in sd.items()}
     with torch.no_grad():
         ou.unet_forward(cfg, sd32, x, 981, enc, ip_scale=0.4, num_tokens=4)      # warm-up
         t0 = time.perf_counter()

@@ -119,20 +119,23 @@ def unet_param_shapes(cfg: UNetConfig, ip_adapter=True):
     return s
 
 
-def _fill(shapes, seed, dtype=torch.float32, norm_jitter=0.1):
-    g = torch.Generator().manual_seed(seed)
+def _fill(shapes, seed, dtype=torch.float32, norm_jitter=0.1, device=None):
+    """``device``: draw on that device with ITS generator (bench start-up: no host RNG, and every rank of a multi-GPU launch draws the same values from the same
+    seed on its own GPU — nothing to broadcast); None = the host generator (tests, goldens: values unchanged)."""
+    g = torch.Generator(device=device).manual_seed(seed) if device is not None else torch.Generator().manual_seed(seed)
+    kwd = {"device": device} if device is not None else {}
     sd = OrderedDict()
     for name, shape in shapes.items():
         leaf = name.rsplit(".", 2)[-2] if name.count(".") else name
         is_norm = ("norm" in leaf) and len(shape) == 1
         if name == "latents":
-            sd[name] = (torch.randn(shape, generator=g) / shape[-1] ** 0.5).to(dtype)
+            sd[name] = (torch.randn(shape, generator=g, **kwd) / shape[-1] ** 0.5).to(dtype)
             continue
         if is_norm:
             if name.endswith(".weight"):
-                sd[name] = (1.0 + norm_jitter * torch.randn(shape, generator=g)).to(dtype)
+                sd[name] = (1.0 + norm_jitter * torch.randn(shape, generator=g, **kwd)).to(dtype)
             else:
-                sd[name] = (norm_jitter * torch.randn(shape, generator=g)).to(dtype)
+                sd[name] = (norm_jitter * torch.randn(shape, generator=g, **kwd)).to(dtype)
             continue
         if name.endswith(".weight"):
             fan_in = 1
@@ -144,14 +147,14 @@ def _fill(shapes, seed, dtype=torch.float32, norm_jitter=0.1):
             for d in (wshape[1:] if wshape is not None else shape):
                 fan_in *= d
         bound = 1.0 / math.sqrt(max(fan_in, 1))
-        sd[name] = ((torch.rand(shape, generator=g) * 2 - 1) * bound).to(dtype)
+        sd[name] = ((torch.rand(shape, generator=g, **kwd) * 2 - 1) * bound).to(dtype)
     return sd
 
 
-def random_unet_state_dict(cfg: UNetConfig, seed=0, ip_adapter=True, dtype=torch.float32):
+def random_unet_state_dict(cfg: UNetConfig, seed=0, ip_adapter=True, dtype=torch.float32, device=None):
     """Seeded nn.Linear/nn.Conv2d-style init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); norm affine jittered
     around (1, 0) so a wrong gamma/beta shows up in parity tests."""
-    return _fill(unet_param_shapes(cfg, ip_adapter), seed, dtype)
+    return _fill(unet_param_shapes(cfg, ip_adapter), seed, dtype, device=device)
 
 
 def resampler_param_shapes(dim, depth, dim_head, heads, num_queries, embedding_dim, output_dim, ff_mult=4,
