@@ -273,11 +273,8 @@ class ControlNetModel(nn.Module):
 
     @classmethod
     def from_state_dict(cls, config, state_dict, device="cuda", dtype=torch.bfloat16, cn_processors=True, num_tokens=4, **kw):
-        m = cls(config, **kw)
-        missing, unexpected = m.load_state_dict(state_dict, strict=False)
-        if unexpected or missing:
-            raise RuntimeError(f"state dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
-        m = m.to(device=device, dtype=dtype)
+        from .unet import _load_on_meta
+        m = _load_on_meta(lambda: cls(config, **kw), state_dict, device, dtype)
         if cn_processors:
             install_cn_processors(m, num_tokens)
         return m
