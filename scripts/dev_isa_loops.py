@@ -47,8 +47,28 @@ def main():
             ops = [o.strip() for o in body[j].split(";")[0].split(None, 1)[1].split(",")]
             if len(ops) >= 4 and ops[3] != "0" and ops[0] != ops[3]:
                 ren += 1
+        # accumulator registers = destinations of the loop's MFMAs; any OTHER instruction of the loop that names one of them (a copy at the back edge, a spill) is
+        # a hazard when the MFMAs are inline asm (no wait states inserted), and a slow loop either way
+        def regs(tok):
+            m = re.match(r"v\[(\d+):(\d+)\]", tok)
+            if m:
+                return set(range(int(m.group(1)), int(m.group(2)) + 1))
+            m = re.match(r"v(\d+)$", tok)
+            return {int(m.group(1))} if m else set()
+        accs = set()
+        for l in loop:
+            if "v_mfma" in l:
+                accs |= regs(l.split(";")[0].split(None, 1)[1].split(",")[0].strip())
+        touched = 0
+        for l in loop:
+            t = l.split(";")[0].strip()
+            if not t or t.startswith((".", ";")) or "v_mfma" in t or ":" in t.split()[0]:
+                continue
+            ops = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+            if any(regs(o) & accs for o in ops):
+                touched += 1
         ss = next((l.split(":")[1].strip() for l in lines[e:e + 400] if "ScratchSize" in l), "?")
-        print(f"{name[:100]:100s} loop {len(loop):5d} lines, mfma {len(mf):4d} (renamed {ren:3d}), scratch in loop {len(sc):3d} (wide {len(wide):2d}), kernel scratch {ss} B")
+        print(f"{name[:100]:100s} loop {len(loop):5d} lines, mfma {len(mf):4d} (renamed {ren:3d}), scratch in loop {len(sc):3d} (wide {len(wide):2d}), accumulators touched outside MFMAs {touched:3d}, kernel scratch {ss} B")
 
 
 if __name__ == "__main__":

@@ -240,6 +240,73 @@ def check_resources(res):
     return bad
 
 
+# ---- inline-asm MFMA loops (round 6) ----------------------------------------------------------------------------------------
+# Kernels whose K loop issues MFMAs as inline asm with a tied accumulator (tg_conv_slab_pp.hip) are opaque to the compiler's hazard recogniser: if the allocator
+# copies or spills an accumulator inside the loop (it did, in one instance, one unrelated edit away: v_mov_b64 of registers an MFMA had just written, with s_nop 0),
+# the values are read before the matrix pipe has written them and the output is silently wrong on some boxes.  The check disassembles the object and refuses any
+# instruction between a kernel's first and last MFMA — other than an MFMA — that names a register some MFMA in that range writes.
+ASM_MFMA_KERNELS = {"tg_conv_slab_pp.o": "conv_slab_pp_kernel"}
+
+
+def check_mfma_loops(verbose=True):
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin")
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    bad = []
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    for obj, sub in ASM_MFMA_KERNELS.items():
+        o = os.path.join(OBJ, obj)
+        if not os.path.exists(o):
+            continue
+        with tempfile.TemporaryDirectory(prefix="tg_isa_") as td:
+            fb, co = os.path.join(td, "k.fatbin"), os.path.join(td, "k.co")
+            subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, o], check=True)
+            subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH, "--output=" + co], check=True)
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        kern, body, kernels = None, [], []
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+            if m:
+                if kern is not None:
+                    kernels.append((kern, body))
+                kern, body = m.group(1), []
+            elif kern is not None:
+                body.append(line.split("//")[0].strip())
+        if kern is not None:
+            kernels.append((kern, body))
+        seen = 0
+        for name, body in kernels:
+            if sub not in name:
+                continue
+            mf = [i for i, t in enumerate(body) if t.startswith("v_mfma")]
+            if not mf:
+                continue
+            seen += 1
+            loop = body[mf[0]:mf[-1] + 1]
+            accs = set()
+            for t in loop:
+                if t.startswith("v_mfma"):
+                    accs |= regs(t.split(None, 1)[1].split(",")[0].strip())
+            hits = [t for t in loop if t and not t.startswith("v_mfma") and any(regs(x) & accs for x in re.findall(r"v\[\d+:\d+\]|v\d+", t))]
+            if hits:
+                bad.append(f"{_pretty(name)}: {len(hits)} instruction(s) inside the inline-asm MFMA loop touch an accumulator register, e.g. `{hits[0]}`")
+        if verbose:
+            print(f"[mfma-loops] {obj}: {seen} kernels checked", flush=True)
+        if seen == 0:
+            bad.append(f"{obj}: no kernel matching {sub!r} with MFMAs found (the check would be vacuous)")
+    return bad
+
+
 def write_resources(check=False, verbose=True):
     import json
     res = kernel_resources(verbose=verbose)
@@ -253,7 +320,7 @@ def write_resources(check=False, verbose=True):
             json.dump({"flags": FLAGS, "built_from_commit_or_later": commit, "gates": HOT_GATES, "kernels": dict(sorted(res.items()))}, f, indent=1)
     except OSError as e:                                         # read-only tree: the report is optional, the check below is not
         print(f"[resources] cannot write {RESOURCES_JSON}: {e}", flush=True)
-    bad = check_resources(res)
+    bad = check_resources(res) + check_mfma_loops(verbose=verbose)
     for b in bad:
         print("[resources] GATE:", b, flush=True)
     if check and bad:

@@ -159,7 +159,7 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     elif kk.value == 6:
         kname = f"gemm_glds_kernel<plain+ln,{tm.value}x{tn.value}>"
     elif kk.value == 7:
-        kname = f"pp_gemm_kernel<{tm.value}x{tn.value}" + (",geglu" if geglu else "") + (",ln" if ln is not None else "") + ">"
+        kname = ("pp160_gemm_kernel" if tn.value == 160 else "pp_gemm_kernel") + f"<{tm.value}x{tn.value}" + (",geglu" if geglu else "") + (",ln" if ln is not None else "") + ">"
     else:
         kname = f"gemm_glds_kernel<{'conv' if mode == 1 else 'plain'},{tm.value}x{tn.value}>"
     _gemm_profile.append(dict(kernel=kname, splits=sp.value,
