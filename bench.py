@@ -922,7 +922,7 @@ def drop_in_leg(args):
     cfg, sd, unet, adapter = build_model("sd15", dtype, dev, num_tokens=T)
     ctx = cfg.cross_attention_dim
     shared = story.shared_conditioning(ctx, T, dtype, dev)
-    jobs = story.story_jobs(0)[:3]
+    jobs = story.story_jobs(0)[:5]                    # one warm-up character + four timed
     img_tok = story.character_image_tokens(sorted({j.char_id for j in jobs}), ctx, T, dtype, dev)
     cidx = {c: i for i, c in enumerate(sorted({j.char_id for j in jobs}))}
     steps = args.ddim_steps
