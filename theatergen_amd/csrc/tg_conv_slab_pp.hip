@@ -255,13 +255,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   int srow0 = ((group * 64 + fpix) / WI) * SW + (group * 64 + fpix) % WI;
   constexpr int srow_d[4] = {0, (16 / WI) * SW + 16 % WI, (32 / WI) * SW + 32 % WI, (48 / WI) * SW + 48 % WI};
   // Fragment pipeline (inline asm reads stay where they are written; LDS returns in order): see `phase` below for the issue order and the counted waits.
-  unsigned ax[4], aw;
+  // Window addresses: pixel tiles whose slab rows are 16 apart share the swizzle key (it has period 16 rows) and differ by 2048 bytes — an immediate of the read.
+  // 64-wide maps: ONE address per tap (tiles at +0 / 16 / 32 / 48 rows); 32-wide: two (rows +0 / 16 and +34 / 50); 16-wide: four.  Every address instruction saved is
+  // matrix-pipe time (profiles/r6_mfma_exp_overlap.json: a VALU instruction takes 1-2 cycles of it along).
+  constexpr int NAX = WI == 64 ? 1 : (WI == 32 ? 2 : 4);
+  unsigned ax[NAX], aw;
   auto set_x = [&](int tap) {
     const int off = (tap / 3) * SW + tap % 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned sr = (unsigned)(srow0 + srow_d[i] + off);
-      ax[i] = lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4);
+    for (int b = 0; b < NAX; ++b) {
+      const unsigned sr = (unsigned)(srow0 + srow_d[b * (4 / NAX)] + off);
+      ax[b] = lds0 + sr * 128u + ((((sr >> 1) & 7u) ^ (unsigned)fq) << 4);
     }
   };
   auto set_w = [&](int tap) {
@@ -270,8 +274,24 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
   auto read_x = [&](u32x4 (&xf)[4], int ks) {
     const unsigned kx = (unsigned)ks << 6;
+    if constexpr (WI == 64) {
+      static_assert(srow_d[1] == 16 && srow_d[2] == 32 && srow_d[3] == 48, "64-wide: pixel tiles 16 slab rows apart");
+      const unsigned a = ax[0] ^ kx;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xf[0]) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[1]) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(xf[2]) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(xf[3]) : "v"(a));
+    } else if constexpr (WI == 32) {
+      static_assert(srow_d[1] == 16 && srow_d[3] == srow_d[2] + 16, "32-wide: pixel tiles pair up 16 slab rows apart");
+      const unsigned a = ax[0] ^ kx, b = ax[1] ^ kx;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xf[0]) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[1]) : "v"(a));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xf[2]) : "v"(b));
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[3]) : "v"(b));
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[i]) : "v"(ax[i] ^ kx));
+      for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[i]) : "v"(ax[i] ^ kx));
+    }
   };
   auto read_w = [&](u32x4& wf, int j, int ks) {
     const unsigned a = aw ^ ((unsigned)ks << 6);
