@@ -111,7 +111,25 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(GemmParams p) {
       }
     }
   };
+  // weight tile requests of a column tile wholly inside N: wave-uniform base (weight pointer + the K-step's column offset) + this lane's constant 32-bit byte offset
+  // (tg_gemm_glds.h, round 6: no 64-bit pointer arithmetic / zero-page select per request in the K loop)
+  const unsigned lds_sw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sW;
+  const bool fastw = n0 + BN <= p.N && (long)p.N * p.K * (long)sizeof(T) < (1L << 31);
+  unsigned voffw[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) voffw[j] = (unsigned)(((n0 + (j * NW + wave) * 8 + lrow) * p.K + chunk * 8) * (long)sizeof(T));
+  auto dma_s = [&](const T* base, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_byte_addr) : "memory");
+  };
   auto issue_w = [&](int cc, int tap, int buf) {
+    if (fastw) {
+      const T* wb = Wp + ((long)tap * ctot + cc * BK);
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) dma_s(wb, voffw[j], lds_sw + (unsigned)((buf * BN * BK + (j * NW + wave) * 8 * BK) * sizeof(T)));
+      return;
+    }
     const long kc = (long)tap * ctot + cc * BK + chunk * 8;
     T* dw = sW + buf * BN * BK;
 #pragma unroll

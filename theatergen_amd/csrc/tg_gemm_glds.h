@@ -147,8 +147,38 @@ void gemm_glds_kernel(GemmParams p) {
                                      (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
   };
 
+  // FAST DMA ADDRESSING (round 6): a plain single-source GEMM tile that lies wholly inside M x N with K a multiple of the K-tile needs no per-request pointer
+  // arithmetic — the source of a request is a wave-uniform base (operand pointer + the K-tile's offset: SGPR pair, scalar add) plus this lane's constant 32-bit byte
+  // offset (its row and swizzled chunk).  The generic path below forms a 64-bit pointer and a zero-page select per request: 45 of the 66 VALU instructions of a
+  // 128 x 160 K-tile, and every VALU instruction takes matrix-pipe time with it (profiles/r6_mfma_exp_overlap.json).
+  const unsigned lds_sx = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds_sw = lds_sx + (unsigned)(STAGES * BM * BKT * sizeof(T));
+  const bool fastdma = !CONV && A1 == nullptr && p.a_rpb <= 0 && p.K % BKT == 0 && m0 + BM <= p.M && n0 + BN <= p.N &&
+                       (long)p.N * p.ldw * (long)sizeof(T) < (1L << 31) && (long)p.M * p.lda * (long)sizeof(T) < (1L << 31);
+  unsigned voffw[WJ], voffx[XJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) voffw[j] = (unsigned)(((n0 + (j * NW + wave) * RPI + lrow) * p.ldw + chunk * 8) * (long)sizeof(T));
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) voffx[j] = (unsigned)(((m0 + (j * NW + wave) * RPI + lrow) * p.lda + chunk * 8) * (long)sizeof(T));
+  auto dma_s = [&](const T* base, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_byte_addr) : "memory");
+  };
+
   auto issue_tile = [&](int kt, int buf) {
     const long k0 = (long)kt * BKT;
+    if constexpr (!CONV) {
+      if (fastdma) {
+        const T* wb = Wp + k0;
+        const T* xb = A0 + k0;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) dma_s(wb, voffw[j], lds_sw + (unsigned)((buf * BN * BKT + (j * NW + wave) * RPI * BKT) * sizeof(T)));
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) dma_s(xb, voffx[j], lds_sx + (unsigned)((buf * BM * BKT + (j * NW + wave) * RPI * BKT) * sizeof(T)));
+        return;
+      }
+    }
     const long kc = k0 + chunk * 8;
     const bool kok = kc < p.K;
     T* dx = sX + buf * BM * BKT;
