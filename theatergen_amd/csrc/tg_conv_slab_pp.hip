@@ -95,18 +95,21 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const T* zero = reinterpret_cast<const T*>(tg_zero_page);
     const float* coef = reinterpret_cast<const float*>(p.a_coef);
     const int wchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-    auto dma = [&](const T* src, unsigned lds_byte_addr) {
+    // weight requests: wave-uniform base (weight pointer + the tile's first row + the K-step's column offset + 32 rows per request: scalar adds) + this lane's
+    // constant 32-bit byte offset (its row of the 8-row piece and its swizzled chunk) — no 64-bit VALU pointer arithmetic in the K loop
+    auto dma_s = [&](const T* base, unsigned voff, unsigned lds_byte_addr) {
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(lds_byte_addr) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_byte_addr) : "memory");
     };
-    const T* wlane = nullptr;
+    const unsigned wvoff = (unsigned)((((long)wave * 8 + (lane >> 3)) * p.K + wchunk * 8) * (long)sizeof(T));
+    const T* wtile = nullptr;                         // Wp + n0 * K (wave-uniform, per tile)
     int cfirst = 0, nchunks = 0, nkt = 0;
     auto issue_w = [&](int cc, int tap, int stage) {
-      const T* src = wlane + ((long)tap * ctot + cc * BK);
+      const T* src = wtile + ((long)tap * ctot + cc * BK);
       const unsigned dst = lds0 + W_BASE + (unsigned)stage * WST_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) dma(src + (long)j * 32 * p.K, dst + (unsigned)j * 4096u);
+      for (int j = 0; j < WJ; ++j) dma_s(src + (long)j * 32 * p.K, wvoff, dst + (unsigned)j * 4096u);
     };
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const unsigned sdst = (unsigned)tid * 16u;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI;
         spix[j] = ok ? (img * H + iy) * WI + ix : -1;
       }
-      wlane = Wp + (n0 + wave * 8 + (lane >> 3)) * p.K + wchunk * 8;
+      wtile = Wp + n0 * p.K;
     };
     auto prologue = [&](int v) {
       setup_tile(v);
