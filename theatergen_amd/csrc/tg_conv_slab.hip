@@ -483,14 +483,17 @@ int tg_conv_slab_pp_launch(const tg_gemm_desc* d, const void* params, int splits
 // Called by tg_gemm.hip's planner (not part of the C ABI); GemmParams arrives filled except for the tile bookkeeping.  With
 // splits > 1 the caller runs the reduce kernel over the tiles_m * tiles_n tail tiles of `splits` partials each.
 // TG_SLAB_PP (dev A/B knob): 0 keeps every layer on conv_slab_kernel (one compute wave per SIMD), 1 = the two-waves-per-SIMD kernel on the 64-wide
-// maps only, 2 (default) = on the 32- and 16-wide maps as well.  Isolated launches (scripts/dev_slab_pp.py): 64 x 64 layers 4-6 % faster, 32 x 32 equal,
+// maps only, 2 = on the 32- and 16-wide maps as well, 3 (default) = also on the 64 / 32 / 16-wide PATCH tiles of wider maps.  Isolated launches (scripts/dev_slab_pp.py): 64 x 64 layers 4-6 % faster, 32 x 32 equal,
 // 16 x 16 (split tiles) 5-10 % slower; under graph replay, same box, interleaved (profiles/r6_ab_slab2w.json): 864.3 -> 859.3 (mode 1) -> 855.3 ms per
 // story (mode 2, +1.05 %): the whole-step evidence decides.
 bool tg_conv_slab_is_pp(const tg_gemm_desc* d, int patch_pwl, int patch_np, int epi_lds) {
   const char* e = getenv("TG_SLAB_PP");
-  const int mode = e == nullptr ? 2 : (int)strtol(e, nullptr, 0);
-  const bool w_ok = d->out_w == 64 || (mode >= 2 && (d->out_w == 32 || d->out_w == 16));
-  return mode >= 1 && w_ok && patch_pwl == 0 && patch_np == 1 && epi_lds && d->in_w == d->out_w;
+  const int mode = e == nullptr ? 3 : (int)strtol(e, nullptr, 0);
+  // tile width: the whole row, or (round 6, TG_SLAB_PP >= 3 = default) one patch of a wider map (SD-2.1's 96 / 48-wide, SDXL's 128-wide levels)
+  const int pw = patch_pwl > 0 ? (1 << patch_pwl) : d->out_w;
+  if (patch_pwl > 0 && mode < 3) return false;
+  const bool w_ok = pw == 64 || (mode >= 2 && (pw == 32 || pw == 16));
+  return mode >= 1 && w_ok && patch_np == 1 && epi_lds && d->in_w == d->out_w;
 }
 
 int tg_conv_slab_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {

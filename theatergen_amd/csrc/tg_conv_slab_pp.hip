@@ -35,7 +35,10 @@ template <> __device__ __forceinline__ float dot2acc<f16_t>(unsigned a, unsigned
   return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), acc, false);
 }
 
-template <typename T, int WI, bool PRO>
+// PATCH (own instantiations, round 6): the tile is one WI-wide patch of a wider map (image width p.in_w a multiple of WI: SD-2.1's 96 = 3 x 32 and 48 = 3 x 16, SDXL's
+// 128 = 2 x 64; patches numbered image-major / patch-row / patch-column like tg_gemm_common.h: patch_token) — the window's left / right halo columns are then real
+// neighbours and the epilogue's rows are not contiguous tokens.  The whole-row instances carry none of it (their register allocation is the measured one).
+template <typename T, int WI, bool PRO, bool PATCH>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_slab_pp_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 320;
   constexpr int TH = BM / WI, SW = WI + 2, SROWS = TH + 2, SLAB = SROWS * SW, SJ = (SLAB + 31) / 32;
@@ -173,6 +176,20 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       cfirst = sp * cps;
       nchunks = nchunks_all - cfirst < cps ? nchunks_all - cfirst : cps;
       nkt = nchunks * 9;
+      if constexpr (PATCH) {
+        const int IW = p.in_w, ppr = IW / WI, tpi = (H / TH) * ppr;
+        img = tile_m / tpi;
+        const int rem = tile_m - img * tpi, prow = rem / ppr;
+        const int y0 = prow * TH, x0 = (rem - prow * ppr) * WI;
+#pragma unroll
+        for (int j = 0; j < SJ; ++j) {
+          const int sr = (tid >> 3) + 32 * j;
+          const int sy = sr / SW, sx = sr - sy * SW;
+          const int iy = y0 - 1 + sy, ix = x0 + sx - 1;
+          const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < IW;
+          spix[j] = ok ? (img * H + iy) * IW + ix : -1;
+        }
+      } else {
       const int tpi = H / TH;                       // whole-row tiles: TH image rows per tile
       img = tile_m / tpi;
       const int y0 = (tile_m - img * tpi) * TH;
@@ -183,6 +200,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int iy = y0 - 1 + sy, ix = sx - 1;
         const bool ok = sr < SLAB && iy >= 0 && iy < H && ix >= 0 && ix < WI;
         spix[j] = ok ? (img * H + iy) * WI + ix : -1;
+      }
       }
       wtile = Wp + n0 * p.K;
     };
@@ -422,9 +440,20 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ... per channel PAIR (GroupNorm groups are even-sized and start on even channels): one v_dot2c per pair and moment, 8 accumulators
     float gs[4], gq[4];
     const unsigned one2 = sizeof(T) == 2 && __builtin_bit_cast(unsigned short, from_f32<T>(1.0f)) == 0x3F80 ? 0x3F803F80u : 0x3C003C00u;
+    // PATCH: token of tile row lr = row lr / WI, column x0 + lr % WI of the patch (whole-row tiles: m0 + lr)
+    long tok0 = 0;
+    int IWe = WI;
+    if constexpr (PATCH) {
+      IWe = p.in_w;
+      const int ppr_e = IWe / WI, tpi_e = (p.in_h / TH) * ppr_e;
+      const int img_e = tile_m / tpi_e, rem_e = tile_m - img_e * tpi_e, prow_e = rem_e / ppr_e;
+      tok0 = ((long)img_e * p.in_h + prow_e * TH) * IWe + (rem_e - prow_e * ppr_e) * WI;
+    }
     auto finish8 = [&](const f32x4& lo, const f32x4& hi, long m, long n, const float (&bias_f)[8]) {
+      const long lr_ = m - m0;                       // row of the tile
+      if constexpr (PATCH) m = tok0 + (lr_ / WI) * IWe + lr_ % WI;
       if (part) {                                   // fp32 partial in tile-local order: the reduce kernel sums the splits and applies the epilogue
-        float* q = wsp + (m - m0) * BN + (n - n0);
+        float* q = wsp + lr_ * BN + (n - n0);
         *reinterpret_cast<f32x4*>(q) = lo;
         *reinterpret_cast<f32x4*>(q + 4) = hi;
         return;
@@ -559,7 +588,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef SLAB_BAR
 }
 
-template <typename T, int WI, bool PRO>
+template <typename T, int WI, bool PRO, bool PATCH>
 int launch_slab_pp(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t st) {
   constexpr int BM = 128, TH = BM / WI, SLAB = (TH + 2) * (WI + 2), SJ = (SLAB + 31) / 32;
   constexpr size_t slab = (size_t)SJ * 32 * 128, scratch = 8 * 16 * 68 * 4;
@@ -574,7 +603,7 @@ int launch_slab_pp(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t 
   p.slab_order = ((long)d->N * d->K > (long)d->M * (d->K / 9) && !(p.flags & 8192)) ? 1 : 0;
   long grid = tiles_m * tiles_n * splits;
   if (grid > 256) grid = 256;
-  auto k = conv_slab_pp_kernel<T, WI, PRO>;
+  auto k = conv_slab_pp_kernel<T, WI, PRO, PATCH>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)attr;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(768), lds, st, p);
@@ -584,20 +613,24 @@ int launch_slab_pp(const tg_gemm_desc* d, GemmParams p, int splits, hipStream_t 
 
 template <typename T>
 int launch_slab_pp_dtype(const tg_gemm_desc* d, const GemmParams& p, int splits, hipStream_t st) {
-  const bool pro = d->a_coef != nullptr;
+  const bool pro = d->a_coef != nullptr, patch = p.patch_pwl > 0;
+  const int pw = patch ? (1 << p.patch_pwl) : d->out_w;                 // tile width: the whole row or one patch
 #define TG_SPP_CASE(W) \
-  if (d->out_w == W) return pro ? launch_slab_pp<T, W, true>(d, p, splits, st) : launch_slab_pp<T, W, false>(d, p, splits, st);
+  if (pw == W) {                                                                                                                      \
+    if (patch) return pro ? launch_slab_pp<T, W, true, true>(d, p, splits, st) : launch_slab_pp<T, W, false, true>(d, p, splits, st);    \
+    return pro ? launch_slab_pp<T, W, true, false>(d, p, splits, st) : launch_slab_pp<T, W, false, false>(d, p, splits, st);             \
+  }
   TG_SPP_CASE(64)
   TG_SPP_CASE(32)
   TG_SPP_CASE(16)
 #undef TG_SPP_CASE
-  tg_set_error("tg_gemm conv: no ping-pong slab kernel for width %d", d->out_w);
+  tg_set_error("tg_gemm conv: no ping-pong slab kernel for tile width %d", pw);
   return TG_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// Called by tg_conv_slab.hip (not part of the C ABI) for whole-row tiles (patch_pwl == 0, one patch per tile) with 16-byte aligned epilogue operands.
+// Called by tg_conv_slab.hip (not part of the C ABI) for tiles of one 64 / 32 / 16-wide patch (the whole row, or a patch of a wider map) with 16-byte aligned epilogue operands.
 int tg_conv_slab_pp_launch(const tg_gemm_desc* d, const void* params, int splits, void* stream) {
   const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -149,10 +149,11 @@ def gemm(a0, w, M, N, K, *, mode=0, a1=None, c0=None, c1=0, conv=None, bias=None
     if kk.value == 2:
         kname = "conv_halo_kernel<128x128>"
     elif kk.value == 4:
-        # round 6: whole-row tiles of the 64 / 32 / 16-wide maps run on conv_slab_pp_kernel (csrc/tg_conv_slab.hip: TG_SLAB_PP, default 2)
-        spp = os.environ.get("TG_SLAB_PP", "2")
+        # round 6: tiles of one 64 / 32 / 16-wide patch — the whole row or a patch of a wider map — run on conv_slab_pp_kernel (csrc/tg_conv_slab.hip: TG_SLAB_PP, default 3)
+        spp = os.environ.get("TG_SLAB_PP", "3")
         ow = int(conv[4]) if conv is not None else 0
-        two_wave = (ow == 64 and spp != "0") or (ow in (16, 32) and spp not in ("0", "1"))
+        pw = ow if ow in (16, 32, 64) else (64 if ow % 64 == 0 else 32 if ow % 32 == 0 else 16 if ow % 16 == 0 else 8)
+        two_wave = ((pw == 64 and spp != "0") or (pw in (16, 32) and spp not in ("0", "1"))) and (pw == ow or spp not in ("0", "1", "2"))
         kname = ("conv_slab_pp_kernel" if two_wave and int(conv[2]) == ow else "conv_slab_kernel") + f"<{tm.value}x{tn.value}>" + ("+gn" if a_coef is not None else "")
     elif kk.value == 3:
         kname = f"bt_gemm_kernel<{tm.value}x{tn.value}>"
