@@ -795,3 +795,15 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_inline_asm_mfma_loops_leave_accumulators_alone():
+    """round 6: kernels whose K loop issues MFMAs as inline asm (tied accumulators) are opaque to the compiler's hazard recogniser; the build gate disassembles the
+    object and refuses any other instruction inside the loop that names an accumulator register (an allocator copy / spill there reads values the matrix pipe has
+    not written yet).  Runs on the objects the build left behind; skipped on a tree that was never built."""
+    import os
+    from theatergen_amd import build
+    objs = [os.path.join(build.OBJ, o) for o in build.ASM_MFMA_KERNELS]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("no build objects in this tree")
+    assert build.check_mfma_loops(verbose=False) == []
