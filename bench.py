@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md (6.3 TB/s achievable)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--char-batch", type=int, default=8, help="character images denoised together (8 = one whole story)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--streams", type=int, default=1,
